@@ -1,0 +1,596 @@
+"""CPU oracle for the Flux.2 denoise + VAE-decode hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product path (the package
+`flux-2-swift-mlx_amd/`, `libflux2mi.so`) may import, call or link this file;
+only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
+`bench.py` use it, and only as the checker.
+
+What it is: a torch-CPU float32, eager, functional restatement of the Swift
+reference (VincentGourbin/flux-2-swift-mlx @ v2.4.0), one function per row of
+SURVEY.md §8(a).  Every function cites the reference file:line it follows
+(paths relative to the reference's `Sources/`).
+
+PARITY STATUS: **parity unpinned** for the floating-point tensors (DiT forward,
+SDPA, RoPE values, VAE decode, seeded noise).  The reference arithmetic lives in
+the un-vendored dependency `ml-explore/mlx-swift` exact 0.31.6 (mlx core
+0.31.1, `Package.swift:23`), the reference is Swift/Metal and cannot be built
+or imported in this environment, and its own XCTest suite holds no numeric
+golden vector for this path.  What IS pinned: the
+structural/known-answer facts the reference's tests assert (scheduler counts
+and end points, strength slicing, custom-sigma terminal append, position-ID
+layout, pack/unpack shapes, dimension rounding, mask packing sums) — see
+`tests/test_oracle_structural.py`, which cites each XCTest it mirrors.
+
+Numerics: the reference runs fp16 weights x fp32 activations.  The
+oracle runs everything in fp32 on the weights it is handed (tests hand it
+bf16-rounded values so the GPU sees identical weights).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+f32 = np.float32
+
+# ---------------------------------------------------------------------------
+# Model presets (Flux2Core/Configuration/Flux2Config.swift:258-329,
+# Flux2Core/Configuration/VAEConfig.swift:44-81)
+# ---------------------------------------------------------------------------
+
+DIT_PRESETS = {
+    #            d     H   nd  ns   J     guidance
+    "klein-4b": dict(dim=3072, heads=24, n_double=5, n_single=20, joint_dim=7680, guidance=False),
+    "klein-9b": dict(dim=4096, heads=32, n_double=8, n_single=24, joint_dim=12288, guidance=False),
+    "dev": dict(dim=6144, heads=48, n_double=8, n_single=48, joint_dim=15360, guidance=True),
+    # tiny config for kernel-level parity (head_dim must stay 128)
+    "tiny": dict(dim=256, heads=2, n_double=1, n_single=2, joint_dim=384, guidance=False),
+    "tiny-g": dict(dim=256, heads=2, n_double=1, n_single=1, joint_dim=384, guidance=True),
+}
+HEAD_DIM = 128
+ROPE_AXES = (32, 32, 32, 32)
+ROPE_THETA = 2000.0
+IN_CHANNELS = 128
+
+VAE_PRESETS = {
+    "standard": dict(channels=(128, 256, 512, 512), latent=32, groups=32, layers_per_block=2),
+    "small": dict(channels=(96, 192, 384, 384), latent=32, groups=32, layers_per_block=2),
+    "tiny": dict(channels=(32, 64, 64, 64), latent=32, groups=32, layers_per_block=2),
+}
+
+
+# ---------------------------------------------------------------------------
+# a4  scheduler — Flux2Core/Scheduler/FlowMatchEulerScheduler.swift
+# ---------------------------------------------------------------------------
+
+def compute_empirical_mu(image_seq_len: int, num_steps: int) -> np.float32:
+    """FlowMatchEulerScheduler.swift:9-28 (all arithmetic in Swift `Float` = f32)."""
+    a1, b1 = f32(8.73809524e-05), f32(1.89833333)
+    a2, b2 = f32(0.00016927), f32(0.45666666)
+    n = f32(image_seq_len)
+    if image_seq_len > 4300:
+        return f32(a2 * n + b2)
+    m_200 = f32(a2 * n + b2)
+    m_10 = f32(a1 * n + b1)
+    a = f32(f32(m_200 - m_10) / f32(190.0))
+    b = f32(m_200 - f32(f32(200.0) * a))
+    return f32(f32(a * f32(num_steps)) + b)
+
+
+def time_shift(mu: np.float32, sigma: np.float32, t: np.float32) -> np.float32:
+    """FlowMatchEulerScheduler.swift:123-128: exp(mu) / (exp(mu) + (1/t - 1)^sigma)."""
+    exp_mu = f32(np.exp(f32(mu)))
+    base = f32(f32(1.0) / f32(t) - f32(1.0))
+    den = f32(exp_mu + f32(np.power(base, f32(sigma))))
+    return f32(exp_mu / den)
+
+
+def set_timesteps(num_inference_steps: int, image_seq_len: Optional[int] = None,
+                  strength: float = 1.0) -> Tuple[List[np.float32], int]:
+    """FlowMatchEulerScheduler.swift:65-115.  Returns (sigmas, tStart)."""
+    seq = 4096 if image_seq_len is None else image_seq_len
+    mu = compute_empirical_mu(seq, num_inference_steps)
+    all_sigmas: List[np.float32] = []
+    for i in range(num_inference_steps):
+        s = f32(f32(1.0) - f32(i) / f32(num_inference_steps))
+        all_sigmas.append(time_shift(mu, f32(1.0), s))
+    all_sigmas.append(f32(0.0))
+    clamped = max(f32(0.01), min(f32(1.0), f32(strength)))
+    init_idx = num_inference_steps - int(f32(f32(num_inference_steps) * f32(clamped)))
+    t_start = max(0, init_idx)
+    return all_sigmas[t_start:], t_start
+
+
+def set_custom_sigmas(custom: Sequence[float]) -> List[np.float32]:
+    """FlowMatchEulerScheduler.swift:236-260 (terminal 0 appended unless already 0)."""
+    if len(custom) == 0:
+        raise ValueError("empty custom sigmas are ignored by the reference")
+    out = [f32(x) for x in custom]
+    if out[-1] != f32(0.0):
+        out.append(f32(0.0))
+    return out
+
+
+def scheduler_step(sample: Tensor, model_output: Tensor, sigma: float, sigma_next: float) -> Tensor:
+    """a5 — FlowMatchEulerScheduler.swift:136-156: x + (sigma_next - sigma) * v."""
+    dt = f32(f32(sigma_next) - f32(sigma))
+    return sample + float(dt) * model_output
+
+
+def scale_noise(sample: Tensor, sigma: float, noise: Tensor) -> Tensor:
+    """a6 — FlowMatchEulerScheduler.swift:195-204: (1 - sigma)*sample + sigma*noise."""
+    s = float(f32(sigma))
+    return (1.0 - s) * sample + s * noise
+
+
+def cfg_combine(v_cond: Tensor, v_uncond: Tensor, guidance: float) -> Tensor:
+    """a7 — Flux2Core/Pipeline/Flux2Pipeline.swift:1955-1973."""
+    return v_uncond + float(f32(guidance)) * (v_cond - v_uncond)
+
+
+def repaint_blend(latents: Tensor, image_latents: Tensor, blend_noise: Tensor, mask: Tensor,
+                  sigma_next: float) -> Tensor:
+    """a8 — Flux2Chains/Flux2MaskedInpaintingChain.swift:399-403.
+    mask is [1,S,1] (1 = regenerate, 0 = keep source)."""
+    s = float(f32(sigma_next))
+    original_noised = (1.0 - s) * image_latents + s * blend_noise
+    return (1.0 - mask) * original_noised + mask * latents
+
+
+# ---------------------------------------------------------------------------
+# a1-a3, a21, a25  latent utils — Flux2Core/Pipeline/LatentUtils.swift
+# ---------------------------------------------------------------------------
+
+def validate_dimensions(height: int, width: int, patch: int = 2) -> Tuple[int, int]:
+    """LatentUtils.swift:382-394 — round UP to a multiple of 16."""
+    f = 8 * patch
+    return ((height + f - 1) // f) * f, ((width + f - 1) // f) * f
+
+
+def resolve_chain_dimensions(width: int, height: int, max_pixels: int = 1024 * 1024) -> Tuple[int, int]:
+    """Flux2Core/Pipeline/Flux2Pipeline+ChainHelpers.swift:112-129 — scale down to
+    max_pixels when exceeded (Double sqrt, Int truncation), then floor to a
+    multiple of 32, min 32.  Returns (height, width) like the reference."""
+    w, h = width, height
+    if w * h > max_pixels:
+        scale = math.sqrt(float(max_pixels) / float(w * h))
+        w, h = int(float(w) * scale), int(float(h) * scale)
+    w = max(32, (w // 32) * 32)
+    h = max(32, (h // 32) * 32)
+    return h, w
+
+
+def pack_patchified_to_sequence(p: Tensor) -> Tensor:
+    """LatentUtils.swift:76-86: [B,C,H,W] -> [B,H*W,C]."""
+    B, C, H, W = p.shape
+    return p.permute(0, 2, 3, 1).reshape(B, H * W, C)
+
+
+def unpack_sequence_to_patchified(seq: Tensor, height: int, width: int) -> Tensor:
+    """LatentUtils.swift:95-110: [B,S,C] -> [B,C,H/16,W/16]."""
+    B, _, C = seq.shape
+    return seq.reshape(B, height // 16, width // 16, C).permute(0, 3, 1, 2)
+
+
+def unpatchify_latents(p: Tensor, latent_channels: int = 32, patch: int = 2) -> Tensor:
+    """LatentUtils.swift:119-142: [B,C*p*p,H,W] -> [B,C,H*p,W*p], channel = c*4+py*2+px."""
+    B, _, H, W = p.shape
+    x = p.reshape(B, latent_channels, patch, patch, H, W).permute(0, 1, 4, 2, 5, 3)
+    return x.reshape(B, latent_channels, H * patch, W * patch)
+
+
+def pack_latents_to_patchified(z: Tensor, patch: int = 2) -> Tensor:
+    """LatentUtils.swift:186-212: [B,32,H,W] -> [B,128,H/2,W/2]."""
+    B, C, H, W = z.shape
+    x = z.reshape(B, C, H // patch, patch, W // patch, patch).permute(0, 2, 4, 1, 3, 5)
+    x = x.reshape(B, H // patch, W // patch, C * patch * patch)
+    return x.permute(0, 3, 1, 2)
+
+
+def image_position_ids(height: int, width: int, patch: int = 2) -> Tensor:
+    """LatentUtils.swift:256-286: int32 [S,4] = (0, y, x, 0), row-major."""
+    nh, nw = height // 8 // patch, width // 8 // patch
+    ys = torch.arange(nh, dtype=torch.int32).view(nh, 1).expand(nh, nw).reshape(-1)
+    xs = torch.arange(nw, dtype=torch.int32).view(1, nw).expand(nh, nw).reshape(-1)
+    z = torch.zeros(nh * nw, dtype=torch.int32)
+    return torch.stack([z, ys, xs, z], dim=1)
+
+
+def text_position_ids(length: int) -> Tensor:
+    """LatentUtils.swift:291-298: (0,0,0,l)."""
+    z = torch.zeros(length, dtype=torch.int32)
+    return torch.stack([z, z, z, torch.arange(length, dtype=torch.int32)], dim=1)
+
+
+def reference_position_ids(latent_heights: Sequence[int], latent_widths: Sequence[int],
+                           scale: int = 10) -> Tensor:
+    """LatentUtils.swift:324-346: reference image i gets T = scale + scale*i."""
+    rows = []
+    for i, (h, w) in enumerate(zip(latent_heights, latent_widths)):
+        t = scale + scale * i
+        for y in range(h):
+            for x in range(w):
+                rows.append((t, y, x, 0))
+    return torch.tensor(rows, dtype=torch.int32).reshape(-1, 4)
+
+
+def normalize_latents_bn(x: Tensor, mean: Tensor, var: Tensor, eps: float = 1e-4) -> Tensor:
+    """LatentUtils.swift:460-473 (NCHW, 128 patchified channels, eps 1e-4)."""
+    C = mean.shape[0]
+    return (x - mean.view(1, C, 1, 1)) / torch.sqrt(var.view(1, C, 1, 1) + eps)
+
+
+def denormalize_latents_bn(x: Tensor, mean: Tensor, var: Tensor, eps: float = 1e-4) -> Tensor:
+    """a21 — LatentUtils.swift:483-496."""
+    C = mean.shape[0]
+    return x * torch.sqrt(var.view(1, C, 1, 1) + eps) + mean.view(1, C, 1, 1)
+
+
+def pack_mask_for_latent_blending(mask_hw: Tensor, height: int, width: int) -> Tensor:
+    """Shape contract of Flux2Pipeline+ChainHelpers.swift:148-236: a [H,W] mask in
+    [0,1] (1 = regenerate) -> [1, (H/16)*(W/16), 1].  The reference rasterises with
+    CoreGraphics high-quality resampling into an 8-bit grey context and divides by
+    255 (not reproducible off-platform); the oracle uses an exact area average
+    rounded to 8 bits, documented in DESIGN.md."""
+    m = mask_hw.float().reshape(1, 1, mask_hw.shape[0], mask_hw.shape[1])
+    m = F.adaptive_avg_pool2d(m, (height // 16, width // 16))
+    m = torch.round(m * 255.0) / 255.0
+    return m.reshape(1, -1, 1)
+
+
+# ---------------------------------------------------------------------------
+# a18 RoPE tables — Flux2Core/Transformer/Flux2RoPE.swift:129-169
+# ---------------------------------------------------------------------------
+
+def rope_tables(ids: Tensor, axes: Sequence[int] = ROPE_AXES, theta: float = ROPE_THETA) -> Tuple[Tensor, Tensor]:
+    """cos/sin [S, sum(axes)] f32; per axis cos(pos * theta^(-2j/dim)) repeated twice
+    (interleaved), axes concatenated.  Computed from the IDs (the reference's
+    cache-by-length quirk, Flux2RoPE.swift:65-70, is deliberately not reproduced)."""
+    cos_parts, sin_parts = [], []
+    for a, dim in enumerate(axes):
+        pos = ids[:, a].to(torch.float32).unsqueeze(1)
+        freq_seq = torch.arange(0, dim, 2, dtype=torch.float32)
+        inv_freq = 1.0 / torch.pow(torch.tensor(theta, dtype=torch.float32), freq_seq / float(dim))
+        freqs = pos * inv_freq.unsqueeze(0)
+        cos_parts.append(torch.cos(freqs).repeat_interleave(2, dim=1))
+        sin_parts.append(torch.sin(freqs).repeat_interleave(2, dim=1))
+    return torch.cat(cos_parts, dim=1), torch.cat(sin_parts, dim=1)
+
+
+def rotate_half(x: Tensor) -> Tensor:
+    """Flux2Attention.swift:442-461: pairs (2i,2i+1) -> (-x1, x0)."""
+    xr = x.reshape(*x.shape[:-1], x.shape[-1] // 2, 2)
+    return torch.stack([-xr[..., 1], xr[..., 0]], dim=-1).reshape(x.shape)
+
+
+def apply_rope(x: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
+    """Flux2Attention.swift:212-229: x*cos + rotate_half(x)*sin, x [B,H,S,D], cos/sin [S,D]."""
+    return x * cos[None, None] + rotate_half(x) * sin[None, None]
+
+
+# ---------------------------------------------------------------------------
+# a11 timestep embedding — Flux2Core/Transformer/Flux2Embeddings.swift:9-142
+# ---------------------------------------------------------------------------
+
+def sinusoid_embedding(t: Tensor, num_channels: int = 256) -> Tensor:
+    """Timesteps(flipSinToCos: true, downscaleFreqShift: 0): [cos | sin]."""
+    half = num_channels // 2
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / float(half)
+    emb = torch.exp(exponent)
+    arg = t.to(torch.float32).unsqueeze(-1) * emb.unsqueeze(0)
+    return torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1)
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    return F.linear(x, w.float(), None if b is None else b.float())
+
+
+def time_guidance_embed(P: Dict[str, Tensor], t: Tensor, g: Optional[Tensor]) -> Tensor:
+    """Flux2Embeddings.swift:124-142; t/g already multiplied by 1000 by the caller
+    (Flux2Transformer.swift:145-146)."""
+    temb = linear(F.silu(linear(sinusoid_embedding(t), P["time_in.in_layer.weight"])),
+                  P["time_in.out_layer.weight"])
+    if g is not None and "guidance_in.in_layer.weight" in P:
+        gemb = linear(F.silu(linear(sinusoid_embedding(g), P["guidance_in.in_layer.weight"])),
+                      P["guidance_in.out_layer.weight"])
+        temb = temb + gemb
+    return temb
+
+
+# ---------------------------------------------------------------------------
+# a12-a17 blocks
+# ---------------------------------------------------------------------------
+
+def layer_norm_noaffine(x: Tensor, eps: float = 1e-6) -> Tensor:
+    """a13 — LayerNorm(eps 1e-6, affine false), Flux2TransformerBlock.swift:56-61."""
+    return F.layer_norm(x, (x.shape[-1],), None, None, eps)
+
+
+def rms_norm(x: Tensor, w: Tensor, eps: float = 1e-6) -> Tensor:
+    """Flux2Attention.swift:11-26 (MLXFast.rmsNorm over the last dim)."""
+    return x * torch.rsqrt(x.pow(2).mean(dim=-1, keepdim=True) + eps) * w.float()
+
+
+def modulation(temb: Tensor, w: Tensor, num_sets: int) -> List[Tuple[Tensor, Tensor, Tensor]]:
+    """Flux2Modulation.swift:49-75 — linear(silu(temb)) chunked (shift, scale, gate) per set."""
+    dim = temb.shape[-1]
+    allp = linear(F.silu(temb), w)
+    out = []
+    for i in range(num_sets):
+        s0 = i * dim * 3
+        out.append((allp[:, s0:s0 + dim], allp[:, s0 + dim:s0 + 2 * dim], allp[:, s0 + 2 * dim:s0 + 3 * dim]))
+    return out
+
+
+def apply_modulation(x: Tensor, shift: Tensor, scale: Tensor) -> Tensor:
+    """Flux2Modulation.swift:96-112."""
+    return x * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
+
+
+def sdpa(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+    """softmax(QK^T/sqrt(D) [+mask]) V, explicit form (MLXFast.scaledDotProductAttention,
+    Flux2Attention.swift:168-174)."""
+    scale = 1.0 / math.sqrt(q.shape[-1])
+    s = torch.matmul(q, k.transpose(-1, -2)) * scale
+    if mask is not None:
+        s = s + mask
+    return torch.matmul(torch.softmax(s, dim=-1), v)
+
+
+def _heads(x: Tensor, H: int) -> Tensor:
+    B, S, _ = x.shape
+    return x.reshape(B, S, H, HEAD_DIM).permute(0, 2, 1, 3)
+
+
+def _unheads(x: Tensor) -> Tensor:
+    B, H, S, D = x.shape
+    return x.permute(0, 2, 1, 3).reshape(B, S, H * D)
+
+
+def swiglu_ff(x: Tensor, w_in: Tensor, w_out: Tensor) -> Tensor:
+    """a15 — Flux2FeedForward.swift:42-109: gate = first half, value = second half."""
+    p = linear(x, w_in)
+    gate, value = p.chunk(2, dim=-1)
+    return linear(F.silu(gate) * value, w_out)
+
+
+def double_block(P: Dict[str, Tensor], i: int, img: Tensor, txt: Tensor, H: int,
+                 cos: Tensor, sin: Tensor, img_mod, txt_mod) -> Tuple[Tensor, Tensor]:
+    """a14-a16 — Flux2TransformerBlock.swift:80-168 + Flux2Attention.swift:103-193."""
+    pre = f"double_blocks.{i}."
+    S_txt = txt.shape[1]
+    img_n = apply_modulation(layer_norm_noaffine(img), img_mod[0][0], img_mod[0][1])
+    txt_n = apply_modulation(layer_norm_noaffine(txt), txt_mod[0][0], txt_mod[0][1])
+
+    def qkv(x, name):
+        p = linear(x, P[pre + name + ".qkv.weight"])
+        q, k, v = p.chunk(3, dim=-1)              # WeightLoader.swift:99-119: q | k | v
+        q, k, v = _heads(q, H), _heads(k, H), _heads(v, H)
+        q = rms_norm(q, P[pre + name + ".norm.query_norm.scale"])
+        k = rms_norm(k, P[pre + name + ".norm.key_norm.scale"])
+        return q, k, v
+
+    q_i, k_i, v_i = qkv(img_n, "img_attn")
+    q_t, k_t, v_t = qkv(txt_n, "txt_attn")
+    q_i, k_i = apply_rope(q_i, cos[S_txt:], sin[S_txt:]), apply_rope(k_i, cos[S_txt:], sin[S_txt:])
+    q_t, k_t = apply_rope(q_t, cos[:S_txt], sin[:S_txt]), apply_rope(k_t, cos[:S_txt], sin[:S_txt])
+    q = torch.cat([q_t, q_i], dim=2)               # [txt ; img]  (Flux2Attention.swift:161-163)
+    k = torch.cat([k_t, k_i], dim=2)
+    v = torch.cat([v_t, v_i], dim=2)
+    o = _unheads(sdpa(q, k, v))
+    txt_attn = linear(o[:, :S_txt], P[pre + "txt_attn.proj.weight"])
+    img_attn = linear(o[:, S_txt:], P[pre + "img_attn.proj.weight"])
+    img = img + img_attn * img_mod[0][2].unsqueeze(1)
+    txt = txt + txt_attn * txt_mod[0][2].unsqueeze(1)
+
+    img_n2 = apply_modulation(layer_norm_noaffine(img), img_mod[1][0], img_mod[1][1])
+    txt_n2 = apply_modulation(layer_norm_noaffine(txt), txt_mod[1][0], txt_mod[1][1])
+    img = img + swiglu_ff(img_n2, P[pre + "img_mlp.0.weight"], P[pre + "img_mlp.2.weight"]) * img_mod[1][2].unsqueeze(1)
+    txt = txt + swiglu_ff(txt_n2, P[pre + "txt_mlp.0.weight"], P[pre + "txt_mlp.2.weight"]) * txt_mod[1][2].unsqueeze(1)
+    return txt, img
+
+
+def single_block(P: Dict[str, Tensor], i: int, hs: Tensor, H: int, cos: Tensor, sin: Tensor, mod) -> Tensor:
+    """a17 — Flux2SingleBlock.swift:59-98 + Flux2ParallelAttention.swift:72-123."""
+    pre = f"single_blocks.{i}."
+    d = hs.shape[-1]
+    x = apply_modulation(layer_norm_noaffine(hs), mod[0][0], mod[0][1])
+    p = linear(x, P[pre + "linear1.weight"])      # [q | k | v | gate | up]
+    q, k, v = p[..., :d], p[..., d:2 * d], p[..., 2 * d:3 * d]
+    mlp_hidden = (p.shape[-1] - 3 * d) // 2
+    gate, up = p[..., 3 * d:3 * d + mlp_hidden], p[..., 3 * d + mlp_hidden:]
+    q, k, v = _heads(q, H), _heads(k, H), _heads(v, H)
+    q = apply_rope(rms_norm(q, P[pre + "norm.query_norm.scale"]), cos, sin)
+    k = apply_rope(rms_norm(k, P[pre + "norm.key_norm.scale"]), cos, sin)
+    attn = _unheads(sdpa(q, k, v))
+    out = linear(torch.cat([attn, F.silu(gate) * up], dim=-1), P[pre + "linear2.weight"])
+    return hs + out * mod[0][2].unsqueeze(1)
+
+
+def dit_forward(P: Dict[str, Tensor], cfg: dict, lat: Tensor, txt_emb: Tensor, t: Tensor,
+                g: Optional[Tensor], img_ids: Tensor, txt_ids: Tensor,
+                taps: Optional[dict] = None) -> Tensor:
+    """a9 — Flux2Transformer2DModel.callAsFunction, Flux2Transformer.swift:123-327.
+    lat [B,S_img,128], txt_emb [B,S_txt,J], t [B] in [0,1], g [B] or None.
+    `taps`, if given, receives intermediate tensors (test aid)."""
+    H = cfg["heads"]
+    img = linear(lat.float(), P["img_in.weight"])
+    txt = linear(txt_emb.float(), P["txt_in.weight"])
+    temb = time_guidance_embed(P, t.float() * 1000.0, None if g is None else g.float() * 1000.0)
+    cos, sin = rope_tables(torch.cat([txt_ids, img_ids], dim=0))
+    img_mod = modulation(temb, P["double_stream_modulation_img.lin.weight"], 2)
+    txt_mod = modulation(temb, P["double_stream_modulation_txt.lin.weight"], 2)
+    if taps is not None:
+        taps.update(temb=temb, cos=cos, sin=sin, img_in=img, txt_in=txt)
+    for i in range(cfg["n_double"]):
+        txt, img = double_block(P, i, img, txt, H, cos, sin, img_mod, txt_mod)
+        if taps is not None:
+            taps[f"double{i}.img"], taps[f"double{i}.txt"] = img, txt
+    S_txt = txt.shape[1]
+    hs = torch.cat([txt, img], dim=1)
+    smod = modulation(temb, P["single_stream_modulation.lin.weight"], 1)
+    for i in range(cfg["n_single"]):
+        hs = single_block(P, i, hs, H, cos, sin, smod)
+        if taps is not None:
+            taps[f"single{i}"] = hs
+    img = hs[:, S_txt:, :]
+    # AdaLayerNormContinuous (Flux2Modulation.swift:125-156).  The BFL checkpoint
+    # stores [shift | scale]; the reference swaps the halves at load
+    # (WeightLoader.swift:182-202) and then reads (scale, shift).  Net effect on
+    # the BFL-ordered weight used here: shift = first half, scale = second half.
+    d = img.shape[-1]
+    p = linear(F.silu(temb), P["final_layer.adaLN_modulation.1.weight"])
+    shift, scale = p[:, :d], p[:, d:]
+    img = apply_modulation(layer_norm_noaffine(img), shift, scale)
+    return linear(img, P["final_layer.linear.weight"])
+
+
+# ---------------------------------------------------------------------------
+# a22-a23 VAE decoder — Flux2Core/VAE/{AutoencoderKL,VAEDecoder,ResnetBlock}.swift
+# Weights in diffusers naming, conv weights OIHW as in the checkpoint file
+# (the reference transposes to OHWI for MLX's NHWC conv: WeightLoader.swift:486-560;
+# the arithmetic is identical).
+# ---------------------------------------------------------------------------
+
+def group_norm(x: Tensor, w: Tensor, b: Tensor, groups: int = 32, eps: float = 1e-6) -> Tensor:
+    """ResnetBlock.swift:9-55 (f32 statistics over (H,W,C/G))."""
+    return F.group_norm(x, groups, w.float(), b.float(), eps)
+
+
+def conv2d(x: Tensor, P: Dict[str, Tensor], name: str, padding: int) -> Tensor:
+    return F.conv2d(x, P[name + ".weight"].float(), P[name + ".bias"].float(), padding=padding)
+
+
+def resnet_block(x: Tensor, P: Dict[str, Tensor], pre: str, groups: int) -> Tensor:
+    """ResnetBlock.swift:122-187."""
+    h = F.silu(group_norm(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], groups))
+    h = conv2d(h, P, pre + "conv1", 1)
+    h = F.silu(group_norm(h, P[pre + "norm2.weight"], P[pre + "norm2.bias"], groups))
+    h = conv2d(h, P, pre + "conv2", 1)
+    if pre + "conv_shortcut.weight" in P:
+        x = conv2d(x, P, pre + "conv_shortcut", 0)
+    return h + x
+
+
+def vae_attention(x: Tensor, P: Dict[str, Tensor], pre: str, groups: int) -> Tensor:
+    """ResnetBlock.swift:257-313: single head, scale 1/sqrt(C), Linear with bias."""
+    B, C, Hh, Ww = x.shape
+    h = group_norm(x, P[pre + "group_norm.weight"], P[pre + "group_norm.bias"], groups)
+    h = h.permute(0, 2, 3, 1).reshape(B, Hh * Ww, C)
+    q = linear(h, P[pre + "to_q.weight"], P[pre + "to_q.bias"])
+    k = linear(h, P[pre + "to_k.weight"], P[pre + "to_k.bias"])
+    v = linear(h, P[pre + "to_v.weight"], P[pre + "to_v.bias"])
+    a = torch.softmax(torch.matmul(q, k.transpose(1, 2)) * (1.0 / math.sqrt(C)), dim=-1)
+    o = linear(torch.matmul(a, v), P[pre + "to_out.0.weight"], P[pre + "to_out.0.bias"])
+    return o.reshape(B, Hh, Ww, C).permute(0, 3, 1, 2) + x
+
+
+def upsample2x(x: Tensor, P: Dict[str, Tensor], pre: str) -> Tensor:
+    """ResnetBlock.swift:217-254: nearest 2x then conv3x3 pad 1."""
+    x = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    return conv2d(x, P, pre + "conv", 1)
+
+
+def vae_decode(P: Dict[str, Tensor], vcfg: dict, z: Tensor, taps: Optional[dict] = None) -> Tensor:
+    """a22 — AutoencoderKL.swift:129-143 + VAEDecoder.swift:91-121.
+    z [B,32,h,w] -> [B,3,8h,8w]; no scaling factor; post_quant_conv applied."""
+    groups = vcfg["groups"]
+    n_up = len(vcfg["channels"])
+    x = conv2d(z.float(), P, "post_quant_conv", 0)
+    x = conv2d(x, P, "decoder.conv_in", 1)
+    x = resnet_block(x, P, "decoder.mid_block.resnets.0.", groups)
+    x = vae_attention(x, P, "decoder.mid_block.attentions.0.", groups)
+    x = resnet_block(x, P, "decoder.mid_block.resnets.1.", groups)
+    if taps is not None:
+        taps["mid"] = x
+    for i in range(n_up):
+        for j in range(vcfg["layers_per_block"] + 1):
+            x = resnet_block(x, P, f"decoder.up_blocks.{i}.resnets.{j}.", groups)
+        if i < n_up - 1:
+            x = upsample2x(x, P, f"decoder.up_blocks.{i}.upsamplers.0.")
+        if taps is not None:
+            taps[f"up{i}"] = x
+    x = F.silu(group_norm(x, P["decoder.conv_norm_out.weight"], P["decoder.conv_norm_out.bias"], groups))
+    return conv2d(x, P, "decoder.conv_out", 1)
+
+
+def postprocess_vae_output(x: Tensor) -> Tensor:
+    """a24 — Flux2Pipeline.swift:2425-2468: clip((x+1)*127.5, 0, 255) -> TRUNCATING
+    u8 cast -> [H,W,3]."""
+    y = torch.clamp((x + 1.0) * 127.5, 0.0, 255.0)
+    return y[0].permute(1, 2, 0).to(torch.uint8)   # torch float->uint8 truncates toward zero
+
+
+def latents_to_vae_input(packed: Tensor, height: int, width: int, bn_mean: Tensor, bn_var: Tensor) -> Tensor:
+    """Flux2Pipeline.swift:2059-2079: unpack -> BN-denormalise (128 ch) -> unpatchify."""
+    p = unpack_sequence_to_patchified(packed, height, width)
+    p = denormalize_latents_bn(p, bn_mean.float(), bn_var.float())
+    return unpatchify_latents(p)
+
+
+# ---------------------------------------------------------------------------
+# Pipeline loop — Flux2Pipeline.swift:1442-2117 (T2I) / 1490-1808 (I2I)
+# ---------------------------------------------------------------------------
+
+StepHook = Callable[[dict, Tensor], Tensor]
+
+
+def generate(P: Dict[str, Tensor], cfg: dict, VP: Optional[Dict[str, Tensor]], vcfg: Optional[dict],
+             txt_emb: Tensor, noise_patchified: Tensor, height: int, width: int, steps: int,
+             guidance: Optional[float] = None, init_latents: Optional[Tensor] = None,
+             strength: float = 1.0, on_step: Optional[StepHook] = None,
+             ref_latents: Optional[Tensor] = None, ref_ids: Optional[Tensor] = None,
+             neg_emb: Optional[Tensor] = None, cfg_scale: float = 1.0,
+             custom_sigmas: Optional[Sequence[float]] = None, decode: bool = True) -> dict:
+    """Restates generateWithResult's hot section.  Explicit inputs instead of RNG /
+    text encoder: `noise_patchified` [1,128,H/16,W/16] (the reference draws noise
+    in this layout, Flux2Pipeline.swift:1448, then packs it, :1860), `txt_emb`
+    [1,S_txt,J].  Returns sigmas, per-step latents and (if decode) the u8 image."""
+    height, width = validate_dimensions(height, width)
+    packed = pack_patchified_to_sequence(noise_patchified.float())
+    S_img = packed.shape[1]
+    txt_ids = text_position_ids(txt_emb.shape[1])
+    img_ids = image_position_ids(height, width)
+    use_init = init_latents is not None
+    if strength < 1.0 and not use_init:
+        raise ValueError("strength < 1 requires initLatents (Flux2Pipeline.swift:1210-1213)")
+    if custom_sigmas is not None:
+        sigmas = set_custom_sigmas(custom_sigmas)
+    else:
+        sigmas, _ = set_timesteps(steps, S_img, strength if use_init else 1.0)
+        if use_init and len(sigmas) < 2:
+            raise ValueError("zero denoising steps (Flux2Pipeline.swift:1893-1896)")
+        if use_init:
+            if tuple(init_latents.shape) != tuple(packed.shape):
+                raise ValueError("initLatents shape mismatch (Flux2Pipeline.swift:1898-1901)")
+            packed = scale_noise(init_latents.float(), sigmas[0], packed)
+    all_img_ids = img_ids if ref_ids is None else torch.cat([img_ids, ref_ids], dim=0)
+    g = None if (guidance is None or not cfg["guidance"]) else torch.tensor([guidance], dtype=torch.float32)
+    traj = []
+    n = len(sigmas) - 1
+    for k in range(n):
+        sigma, sigma_next = sigmas[k], sigmas[k + 1]
+        t = torch.tensor([float(sigma)], dtype=torch.float32)
+        inp = packed if ref_latents is None else torch.cat([packed, ref_latents.float()], dim=1)
+        v = dit_forward(P, cfg, inp, txt_emb, t, g, all_img_ids, txt_ids)
+        if neg_emb is not None and cfg_scale > 1.0:
+            v_u = dit_forward(P, cfg, inp, neg_emb, t, g, all_img_ids, text_position_ids(neg_emb.shape[1]))
+            v = cfg_combine(v, v_u, cfg_scale)
+        v = v[:, :S_img]
+        packed = scheduler_step(packed, v, sigma, sigma_next)
+        if on_step is not None:
+            ctx = dict(stepIdx=k, totalSteps=n, sigma=float(sigma), sigmaNext=float(sigma_next),
+                       height=height, width=width, isI2I=ref_latents is not None)
+            packed = on_step(ctx, packed)
+        traj.append(packed.clone())
+    out = dict(sigmas=[float(s) for s in sigmas], latents=traj, final_latents=packed)
+    if decode and VP is not None:
+        z = latents_to_vae_input(packed, height, width, VP["bn.running_mean"], VP["bn.running_var"])
+        dec = vae_decode(VP, vcfg, z)
+        out["decoded"] = dec
+        out["image"] = postprocess_vae_output(dec)
+    return out
