@@ -1,0 +1,334 @@
+"""Thin object wrappers over the C ABI.  torch is used for device memory and stream
+ordering only; every compute call goes through libflux2mi.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from ._lib import Flux2Error, check, lib
+
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}
+
+
+# --------------------------------------------------------------------------- host-side functions
+def compute_empirical_mu(image_seq_len: int, num_steps: int) -> float:
+    return float(lib().flux2mi_compute_empirical_mu(image_seq_len, num_steps))
+
+
+def set_timesteps(num_inference_steps: int, image_seq_len: Optional[int] = None, strength: float = 1.0):
+    """FlowMatchEulerScheduler.setTimesteps -> (sigmas float32 array, tStart)."""
+    cap = num_inference_steps + 2
+    buf = (C.c_float * cap)()
+    n, t0 = C.c_int(0), C.c_int(0)
+    check(lib().flux2mi_set_timesteps(num_inference_steps, image_seq_len or 0, strength, buf, cap, C.byref(n), C.byref(t0)))
+    return np.array(buf[: n.value], dtype=np.float32), t0.value
+
+
+def set_custom_sigmas(sigmas: Sequence[float]) -> np.ndarray:
+    n_in = len(sigmas)
+    src = (C.c_float * max(n_in, 1))(*[float(s) for s in sigmas])
+    dst = (C.c_float * (n_in + 1))()
+    n = C.c_int(0)
+    check(lib().flux2mi_set_custom_sigmas(src, n_in, dst, n_in + 1, C.byref(n)))
+    return np.array(dst[: n.value], dtype=np.float32)
+
+
+def validate_dimensions(height: int, width: int) -> Tuple[int, int]:
+    h, w = C.c_int(0), C.c_int(0)
+    lib().flux2mi_validate_dimensions(height, width, C.byref(h), C.byref(w))
+    return h.value, w.value
+
+
+def resolve_chain_dimensions(width: int, height: int, max_pixels: int = 1024 * 1024) -> Tuple[int, int]:
+    """-> (height, width), Flux2Pipeline.resolveChainDimensions."""
+    h, w = C.c_int(0), C.c_int(0)
+    lib().flux2mi_resolve_chain_dimensions(width, height, max_pixels, C.byref(h), C.byref(w))
+    return h.value, w.value
+
+
+def image_position_ids(height: int, width: int) -> np.ndarray:
+    n = (height // 16) * (width // 16)
+    out = np.zeros((max(n, 1), 4), dtype=np.int32)
+    check(lib().flux2mi_image_position_ids(height, width, out.ctypes.data_as(C.POINTER(C.c_int32)), n))
+    return out[:n]
+
+
+def text_position_ids(length: int) -> np.ndarray:
+    out = np.zeros((max(length, 1), 4), dtype=np.int32)
+    check(lib().flux2mi_text_position_ids(length, out.ctypes.data_as(C.POINTER(C.c_int32)), length))
+    return out[:length]
+
+
+def reference_position_ids(latent_heights: Sequence[int], latent_widths: Sequence[int], scale: int = 10) -> np.ndarray:
+    n = sum(h * w for h, w in zip(latent_heights, latent_widths))
+    k = len(latent_heights)
+    hs = (C.c_int * max(k, 1))(*latent_heights)
+    ws = (C.c_int * max(k, 1))(*latent_widths)
+    out = np.zeros((max(n, 1), 4), dtype=np.int32)
+    check(lib().flux2mi_reference_position_ids(hs, ws, k, scale, out.ctypes.data_as(C.POINTER(C.c_int32)), n))
+    return out[:n]
+
+
+# --------------------------------------------------------------------------- device objects
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise Flux2Error(L.ERR_INVALID_ARG, f"{name} must be a device tensor")
+    if t.dtype != dtype:
+        raise Flux2Error(L.ERR_INVALID_ARG, f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+class Context:
+    """One GPU + one HIP stream + one generation in flight (flux2mi_ctx)."""
+
+    def __init__(self, device: int = 0):
+        if not torch.cuda.is_available():
+            raise Flux2Error(L.ERR_HIP, "no HIP device visible: the hot path has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        h = C.c_void_p()
+        check(lib().flux2mi_ctx_create(device, C.c_void_p(self.stream.cuda_stream), C.byref(h)))
+        self.handle = h
+
+    # stream ordering against torch's current stream (no host sync)
+    def _enter(self):
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _exit(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def sync(self):
+        check(lib().flux2mi_ctx_sync(self.handle))
+
+    def close(self):
+        if self.handle:
+            lib().flux2mi_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- elementwise ops (in place on torch tensors)
+    def sched_step(self, x: torch.Tensor, v: torch.Tensor, dt: float):
+        self._enter()
+        check(lib().flux2mi_sched_step(self.handle, _ptr(x), _ptr(v), dt, x.numel()))
+        self._exit()
+
+    def scale_noise(self, sample: torch.Tensor, sigma: float, noise: torch.Tensor) -> torch.Tensor:
+        out = torch.empty_like(sample)
+        self._enter()
+        check(lib().flux2mi_scale_noise(self.handle, _ptr(out), _ptr(sample), _ptr(noise), sigma, out.numel()))
+        self._exit()
+        return out
+
+    def cfg_combine(self, v_cond: torch.Tensor, v_uncond: torch.Tensor, guidance: float):
+        self._enter()
+        check(lib().flux2mi_cfg_combine(self.handle, _ptr(v_cond), _ptr(v_uncond), guidance, v_cond.numel()))
+        self._exit()
+
+    def repaint_blend(self, x, image_latents, blend_noise, mask, sigma_next: float):
+        seq, c = x.shape[-2], x.shape[-1]
+        self._enter()
+        check(lib().flux2mi_repaint_blend(self.handle, _ptr(x), _ptr(image_latents), _ptr(blend_noise), _ptr(mask),
+                                          sigma_next, seq, c))
+        self._exit()
+
+    def pack_patchified_to_sequence(self, p: torch.Tensor) -> torch.Tensor:
+        _, c, h, w = p.shape
+        out = torch.empty((1, h * w, c), dtype=torch.float32, device=p.device)
+        self._enter()
+        check(lib().flux2mi_pack_patchified_to_sequence(self.handle, _ptr(p.contiguous()), _ptr(out), c, h, w))
+        self._exit()
+        return out
+
+    def unpack_sequence_to_patchified(self, s: torch.Tensor, h: int, w: int) -> torch.Tensor:
+        c = s.shape[-1]
+        out = torch.empty((1, c, h, w), dtype=torch.float32, device=s.device)
+        self._enter()
+        check(lib().flux2mi_unpack_sequence_to_patchified(self.handle, _ptr(s.contiguous()), _ptr(out), c, h, w))
+        self._exit()
+        return out
+
+    def latents_to_vae_input(self, packed, bn_mean, bn_var, h16: int, w16: int) -> torch.Tensor:
+        z = torch.empty((1, 32, 2 * h16, 2 * w16), dtype=torch.float32, device=packed.device)
+        self._enter()
+        check(lib().flux2mi_latents_to_vae_input(self.handle, _ptr(packed.contiguous()), _ptr(bn_mean), _ptr(bn_var),
+                                                 _ptr(z), h16, w16))
+        self._exit()
+        return z
+
+    def vae_latents_to_packed(self, z, bn_mean, bn_var) -> torch.Tensor:
+        h16, w16 = z.shape[-2] // 2, z.shape[-1] // 2
+        out = torch.empty((1, h16 * w16, 128), dtype=torch.float32, device=z.device)
+        self._enter()
+        check(lib().flux2mi_vae_latents_to_packed(self.handle, _ptr(z.contiguous()), _ptr(bn_mean), _ptr(bn_var),
+                                                  _ptr(out), h16, w16))
+        self._exit()
+        return out
+
+    # ---- measurement aid
+    def prof_begin(self, kernel_class: int):
+        check(lib().flux2mi_prof_begin(self.handle, kernel_class))
+
+    def prof_end(self):
+        n, ms, fl = C.c_int(0), C.c_double(0.0), C.c_double(0.0)
+        check(lib().flux2mi_prof_end(self.handle, C.byref(n), C.byref(ms), C.byref(fl)))
+        return n.value, ms.value, fl.value
+
+    # ---- standalone ops
+    def op_gemm_bf16(self, a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        a, w = _req(a, torch.bfloat16, "A"), _req(w, torch.bfloat16, "W")
+        m, k = a.shape
+        n = w.shape[0]
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+        self._enter()
+        check(lib().flux2mi_op_gemm_bf16(self.handle, _ptr(a), _ptr(w), _ptr(out), m, n, k))
+        self._exit()
+        return out
+
+    def op_attention(self, qkv: torch.Tensor, heads: int) -> torch.Tensor:
+        qkv = _req(qkv, torch.bfloat16, "qkv")
+        s = qkv.shape[0]
+        out = torch.empty((s, heads * 128), dtype=torch.bfloat16, device=qkv.device)
+        self._enter()
+        check(lib().flux2mi_op_attention(self.handle, _ptr(qkv), _ptr(out), s, heads))
+        self._exit()
+        return out
+
+
+def _set_tensors(fn, handle, tensors: Dict[str, torch.Tensor]):
+    for name, t in tensors.items():
+        if t.dtype not in _DT:
+            t = t.float()
+        t = t.contiguous()
+        shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+        check(fn(handle, name.encode(), _DT[t.dtype], shape, t.dim(), C.c_void_p(t.data_ptr())))
+
+
+class DiT:
+    """Flux2Transformer2DModel (flux2mi_dit)."""
+
+    def __init__(self, ctx: Context, config):
+        self.ctx = ctx
+        cfg = L.DitConfig()
+        if isinstance(config, str):
+            check(lib().flux2mi_dit_preset(config.encode(), C.byref(cfg)))
+        else:
+            cfg.dim, cfg.heads = config["dim"], config["heads"]
+            cfg.n_double, cfg.n_single = config["n_double"], config["n_single"]
+            cfg.joint_dim, cfg.guidance_embeds = config["joint_dim"], int(bool(config["guidance"]))
+        self.cfg = cfg
+        h = C.c_void_p()
+        check(lib().flux2mi_dit_create(ctx.handle, C.byref(cfg), C.byref(h)))
+        self.handle = h
+
+    def load(self, tensors: Dict[str, torch.Tensor]):
+        """Checkpoint tensors by key (BFL or diffusers naming), host or device memory."""
+        _set_tensors(lib().flux2mi_dit_set_tensor, self.handle, tensors)
+        return self
+
+    def finalize(self):
+        check(lib().flux2mi_dit_finalize(self.handle))
+        return self
+
+    @property
+    def param_bytes(self) -> int:
+        return int(lib().flux2mi_dit_param_bytes(self.handle))
+
+    def forward(self, latents: torch.Tensor, txt_emb: torch.Tensor, timestep: float, guidance: float,
+                img_ids: torch.Tensor, txt_ids: torch.Tensor, s_out: Optional[int] = None) -> torch.Tensor:
+        """latents f32 [S_img,128], txt_emb bf16 [S_txt,J], ids i32 [.,4] -> f32 [s_out,128] (async)."""
+        lat = _req(latents.reshape(-1, 128), torch.float32, "latents")
+        txt = _req(txt_emb.reshape(-1, txt_emb.shape[-1]), torch.bfloat16, "txt_emb")
+        ii, ti = _req(img_ids, torch.int32, "img_ids"), _req(txt_ids, torch.int32, "txt_ids")
+        s_img, s_txt = lat.shape[0], txt.shape[0]
+        s_out = s_img if s_out is None else s_out
+        out = torch.empty((s_out, 128), dtype=torch.float32, device=lat.device)
+        self.ctx._enter()
+        check(lib().flux2mi_dit_forward(self.handle, _ptr(lat), s_img, _ptr(txt), s_txt, timestep, guidance,
+                                        _ptr(ii), _ptr(ti), _ptr(out), s_out))
+        self.ctx._exit()
+        return out
+
+    def close(self):
+        if self.handle:
+            lib().flux2mi_dit_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class VAE:
+    """AutoencoderKLFlux2 decoder side (flux2mi_vae)."""
+
+    def __init__(self, ctx: Context, config):
+        self.ctx = ctx
+        cfg = L.VaeConfig()
+        if isinstance(config, str):
+            check(lib().flux2mi_vae_preset(config.encode(), C.byref(cfg)))
+        else:
+            for i, c in enumerate(config["channels"]):
+                cfg.channels[i] = c
+            cfg.latent_channels, cfg.groups = config["latent"], config["groups"]
+            cfg.layers_per_block = config["layers_per_block"]
+        self.cfg = cfg
+        h = C.c_void_p()
+        check(lib().flux2mi_vae_create(ctx.handle, C.byref(cfg), C.byref(h)))
+        self.handle = h
+
+    def load(self, tensors: Dict[str, torch.Tensor]):
+        _set_tensors(lib().flux2mi_vae_set_tensor, self.handle, tensors)
+        return self
+
+    def finalize(self):
+        check(lib().flux2mi_vae_finalize(self.handle))
+        return self
+
+    def _bn(self, fn) -> int:
+        return fn(self.handle)
+
+    @property
+    def bn_mean_ptr(self) -> int:
+        return lib().flux2mi_vae_bn_mean(self.handle)
+
+    @property
+    def bn_var_ptr(self) -> int:
+        return lib().flux2mi_vae_bn_var(self.handle)
+
+    def decode(self, z: torch.Tensor, want_f32: bool = True, want_u8: bool = True):
+        """z f32 [1,32,h,w] -> (f32 [1,3,8h,8w] or None, u8 [8h,8w,3] or None)  (async)."""
+        z = _req(z, torch.float32, "z")
+        h, w = z.shape[-2], z.shape[-1]
+        of = torch.empty((1, 3, 8 * h, 8 * w), dtype=torch.float32, device=z.device) if want_f32 else None
+        ou = torch.empty((8 * h, 8 * w, 3), dtype=torch.uint8, device=z.device) if want_u8 else None
+        self.ctx._enter()
+        check(lib().flux2mi_vae_decode(self.handle, _ptr(z), h, w, _ptr(of), _ptr(ou)))
+        self.ctx._exit()
+        return of, ou
+
+    def close(self):
+        if self.handle:
+            lib().flux2mi_vae_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,199 @@
+// attention.hip — flash-attention forward for the DiT's joint [text ; image] sequence.
+//
+// Replaces MLXFast.scaledDotProductAttention(queries:keys:values:scale:mask: nil)
+// (Transformer/Flux2Attention.swift:168-174, Flux2ParallelAttention.swift:104-110):
+// softmax(Q K^T / sqrt(128)) V, no mask (pad text tokens are attended), one head per
+// blockIdx.y, B = 1.  bf16 operands, f32 scores / softmax statistics / accumulators.
+//
+// Structure (v1): workgroup = 4 waves = 128 query rows (32 per wave), KV tiles of 64 keys.
+//   * swapped product S^T = K Q^T with v_mfma_f32_32x32x16_bf16: the accumulator puts the
+//     query on the lane and 16 keys in registers, so the row max / row sum are in-register
+//     (+ one cross-half exchange), cdna guide T12.
+//   * P^T (bf16) is fed straight back as the B operand of O^T += V^T P^T: a 32x32
+//     accumulator's registers 8s..8s+7 are exactly one k-step of the next MFMA
+//     (guide §3 "An accumulator tile as the next MFMA's operand").  The k order inside a
+//     step is key = 16s + 8(j>>2) + 4h + (j&3); V is therefore stored transposed
+//     ([head][d][key]) with the keys of every group of 16 permuted to position 8h+4a+b
+//     (done once per block by launch_qk_norm_rope_vt), which makes the A fragment one
+//     contiguous ds_read_b128.
+//   * K tile [64][128] and V^T tile [128][64] are double-buffered in LDS (64 KB per
+//     workgroup, 2 workgroups per CU), XOR-swizzled for conflict-free ds_read_b128;
+//     global->register loads of tile t+1 are issued before the MFMAs of tile t and written
+//     to LDS after them (one barrier per tile).
+#include "dev.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BQ = 128, BKV = 64, HD = 128;
+constexpr int K_TILE_BYTES = BKV * HD * 2;   // 16 KB
+constexpr int V_TILE_BYTES = HD * BKV * 2;   // 16 KB
+constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ q,
+                                                          const uint16_t* __restrict__ k, int ldqk,
+                                                          const uint16_t* __restrict__ vt, int s_pad,
+                                                          uint16_t* __restrict__ out, int ldo, int S,
+                                                          float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE_BYTES];
+
+    const int head = blockIdx.y;
+    const int q0 = blockIdx.x * BQ;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = l31][d = 16ks + 8hi + j]
+    const int qrow = q0 + wid * 32 + l31;
+    const uint16_t* qp = q + (size_t)min(qrow, S - 1) * ldqk + head * HD + hi * 8;
+    bf16x8 qf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+
+    // ---- staging assignment
+    const uint16_t* kbase = k + head * HD;
+    const uint16_t* vbase = vt + (size_t)head * HD * s_pad;
+    int k_row[4], k_chunk[4], k_lds[4], v_lds[4];
+    const uint16_t* v_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = t + 256 * i;
+        k_row[i] = idx >> 4;
+        k_chunk[i] = idx & 15;
+        k_lds[i] = k_row[i] * 256 + ((k_chunk[i] ^ (k_row[i] & 15)) << 4);
+        const int vr = idx >> 3, vc = idx & 7;
+        v_src[i] = vbase + (size_t)vr * s_pad + vc * 8;
+        v_lds[i] = K_TILE_BYTES + vr * 128 + ((vc ^ ((vr >> 1) & 7)) << 4);
+    }
+    u32x4 kreg[4], vreg[4];
+#define ATTN_LOAD_TILE(kt_)                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
+        const int kr_ = min((kt_) * BKV + k_row[i_], S - 1);                                             \
+        kreg[i_] = *reinterpret_cast<const u32x4*>(kbase + (size_t)kr_ * ldqk + k_chunk[i_] * 8);        \
+        vreg[i_] = *reinterpret_cast<const u32x4*>(v_src[i_] + (kt_) * BKV);                             \
+    }
+#define ATTN_STORE_TILE(buf_)                                                                            \
+    {                                                                                                    \
+        uint8_t* base_ = smem + (buf_) * STAGE_BYTES;                                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                               \
+            *reinterpret_cast<u32x4*>(base_ + k_lds[i_]) = kreg[i_];                                     \
+            *reinterpret_cast<u32x4*>(base_ + v_lds[i_]) = vreg[i_];                                     \
+        }                                                                                                \
+    }
+
+    f32x16 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nt = (S + BKV - 1) / BKV;
+    ATTN_LOAD_TILE(0)
+    ATTN_STORE_TILE(0)
+    __syncthreads();
+
+    for (int kt = 0; kt < nt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nt) { ATTN_LOAD_TILE(kt + 1) }
+        const uint8_t* sk = smem + buf * STAGE_BYTES;
+        const uint8_t* sv = sk + K_TILE_BYTES;
+
+        // ---- S^T = K Q^T  (A = K rows, B = Q^T)
+        f32x16 sa[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sa[kb][r] = 0.f;
+            const int row = kb * 32 + l31;
+            const uint8_t* rp = sk + row * 256;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(rp + (((ks * 2 + hi) ^ (row & 15)) << 4));
+                sa[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sa[kb], 0, 0, 0);
+            }
+        }
+
+        // ---- online softmax (base-2), per query = per lane pair (lane, lane^32)
+        float mx = -INFINITY;
+        const bool tail = (kt + 1) * BKV > S;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s = sa[kb][r] * scale_log2e;
+                if (tail) {
+                    const int key = kt * BKV + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= S) s = -INFINITY;
+                }
+                sa[kb][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float rs = 0.f;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pv = __builtin_amdgcn_exp2f(sa[kb][s2 * 8 + j] - m_new);
+                    rs += pv;
+                    pf[kb][s2][j] = (__bf16)pv;
+                }
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+        // ---- O^T += V^T P^T  (A = V^T rows d, B = P^T)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const int row = db * 32 + l31;
+            const uint8_t* rp = sv + row * 128;
+            const int sw = (row >> 1) & 7;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(rp + (((kb * 4 + s2 * 2 + hi) ^ sw) << 4));
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], o[db], 0, 0, 0);
+                }
+        }
+
+        if (kt + 1 < nt) ATTN_STORE_TILE(buf ^ 1)
+        __syncthreads();
+    }
+
+    // ---- normalise and store.  o[db][r]: d = db*32 + (r&3) + 8*(r>>2) + 4*hi, query = l31
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (qrow < S) {
+        uint16_t* op = out + (size_t)qrow * ldo + head * HD + hi * 4;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 v;
+                v.x = pack_bf16x2(o[db][g * 4 + 0] * inv, o[db][g * 4 + 1] * inv);
+                v.y = pack_bf16x2(o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv);
+                *reinterpret_cast<uint2*>(op + db * 32 + g * 8) = v;
+            }
+    }
+}
+
+}  // namespace
+
+int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
+                     int s_pad, uint16_t* out, int ldo, int S, int heads) {
+    if (S <= 0 || heads <= 0 || (ldqk & 7) || (ldo & 3) || s_pad < attn_s_pad(S) || (s_pad & 7)) return 1;
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
+    dim3 grid((S + BQ - 1) / BQ, heads);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, stream, q, k, ldqk, vt, s_pad, out, ldo, S,
+                       scale_log2e);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}

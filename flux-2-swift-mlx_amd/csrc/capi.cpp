@@ -1,0 +1,315 @@
+// capi.cpp — context, errors, host-side scheduler / latent utilities and the thin
+// wrappers of the elementwise device ops.  Host logic restates, in C++, the Swift host
+// code of the reference (no Swift toolchain exists on the target image).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+
+void flux2mi_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* flux2mi_last_error(void) { return g_err; }
+extern "C" int flux2mi_version(void) { return FLUX2MI_VERSION; }
+
+// ------------------------------------------------------------------ DevBuf
+int DevBuf::reserve(size_t n) {
+    if (n <= bytes) return FLUX2MI_OK;
+    if (ptr) {
+        (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    const size_t rounded = (n + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&ptr, rounded);
+    if (e != hipSuccess) {
+        ptr = nullptr;
+        flux2mi_set_error("hipMalloc(%zu bytes) failed: %s", rounded, hipGetErrorString(e));
+        return FLUX2MI_ERR_OOM;
+    }
+    bytes = rounded;
+    return FLUX2MI_OK;
+}
+void DevBuf::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+// ------------------------------------------------------------------ context
+extern "C" int flux2mi_ctx_create(int device, void* hip_stream, flux2mi_ctx** out) {
+    F2_REQUIRE(out != nullptr, FLUX2MI_ERR_INVALID_ARG, "ctx_create: out is NULL");
+    int ndev = 0;
+    F2_CHECK_HIP(hipGetDeviceCount(&ndev));
+    F2_REQUIRE(device >= 0 && device < ndev, FLUX2MI_ERR_INVALID_ARG, "ctx_create: device %d of %d", device, ndev);
+    F2_CHECK_HIP(hipSetDevice(device));
+    flux2mi_ctx* c = new flux2mi_ctx();
+    c->device = device;
+    if (hip_stream) {
+        c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+        c->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            flux2mi_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            return FLUX2MI_ERR_HIP;
+        }
+        c->own_stream = true;
+    }
+    *out = c;
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_ctx_destroy(flux2mi_ctx* ctx) {
+    if (!ctx) return FLUX2MI_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (hipEvent_t e : ctx->prof.pool) (void)hipEventDestroy(e);
+    ctx->scratch.release();
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_ctx_sync(flux2mi_ctx* ctx) {
+    F2_REQUIRE(ctx, FLUX2MI_ERR_INVALID_ARG, "ctx_sync: NULL ctx");
+    F2_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return FLUX2MI_OK;
+}
+extern "C" void* flux2mi_ctx_stream(flux2mi_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// ------------------------------------------------------------------ profiling (HIP events around one kernel class)
+void prof_before(flux2mi_ctx* ctx, int cls_mask) {
+    ProfState& p = ctx->prof;
+    if (p.active_class < 0 || !(cls_mask & (1 << p.active_class))) return;
+    if (p.used + 2 > p.pool.size()) {
+        for (int i = 0; i < 512; ++i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            p.pool.push_back(e);
+        }
+    }
+    (void)hipEventRecord(p.pool[p.used], ctx->stream);
+}
+void prof_after(flux2mi_ctx* ctx, int cls_mask, double flops) {
+    ProfState& p = ctx->prof;
+    if (p.active_class < 0 || !(cls_mask & (1 << p.active_class))) return;
+    if (p.used + 2 > p.pool.size()) return;
+    (void)hipEventRecord(p.pool[p.used + 1], ctx->stream);
+    p.used += 2;
+    p.flops += flops;
+}
+
+extern "C" int flux2mi_prof_begin(flux2mi_ctx* ctx, int kernel_class) {
+    F2_REQUIRE(ctx && kernel_class >= 0 && kernel_class < 8, FLUX2MI_ERR_INVALID_ARG, "prof_begin: bad args");
+    ProfState& p = ctx->prof;
+    p.used = 0;
+    p.flops = 0.0;
+    while (p.pool.size() < 8192) {
+        hipEvent_t e;
+        F2_CHECK_HIP(hipEventCreate(&e));
+        p.pool.push_back(e);
+    }
+    p.active_class = kernel_class;
+    return FLUX2MI_OK;
+}
+extern "C" int flux2mi_prof_end(flux2mi_ctx* ctx, int* n_launches, double* total_ms, double* flops) {
+    F2_REQUIRE(ctx, FLUX2MI_ERR_INVALID_ARG, "prof_end: NULL ctx");
+    ProfState& p = ctx->prof;
+    p.active_class = -1;
+    F2_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < p.used; i += 2) {
+        float t = 0.f;
+        F2_CHECK_HIP(hipEventElapsedTime(&t, p.pool[i], p.pool[i + 1]));
+        ms += t;
+    }
+    if (n_launches) *n_launches = (int)(p.used / 2);
+    if (total_ms) *total_ms = ms;
+    if (flops) *flops = p.flops;
+    p.used = 0;
+    return FLUX2MI_OK;
+}
+
+// ------------------------------------------------------------------ scheduler (host)
+// Flux2Core/Scheduler/FlowMatchEulerScheduler.swift — Swift `Float` arithmetic == C float.
+extern "C" float flux2mi_compute_empirical_mu(int image_seq_len, int num_steps) {  // :9-28
+    const float a1 = 8.73809524e-05f, b1 = 1.89833333f;
+    const float a2 = 0.00016927f, b2 = 0.45666666f;
+    if (image_seq_len > 4300) return a2 * (float)image_seq_len + b2;
+    const float m_200 = a2 * (float)image_seq_len + b2;
+    const float m_10 = a1 * (float)image_seq_len + b1;
+    const float a = (m_200 - m_10) / 190.0f;
+    const float b = m_200 - 200.0f * a;
+    return a * (float)num_steps + b;
+}
+
+static float time_shift(float mu, float sigma, float t) {  // :123-128
+    const float exp_mu = expf(mu);
+    const float den = exp_mu + powf(1.0f / t - 1.0f, sigma);
+    return exp_mu / den;
+}
+
+extern "C" int flux2mi_set_timesteps(int num_inference_steps, int image_seq_len, float strength,
+                                     float* sigmas_out, int capacity, int* n_out, int* t_start_out) {  // :65-115
+    F2_REQUIRE(num_inference_steps > 0 && sigmas_out && n_out, FLUX2MI_ERR_INVALID_ARG,
+               "set_timesteps: steps=%d", num_inference_steps);
+    const int seq = image_seq_len > 0 ? image_seq_len : 4096;
+    const float mu = flux2mi_compute_empirical_mu(seq, num_inference_steps);
+    std::vector<float> all((size_t)num_inference_steps + 1);
+    for (int i = 0; i < num_inference_steps; ++i) {
+        const float s = 1.0f - (float)i / (float)num_inference_steps;
+        all[i] = time_shift(mu, 1.0f, s);
+    }
+    all[num_inference_steps] = 0.0f;
+    const float clamped = fmaxf(0.01f, fminf(1.0f, strength));
+    const int init_idx = num_inference_steps - (int)((float)num_inference_steps * clamped);
+    const int t_start = init_idx > 0 ? init_idx : 0;
+    const int n = num_inference_steps + 1 - t_start;
+    F2_REQUIRE(n <= capacity, FLUX2MI_ERR_INVALID_ARG, "set_timesteps: capacity %d < %d", capacity, n);
+    for (int i = 0; i < n; ++i) sigmas_out[i] = all[t_start + i];
+    *n_out = n;
+    if (t_start_out) *t_start_out = t_start;
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_set_custom_sigmas(const float* sigmas_in, int n_in, float* sigmas_out, int capacity,
+                                         int* n_out) {  // :236-260
+    F2_REQUIRE(sigmas_in && n_in > 0 && sigmas_out && n_out, FLUX2MI_ERR_INVALID_ARG,
+               "set_custom_sigmas: empty sigma list is ignored by the reference");
+    const bool append = sigmas_in[n_in - 1] != 0.0f;
+    const int n = n_in + (append ? 1 : 0);
+    F2_REQUIRE(n <= capacity, FLUX2MI_ERR_INVALID_ARG, "set_custom_sigmas: capacity %d < %d", capacity, n);
+    for (int i = 0; i < n_in; ++i) sigmas_out[i] = sigmas_in[i];
+    if (append) sigmas_out[n_in] = 0.0f;
+    *n_out = n;
+    return FLUX2MI_OK;
+}
+
+// ------------------------------------------------------------------ latent utils (host) — Pipeline/LatentUtils.swift
+extern "C" void flux2mi_validate_dimensions(int height, int width, int* out_height, int* out_width) {  // :382-394
+    const int f = 16;
+    if (out_height) *out_height = ((height + f - 1) / f) * f;
+    if (out_width) *out_width = ((width + f - 1) / f) * f;
+}
+
+extern "C" void flux2mi_resolve_chain_dimensions(int width, int height, int max_pixels, int* out_height,
+                                                 int* out_width) {  // +ChainHelpers.swift:112-129
+    long w = width, h = height;
+    const long px = w * h;
+    if (max_pixels > 0 && px > max_pixels) {
+        const double scale = sqrt((double)max_pixels / (double)px);
+        w = (long)((double)w * scale);
+        h = (long)((double)h * scale);
+    }
+    w = (w / 32) * 32;
+    h = (h / 32) * 32;
+    if (w < 32) w = 32;
+    if (h < 32) h = 32;
+    if (out_height) *out_height = (int)h;
+    if (out_width) *out_width = (int)w;
+}
+
+extern "C" int flux2mi_image_position_ids(int height, int width, int32_t* out_host, int capacity_rows) {  // :256-286
+    const int nh = height / 8 / 2, nw = width / 8 / 2;
+    F2_REQUIRE(out_host && nh > 0 && nw > 0 && nh * nw <= capacity_rows, FLUX2MI_ERR_INVALID_ARG,
+               "image_position_ids: %dx%d needs %d rows", height, width, nh * nw);
+    for (int y = 0; y < nh; ++y)
+        for (int x = 0; x < nw; ++x) {
+            int32_t* r = out_host + ((size_t)y * nw + x) * 4;
+            r[0] = 0; r[1] = y; r[2] = x; r[3] = 0;
+        }
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_text_position_ids(int length, int32_t* out_host, int capacity_rows) {  // :291-298
+    F2_REQUIRE(out_host && length > 0 && length <= capacity_rows, FLUX2MI_ERR_INVALID_ARG, "text_position_ids: %d",
+               length);
+    for (int l = 0; l < length; ++l) {
+        int32_t* r = out_host + (size_t)l * 4;
+        r[0] = 0; r[1] = 0; r[2] = 0; r[3] = l;
+    }
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_reference_position_ids(const int* latent_heights, const int* latent_widths, int n_images,
+                                              int scale, int32_t* out_host, int capacity_rows) {  // :324-346
+    F2_REQUIRE(latent_heights && latent_widths && out_host && n_images > 0, FLUX2MI_ERR_INVALID_ARG,
+               "reference_position_ids: bad args");
+    long total = 0;
+    for (int i = 0; i < n_images; ++i) total += (long)latent_heights[i] * latent_widths[i];
+    F2_REQUIRE(total <= capacity_rows, FLUX2MI_ERR_INVALID_ARG, "reference_position_ids: need %ld rows", total);
+    size_t row = 0;
+    for (int i = 0; i < n_images; ++i) {
+        const int32_t t = scale + scale * i;
+        for (int y = 0; y < latent_heights[i]; ++y)
+            for (int x = 0; x < latent_widths[i]; ++x) {
+                int32_t* r = out_host + row * 4;
+                r[0] = t; r[1] = y; r[2] = x; r[3] = 0;
+                ++row;
+            }
+    }
+    return FLUX2MI_OK;
+}
+
+// ------------------------------------------------------------------ elementwise device ops
+extern "C" int flux2mi_sched_step(flux2mi_ctx* ctx, float* x, const float* v, float dt, int64_t n) {
+    F2_REQUIRE(ctx && x && v && n > 0, FLUX2MI_ERR_INVALID_ARG, "sched_step: bad args");
+    F2_LAUNCH(launch_axpy(ctx->stream, x, v, dt, n), "sched_step");
+    return FLUX2MI_OK;
+}
+extern "C" int flux2mi_scale_noise(flux2mi_ctx* ctx, float* out, const float* sample, const float* noise,
+                                   float sigma, int64_t n) {
+    F2_REQUIRE(ctx && out && sample && noise && n > 0, FLUX2MI_ERR_INVALID_ARG, "scale_noise: bad args");
+    F2_LAUNCH(launch_lerp(ctx->stream, out, sample, noise, sigma, n), "scale_noise");
+    return FLUX2MI_OK;
+}
+extern "C" int flux2mi_cfg_combine(flux2mi_ctx* ctx, float* v_cond, const float* v_uncond, float guidance,
+                                   int64_t n) {
+    F2_REQUIRE(ctx && v_cond && v_uncond && n > 0, FLUX2MI_ERR_INVALID_ARG, "cfg_combine: bad args");
+    F2_LAUNCH(launch_cfg_combine(ctx->stream, v_cond, v_uncond, guidance, n), "cfg_combine");
+    return FLUX2MI_OK;
+}
+extern "C" int flux2mi_repaint_blend(flux2mi_ctx* ctx, float* x, const float* image_latents,
+                                     const float* blend_noise, const float* mask, float sigma_next, int seq,
+                                     int channels) {
+    F2_REQUIRE(ctx && x && image_latents && blend_noise && mask, FLUX2MI_ERR_INVALID_ARG, "repaint_blend: bad args");
+    F2_LAUNCH(launch_repaint_blend(ctx->stream, x, image_latents, blend_noise, mask, sigma_next, seq, channels),
+              "repaint_blend");
+    return FLUX2MI_OK;
+}
+extern "C" int flux2mi_pack_patchified_to_sequence(flux2mi_ctx* ctx, const float* patchified, float* seq, int c,
+                                                   int h, int w) {
+    F2_REQUIRE(ctx && patchified && seq, FLUX2MI_ERR_INVALID_ARG, "pack_patchified: bad args");
+    F2_LAUNCH(launch_transpose_2d(ctx->stream, patchified, seq, c, h * w), "pack_patchified_to_sequence");
+    return FLUX2MI_OK;
+}
+extern "C" int flux2mi_unpack_sequence_to_patchified(flux2mi_ctx* ctx, const float* seq, float* patchified, int c,
+                                                     int h, int w) {
+    F2_REQUIRE(ctx && patchified && seq, FLUX2MI_ERR_INVALID_ARG, "unpack_sequence: bad args");
+    F2_LAUNCH(launch_transpose_2d(ctx->stream, seq, patchified, h * w, c), "unpack_sequence_to_patchified");
+    return FLUX2MI_OK;
+}
+extern "C" int flux2mi_latents_to_vae_input(flux2mi_ctx* ctx, const float* packed, const float* bn_mean,
+                                            const float* bn_var, float* z, int h16, int w16) {
+    F2_REQUIRE(ctx && packed && bn_mean && bn_var && z, FLUX2MI_ERR_INVALID_ARG, "latents_to_vae_input: bad args");
+    F2_LAUNCH(launch_latents_to_vae_input(ctx->stream, packed, bn_mean, bn_var, z, h16, w16), "latents_to_vae_input");
+    return FLUX2MI_OK;
+}
+extern "C" int flux2mi_vae_latents_to_packed(flux2mi_ctx* ctx, const float* z, const float* bn_mean,
+                                             const float* bn_var, float* packed, int h16, int w16) {
+    F2_REQUIRE(ctx && packed && bn_mean && bn_var && z, FLUX2MI_ERR_INVALID_ARG, "vae_latents_to_packed: bad args");
+    F2_LAUNCH(launch_vae_latents_to_packed(ctx->stream, z, bn_mean, bn_var, packed, h16, w16), "vae_latents_to_packed");
+    return FLUX2MI_OK;
+}

@@ -1,0 +1,72 @@
+// common.h — host-side shared declarations of libflux2mi (context, errors, buffers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/flux2mi.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits on the host side
+
+void flux2mi_set_error(const char* fmt, ...);
+
+#define F2_CHECK_HIP(expr)                                                                  \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            flux2mi_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return FLUX2MI_ERR_HIP;                                                         \
+        }                                                                                   \
+    } while (0)
+
+#define F2_REQUIRE(cond, code, ...)            \
+    do {                                       \
+        if (!(cond)) {                         \
+            flux2mi_set_error(__VA_ARGS__);    \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+#define F2_TRY(expr)                 \
+    do {                             \
+        int _s = (expr);             \
+        if (_s != FLUX2MI_OK) return _s; \
+    } while (0)
+
+#define F2_LAUNCH(expr, what)                                                                   \
+    do {                                                                                        \
+        int _r = (expr);                                                                        \
+        if (_r == 1) { flux2mi_set_error("%s: invalid argument", what); return FLUX2MI_ERR_INVALID_ARG; } \
+        if (_r != 0) { flux2mi_set_error("%s: kernel launch failed: %s", what, hipGetErrorString(hipGetLastError())); return FLUX2MI_ERR_HIP; } \
+    } while (0)
+
+// kernel classes for flux2mi_prof_begin (bit masks passed to prof_before/after)
+enum { PROF_LINEAR1 = 1 << 0, PROF_DIT_GEMM = 1 << 1, PROF_ATTENTION = 1 << 2, PROF_VAE_CONV = 1 << 3 };
+
+// Grow-only device buffer (no allocation inside the steady-state loop).
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t n);
+    void release();
+    template <class T> T* as() { return reinterpret_cast<T*>(ptr); }
+};
+
+struct ProfState {
+    int active_class = -1;
+    std::vector<hipEvent_t> pool;   // pairs (start, stop)
+    size_t used = 0;
+    double flops = 0.0;
+};
+
+struct flux2mi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    ProfState prof;
+    DevBuf scratch;  // small misc scratch
+};
+
+// profiling helpers: bracket a launch of class `cls` with events when active.
+void prof_before(flux2mi_ctx* ctx, int cls_mask);
+void prof_after(flux2mi_ctx* ctx, int cls_mask, double flops);

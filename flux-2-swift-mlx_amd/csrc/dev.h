@@ -1,0 +1,35 @@
+// dev.h — device-side helpers shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // staging registers (HIP uint4 arrays are not SROA-promoted)
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
+    return __builtin_bit_cast(float, (uint32_t)b << 16);
+}
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+    __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN-preserving
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+__device__ __forceinline__ float lo_bf16(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float hi_bf16(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}

@@ -1,0 +1,553 @@
+// dit.cpp — Flux2Transformer2DModel on MI355X: weight ingestion (BFL + diffusers key
+// schemes), HBM-resident bf16 weights with the fused layouts the kernels want, and the
+// forward orchestration (Transformer/Flux2Transformer.swift:123-327).
+//
+// Data layout in HBM (B = 1, S = S_txt + S_img, joint order [text ; image (; refs)]):
+//   hs    f32  [S, d]      residual stream (f32 like the reference's activations)
+//   xn    bf16 [S, d]      LayerNorm+modulate output = GEMM A operand
+//   qkv   bf16 [S, 3d]     q | k | v, RMSNorm+RoPE applied in place on q,k
+//   vt    bf16 [H,128,Sp]  V transposed + key-permuted for the attention PV operand
+//   comb  bf16 [S, 4d]     single blocks: attention output (cols 0..d) | SwiGLU hidden (d..4d)
+//                          double blocks: attention output [S,d] (ld d) and FF hidden [S,3d]
+//   mods  f32              temb, per-stream (shift,scale,gate) vectors, final (shift,scale)
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+enum Transform { T_DIRECT = 0, T_SWIGLU = 1, T_LINEAR1 = 2, T_SWAP_HALVES = 3 };
+
+struct Slot {
+    int buf;         // index into bufs
+    int row_off;     // destination row offset (T_DIRECT)
+    int rows, cols;  // expected source shape
+    int transform;
+};
+
+struct Buf {
+    uint16_t* ptr = nullptr;
+    int rows = 0, cols = 0;
+    int got_rows = 0;
+    std::string label;
+};
+
+}  // namespace
+
+struct flux2mi_dit {
+    flux2mi_ctx* ctx = nullptr;
+    flux2mi_dit_config cfg{};
+    std::vector<Buf> bufs;
+    std::unordered_map<std::string, Slot> slots;
+    bool finalized = false;
+    int64_t param_bytes = 0;
+
+    // resolved weight pointers
+    uint16_t *img_in = nullptr, *txt_in = nullptr, *time_in = nullptr, *time_out = nullptr;
+    uint16_t *guid_in = nullptr, *guid_out = nullptr;
+    uint16_t *mod_img = nullptr, *mod_txt = nullptr, *mod_single = nullptr, *final_mod = nullptr, *final_lin = nullptr;
+    struct Dbl { uint16_t *qkv[2], *proj[2], *qn[2], *kn[2], *mlp_in[2], *mlp_out[2]; };  // [0]=txt, [1]=img
+    struct Sgl { uint16_t *lin1, *lin2, *qn, *kn; };
+    std::vector<Dbl> dbl;
+    std::vector<Sgl> sgl;
+
+    // staging for ingestion
+    DevBuf stage_raw, stage_bf16;
+    // forward workspace
+    DevBuf hs, xn, qkv, vt, comb, mods, rope, lat_bf16;
+    int ws_S = 0;
+};
+
+namespace {
+
+int add_buf(flux2mi_dit* m, int rows, int cols, const std::string& label) {
+    Buf b;
+    b.rows = rows;
+    b.cols = cols;
+    b.label = label;
+    m->bufs.push_back(b);
+    return (int)m->bufs.size() - 1;
+}
+void add_slot(flux2mi_dit* m, const std::string& name, int buf, int row_off, int rows, int cols, int transform) {
+    m->slots[name] = Slot{buf, row_off, rows, cols, transform};
+}
+
+// Build the name -> slot registry for both key schemes.
+void build_registry(flux2mi_dit* m) {
+    const int d = m->cfg.dim, J = m->cfg.joint_dim;
+    auto simple = [&](int rows, int cols, const std::string& label, std::initializer_list<const char*> names,
+                      int transform = T_DIRECT) {
+        const int b = add_buf(m, rows, cols, label);
+        for (const char* n : names) add_slot(m, n, b, 0, rows, cols, transform);
+        return b;
+    };
+    // BFL name first, diffusers alias second (WeightLoader.swift:99-205 / :397-480)
+    simple(d, 128, "img_in", {"img_in.weight", "x_embedder.weight"});
+    simple(d, J, "txt_in", {"txt_in.weight", "context_embedder.weight"});
+    simple(d, 256, "time_in.in", {"time_in.in_layer.weight", "time_guidance_embed.timestep_embedder.linear_1.weight"});
+    simple(d, d, "time_in.out", {"time_in.out_layer.weight", "time_guidance_embed.timestep_embedder.linear_2.weight"});
+    if (m->cfg.guidance_embeds) {
+        simple(d, 256, "guidance_in.in",
+               {"guidance_in.in_layer.weight", "time_guidance_embed.guidance_embedder.linear_1.weight"});
+        simple(d, d, "guidance_in.out",
+               {"guidance_in.out_layer.weight", "time_guidance_embed.guidance_embedder.linear_2.weight"});
+    }
+    simple(6 * d, d, "mod_img", {"double_stream_modulation_img.lin.weight", "double_stream_modulation_img.linear.weight"});
+    simple(6 * d, d, "mod_txt", {"double_stream_modulation_txt.lin.weight", "double_stream_modulation_txt.linear.weight"});
+    simple(3 * d, d, "mod_single", {"single_stream_modulation.lin.weight", "single_stream_modulation.linear.weight"});
+    {
+        // internal order = BFL order [shift | scale]; the diffusers file stores [scale | shift]
+        // (WeightLoader.swift:182-202 swaps BFL -> diffusers; we swap the other way).
+        const int b = add_buf(m, 2 * d, d, "final_mod");
+        add_slot(m, "final_layer.adaLN_modulation.1.weight", b, 0, 2 * d, d, T_DIRECT);
+        add_slot(m, "norm_out.linear.weight", b, 0, 2 * d, d, T_SWAP_HALVES);
+    }
+    simple(128, d, "final_lin", {"final_layer.linear.weight", "proj_out.weight"});
+
+    char a[160], c[160];
+    for (int i = 0; i < m->cfg.n_double; ++i) {
+        for (int s = 0; s < 2; ++s) {  // 0 = txt, 1 = img
+            const char* bs = s ? "img" : "txt";
+            // fused qkv [3d, d]
+            snprintf(a, sizeof a, "dbl%d.%s.qkv", i, bs);
+            const int bq = add_buf(m, 3 * d, d, a);
+            snprintf(a, sizeof a, "double_blocks.%d.%s_attn.qkv.weight", i, bs);
+            add_slot(m, a, bq, 0, 3 * d, d, T_DIRECT);
+            const char* dq[3] = {s ? "to_q" : "add_q_proj", s ? "to_k" : "add_k_proj", s ? "to_v" : "add_v_proj"};
+            for (int j = 0; j < 3; ++j) {
+                snprintf(a, sizeof a, "transformer_blocks.%d.attn.%s.weight", i, dq[j]);
+                add_slot(m, a, bq, j * d, d, d, T_DIRECT);
+            }
+            snprintf(a, sizeof a, "double_blocks.%d.%s_attn.proj.weight", i, bs);
+            snprintf(c, sizeof c, "transformer_blocks.%d.attn.%s.weight", i, s ? "to_out.0" : "to_add_out");
+            simple(d, d, a, {a, c});
+            snprintf(a, sizeof a, "double_blocks.%d.%s_attn.norm.query_norm.scale", i, bs);
+            snprintf(c, sizeof c, "transformer_blocks.%d.attn.%s.weight", i, s ? "norm_q" : "norm_added_q");
+            simple(1, 128, a, {a, c});
+            snprintf(a, sizeof a, "double_blocks.%d.%s_attn.norm.key_norm.scale", i, bs);
+            snprintf(c, sizeof c, "transformer_blocks.%d.attn.%s.weight", i, s ? "norm_k" : "norm_added_k");
+            simple(1, 128, a, {a, c});
+            snprintf(a, sizeof a, "double_blocks.%d.%s_mlp.0.weight", i, bs);
+            snprintf(c, sizeof c, "transformer_blocks.%d.%s.linear_in.weight", i, s ? "ff" : "ff_context");
+            simple(6 * d, d, a, {a, c}, T_SWIGLU);
+            snprintf(a, sizeof a, "double_blocks.%d.%s_mlp.2.weight", i, bs);
+            snprintf(c, sizeof c, "transformer_blocks.%d.%s.linear_out.weight", i, s ? "ff" : "ff_context");
+            simple(d, 3 * d, a, {a, c});
+        }
+    }
+    for (int i = 0; i < m->cfg.n_single; ++i) {
+        snprintf(a, sizeof a, "single_blocks.%d.linear1.weight", i);
+        snprintf(c, sizeof c, "single_transformer_blocks.%d.attn.to_qkv_mlp_proj.weight", i);
+        simple(9 * d, d, a, {a, c}, T_LINEAR1);
+        snprintf(a, sizeof a, "single_blocks.%d.linear2.weight", i);
+        snprintf(c, sizeof c, "single_transformer_blocks.%d.attn.to_out.weight", i);
+        simple(d, 4 * d, a, {a, c});
+        snprintf(a, sizeof a, "single_blocks.%d.norm.query_norm.scale", i);
+        snprintf(c, sizeof c, "single_transformer_blocks.%d.attn.norm_q.weight", i);
+        simple(1, 128, a, {a, c});
+        snprintf(a, sizeof a, "single_blocks.%d.norm.key_norm.scale", i);
+        snprintf(c, sizeof c, "single_transformer_blocks.%d.attn.norm_k.weight", i);
+        simple(1, 128, a, {a, c});
+    }
+}
+
+uint16_t* buf_by_label(flux2mi_dit* m, const std::string& label) {
+    for (Buf& b : m->bufs)
+        if (b.label == label) return b.ptr;
+    return nullptr;
+}
+
+size_t dtype_size(int dtype) { return dtype == FLUX2MI_F32 ? 4 : 2; }
+
+}  // namespace
+
+extern "C" int flux2mi_dit_preset(const char* name, flux2mi_dit_config* out) {
+    F2_REQUIRE(name && out, FLUX2MI_ERR_INVALID_ARG, "dit_preset: NULL argument");
+    // Configuration/Flux2Config.swift:258-329
+    if (!strcmp(name, "klein-4b")) *out = flux2mi_dit_config{3072, 24, 5, 20, 7680, 0};
+    else if (!strcmp(name, "klein-9b")) *out = flux2mi_dit_config{4096, 32, 8, 24, 12288, 0};
+    else if (!strcmp(name, "dev")) *out = flux2mi_dit_config{6144, 48, 8, 48, 15360, 1};
+    else {
+        flux2mi_set_error("dit_preset: unknown model '%s'", name);
+        return FLUX2MI_ERR_INVALID_ARG;
+    }
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_dit_create(flux2mi_ctx* ctx, const flux2mi_dit_config* cfg, flux2mi_dit** out) {
+    F2_REQUIRE(ctx && cfg && out, FLUX2MI_ERR_INVALID_ARG, "dit_create: NULL argument");
+    F2_REQUIRE(cfg->dim == cfg->heads * 128 && cfg->dim > 0 && cfg->dim <= 8192 && cfg->n_double >= 0 &&
+                   cfg->n_single >= 0 && cfg->joint_dim > 0 && cfg->joint_dim % 64 == 0,
+               FLUX2MI_ERR_INVALID_ARG, "dit_create: invalid config (dim %d heads %d joint %d)", cfg->dim, cfg->heads,
+               cfg->joint_dim);
+    F2_CHECK_HIP(hipSetDevice(ctx->device));
+    flux2mi_dit* m = new flux2mi_dit();
+    m->ctx = ctx;
+    m->cfg = *cfg;
+    build_registry(m);
+    for (Buf& b : m->bufs) {
+        const size_t bytes = (size_t)b.rows * b.cols * 2;
+        hipError_t e = hipMalloc((void**)&b.ptr, bytes);
+        if (e != hipSuccess) {
+            flux2mi_set_error("dit_create: hipMalloc(%zu) for %s failed: %s", bytes, b.label.c_str(),
+                              hipGetErrorString(e));
+            flux2mi_dit_destroy(m);
+            return FLUX2MI_ERR_OOM;
+        }
+        m->param_bytes += (int64_t)bytes;
+    }
+    *out = m;
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_dit_destroy(flux2mi_dit* m) {
+    if (!m) return FLUX2MI_OK;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    for (Buf& b : m->bufs)
+        if (b.ptr) (void)hipFree(b.ptr);
+    DevBuf* ws[] = {&m->stage_raw, &m->stage_bf16, &m->hs, &m->xn, &m->qkv, &m->vt, &m->comb, &m->mods, &m->rope,
+                    &m->lat_bf16};
+    for (DevBuf* w : ws) w->release();
+    delete m;
+    return FLUX2MI_OK;
+}
+
+extern "C" int64_t flux2mi_dit_param_bytes(const flux2mi_dit* m) { return m ? m->param_bytes : 0; }
+
+extern "C" int flux2mi_dit_set_tensor(flux2mi_dit* m, const char* name, int dtype, const int64_t* shape, int ndim,
+                                      const void* data) {
+    F2_REQUIRE(m && name && shape && data, FLUX2MI_ERR_INVALID_ARG, "dit_set_tensor: NULL argument");
+    F2_REQUIRE(dtype == FLUX2MI_F32 || dtype == FLUX2MI_BF16 || dtype == FLUX2MI_F16, FLUX2MI_ERR_INVALID_ARG,
+               "dit_set_tensor(%s): unsupported dtype %d", name, dtype);
+    auto it = m->slots.find(name);
+    if (it == m->slots.end()) {
+        flux2mi_set_error("dit_set_tensor: unknown key '%s'", name);
+        return FLUX2MI_ERR_INVALID_ARG;
+    }
+    const Slot& s = it->second;
+    int64_t rows = 1, cols = 1;
+    if (ndim == 1) { rows = 1; cols = shape[0]; }
+    else if (ndim == 2) { rows = shape[0]; cols = shape[1]; }
+    else { flux2mi_set_error("dit_set_tensor(%s): ndim %d", name, ndim); return FLUX2MI_ERR_SHAPE; }
+    F2_REQUIRE(rows == s.rows && cols == s.cols, FLUX2MI_ERR_SHAPE, "dit_set_tensor(%s): shape [%lld,%lld], expected [%d,%d]",
+               name, (long long)rows, (long long)cols, s.rows, s.cols);
+    F2_CHECK_HIP(hipSetDevice(m->ctx->device));
+    hipStream_t st = m->ctx->stream;
+    const int64_t n = rows * cols;
+    Buf& b = m->bufs[s.buf];
+    // 1. bring the bytes onto the device (src may be host or device memory)
+    F2_TRY(m->stage_raw.reserve((size_t)n * dtype_size(dtype)));
+    F2_CHECK_HIP(hipMemcpyAsync(m->stage_raw.ptr, data, (size_t)n * dtype_size(dtype), hipMemcpyDefault, st));
+    // 2. convert to bf16
+    const uint16_t* src = nullptr;
+    if (dtype == FLUX2MI_BF16) {
+        src = m->stage_raw.as<uint16_t>();
+    } else {
+        F2_TRY(m->stage_bf16.reserve((size_t)n * 2));
+        F2_LAUNCH(launch_convert_to_bf16(st, m->stage_raw.ptr, dtype, m->stage_bf16.as<uint16_t>(), n), "convert_to_bf16");
+        src = m->stage_bf16.as<uint16_t>();
+    }
+    // 3. place with the layout transform
+    const size_t row_bytes = (size_t)cols * 2;
+    switch (s.transform) {
+        case T_DIRECT:
+            F2_CHECK_HIP(hipMemcpyAsync(b.ptr + (size_t)s.row_off * cols, src, (size_t)rows * row_bytes,
+                                        hipMemcpyDeviceToDevice, st));
+            break;
+        case T_SWAP_HALVES: {
+            const size_t half = (size_t)(rows / 2) * cols;
+            F2_CHECK_HIP(hipMemcpyAsync(b.ptr, src + half, half * 2, hipMemcpyDeviceToDevice, st));
+            F2_CHECK_HIP(hipMemcpyAsync(b.ptr + half, src, half * 2, hipMemcpyDeviceToDevice, st));
+            break;
+        }
+        case T_SWIGLU:
+            F2_LAUNCH(launch_swiglu_interleave_rows(st, src, b.ptr, (int)(rows / 2), (int)cols), "swiglu_interleave");
+            break;
+        case T_LINEAR1: {
+            const int d = m->cfg.dim;
+            F2_CHECK_HIP(hipMemcpyAsync(b.ptr, src, (size_t)3 * d * row_bytes, hipMemcpyDeviceToDevice, st));
+            F2_LAUNCH(launch_swiglu_interleave_rows(st, src + (size_t)3 * d * cols, b.ptr + (size_t)3 * d * cols, 3 * d,
+                                                    (int)cols),
+                      "swiglu_interleave(linear1)");
+            break;
+        }
+    }
+    F2_CHECK_HIP(hipStreamSynchronize(st));  // the caller may free `data` on return
+    b.got_rows += (int)rows;
+    m->finalized = false;
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_dit_finalize(flux2mi_dit* m) {
+    F2_REQUIRE(m, FLUX2MI_ERR_INVALID_ARG, "dit_finalize: NULL");
+    for (const Buf& b : m->bufs) {
+        if (b.got_rows < b.rows) {
+            flux2mi_set_error("dit_finalize: tensor '%s' missing (%d of %d rows loaded)", b.label.c_str(), b.got_rows,
+                              b.rows);
+            return FLUX2MI_ERR_NOT_LOADED;
+        }
+    }
+    char a[160];
+    m->img_in = buf_by_label(m, "img_in");
+    m->txt_in = buf_by_label(m, "txt_in");
+    m->time_in = buf_by_label(m, "time_in.in");
+    m->time_out = buf_by_label(m, "time_in.out");
+    m->guid_in = buf_by_label(m, "guidance_in.in");
+    m->guid_out = buf_by_label(m, "guidance_in.out");
+    m->mod_img = buf_by_label(m, "mod_img");
+    m->mod_txt = buf_by_label(m, "mod_txt");
+    m->mod_single = buf_by_label(m, "mod_single");
+    m->final_mod = buf_by_label(m, "final_mod");
+    m->final_lin = buf_by_label(m, "final_lin");
+    m->dbl.resize(m->cfg.n_double);
+    for (int i = 0; i < m->cfg.n_double; ++i)
+        for (int s = 0; s < 2; ++s) {
+            const char* bs = s ? "img" : "txt";
+            snprintf(a, sizeof a, "dbl%d.%s.qkv", i, bs);
+            m->dbl[i].qkv[s] = buf_by_label(m, a);
+            snprintf(a, sizeof a, "double_blocks.%d.%s_attn.proj.weight", i, bs);
+            m->dbl[i].proj[s] = buf_by_label(m, a);
+            snprintf(a, sizeof a, "double_blocks.%d.%s_attn.norm.query_norm.scale", i, bs);
+            m->dbl[i].qn[s] = buf_by_label(m, a);
+            snprintf(a, sizeof a, "double_blocks.%d.%s_attn.norm.key_norm.scale", i, bs);
+            m->dbl[i].kn[s] = buf_by_label(m, a);
+            snprintf(a, sizeof a, "double_blocks.%d.%s_mlp.0.weight", i, bs);
+            m->dbl[i].mlp_in[s] = buf_by_label(m, a);
+            snprintf(a, sizeof a, "double_blocks.%d.%s_mlp.2.weight", i, bs);
+            m->dbl[i].mlp_out[s] = buf_by_label(m, a);
+        }
+    m->sgl.resize(m->cfg.n_single);
+    for (int i = 0; i < m->cfg.n_single; ++i) {
+        snprintf(a, sizeof a, "single_blocks.%d.linear1.weight", i);
+        m->sgl[i].lin1 = buf_by_label(m, a);
+        snprintf(a, sizeof a, "single_blocks.%d.linear2.weight", i);
+        m->sgl[i].lin2 = buf_by_label(m, a);
+        snprintf(a, sizeof a, "single_blocks.%d.norm.query_norm.scale", i);
+        m->sgl[i].qn = buf_by_label(m, a);
+        snprintf(a, sizeof a, "single_blocks.%d.norm.key_norm.scale", i);
+        m->sgl[i].kn = buf_by_label(m, a);
+    }
+    m->stage_raw.release();
+    m->stage_bf16.release();
+    m->finalized = true;
+    return FLUX2MI_OK;
+}
+
+// ------------------------------------------------------------------ forward
+namespace {
+
+int ensure_workspace(flux2mi_dit* m, int S, int s_img) {
+    const int d = m->cfg.dim, H = m->cfg.heads;
+    const size_t Sz = (size_t)S;
+    F2_TRY(m->hs.reserve(Sz * d * 4));
+    F2_TRY(m->xn.reserve(Sz * d * 2));
+    F2_TRY(m->qkv.reserve(Sz * 3 * d * 2));
+    const size_t vt_bytes = (size_t)H * 128 * attn_s_pad(S) * 2;
+    if (m->vt.bytes < vt_bytes) {
+        F2_TRY(m->vt.reserve(vt_bytes));
+        F2_CHECK_HIP(hipMemsetAsync(m->vt.ptr, 0, m->vt.bytes, m->ctx->stream));
+    }
+    F2_TRY(m->comb.reserve(Sz * 4 * d * 2));
+    F2_TRY(m->mods.reserve((size_t)(256 + 2 * d + 6 * d + 6 * d + 3 * d + 2 * d) * 4));
+    F2_TRY(m->rope.reserve(Sz * 128 * 4 * 2));
+    F2_TRY(m->lat_bf16.reserve((size_t)s_img * 128 * 2));
+    m->ws_S = S;
+    return FLUX2MI_OK;
+}
+
+GemmProblem mk(const uint16_t* A, int lda, const uint16_t* W, int ldw, void* C, int ldc, int M, int N, int K, int epi) {
+    GemmProblem p;
+    memset(&p, 0, sizeof p);
+    p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.epi = epi; p.alpha = 1.0f;
+    return p;
+}
+
+int run_gemm(flux2mi_dit* m, const GemmProblem* p, int n, int extra_cls, const char* what) {
+    double flops = 0.0;
+    for (int i = 0; i < n; ++i) flops += 2.0 * p[i].M * (double)p[i].N * p[i].K;
+    prof_before(m->ctx, PROF_DIT_GEMM | extra_cls);
+    const int r = launch_gemm(m->ctx->stream, p, n);
+    prof_after(m->ctx, PROF_DIT_GEMM | extra_cls, flops);
+    F2_LAUNCH(r, what);
+    return FLUX2MI_OK;
+}
+
+}  // namespace
+
+extern "C" int flux2mi_dit_forward(flux2mi_dit* m, const float* latents, int s_img, const void* txt_emb, int s_txt,
+                                   float timestep, float guidance, const int32_t* img_ids, const int32_t* txt_ids,
+                                   float* out, int s_out) {
+    F2_REQUIRE(m && latents && txt_emb && img_ids && txt_ids && out, FLUX2MI_ERR_INVALID_ARG, "dit_forward: NULL argument");
+    F2_REQUIRE(m->finalized, FLUX2MI_ERR_NOT_LOADED, "dit_forward: weights not finalized");
+    F2_REQUIRE(s_img > 0 && s_txt > 0 && s_out > 0 && s_out <= s_img, FLUX2MI_ERR_SHAPE,
+               "dit_forward: s_img %d s_txt %d s_out %d", s_img, s_txt, s_out);
+    F2_CHECK_HIP(hipSetDevice(m->ctx->device));
+    hipStream_t st = m->ctx->stream;
+    const int d = m->cfg.dim, H = m->cfg.heads, J = m->cfg.joint_dim;
+    const int S = s_txt + s_img;
+    const int s_pad = attn_s_pad(S);
+    F2_TRY(ensure_workspace(m, S, s_img));
+
+    float* hs = m->hs.as<float>();
+    uint16_t* xn = m->xn.as<uint16_t>();
+    uint16_t* qkv = m->qkv.as<uint16_t>();
+    uint16_t* vt = m->vt.as<uint16_t>();
+    uint16_t* comb = m->comb.as<uint16_t>();
+    float* cos_tab = m->rope.as<float>();
+    float* sin_tab = cos_tab + (size_t)S * 128;
+    // mods layout
+    float* emb = m->mods.as<float>();          // [256]
+    float* tmp = emb + 256;                    // [d]
+    float* temb = tmp + d;                     // [d]
+    float* mod_img = temb + d;                 // [6d]  set0 (shift,scale,gate), set1 (shift,scale,gate)
+    float* mod_txt = mod_img + 6 * d;          // [6d]
+    float* mod_sgl = mod_txt + 6 * d;          // [3d]
+    float* mod_fin = mod_sgl + 3 * d;          // [2d]  (shift, scale)
+
+    // ---- timestep (+guidance) embedding: sinusoid(1000 t) -> Linear -> SiLU -> Linear
+    // (Flux2Transformer.swift:145-149, Flux2Embeddings.swift:124-142)
+    F2_LAUNCH(launch_sinusoid(st, timestep * 1000.0f, emb), "sinusoid");
+    F2_LAUNCH(launch_gemv(st, m->time_in, emb, tmp, d, 256, 0, 0), "time_in.in");
+    F2_LAUNCH(launch_gemv(st, m->time_out, tmp, temb, d, d, 1, 0), "time_in.out");
+    if (m->cfg.guidance_embeds) {
+        F2_LAUNCH(launch_sinusoid(st, guidance * 1000.0f, emb), "sinusoid(g)");
+        F2_LAUNCH(launch_gemv(st, m->guid_in, emb, tmp, d, 256, 0, 0), "guidance_in.in");
+        F2_LAUNCH(launch_gemv(st, m->guid_out, tmp, temb, d, d, 1, 1), "guidance_in.out");
+    }
+    // ---- modulation vectors, once per forward (Flux2Transformer.swift:160-161, 256; Flux2Modulation.swift:49-75)
+    F2_LAUNCH(launch_gemv(st, m->mod_img, temb, mod_img, 6 * d, d, 1, 0), "mod_img");
+    F2_LAUNCH(launch_gemv(st, m->mod_txt, temb, mod_txt, 6 * d, d, 1, 0), "mod_txt");
+    F2_LAUNCH(launch_gemv(st, m->mod_single, temb, mod_sgl, 3 * d, d, 1, 0), "mod_single");
+    F2_LAUNCH(launch_gemv(st, m->final_mod, temb, mod_fin, 2 * d, d, 1, 0), "final_mod");
+    // ---- RoPE tables from the ids of this call (Flux2Transformer.swift:153-154)
+    F2_LAUNCH(launch_rope_tables(st, txt_ids, s_txt, img_ids, s_img, cos_tab, sin_tab), "rope_tables");
+
+    // ---- input projections into the joint residual stream [txt ; img] (:137-138)
+    F2_LAUNCH(launch_f32_to_bf16(st, latents, m->lat_bf16.as<uint16_t>(), (int64_t)s_img * 128), "latents->bf16");
+    {
+        GemmProblem p[2];
+        p[0] = mk(reinterpret_cast<const uint16_t*>(txt_emb), J, m->txt_in, J, hs, d, s_txt, d, J, EPI_F32);
+        p[1] = mk(m->lat_bf16.as<uint16_t>(), 128, m->img_in, 128, hs + (size_t)s_txt * d, d, s_img, d, 128, EPI_F32);
+        F2_TRY(run_gemm(m, p, 2, 0, "embedders"));
+    }
+
+    // ---- double-stream blocks (Flux2TransformerBlock.swift:80-168)
+    for (int i = 0; i < m->cfg.n_double; ++i) {
+        const flux2mi_dit::Dbl& w = m->dbl[i];
+        // attention half: LN -> modulate(set 0) per stream
+        F2_LAUNCH(launch_layernorm_modulate(st, hs, xn, S, d, s_txt, mod_txt + 0 * d, mod_txt + 1 * d, mod_img + 0 * d,
+                                            mod_img + 1 * d), "ln_mod(attn)");
+        {
+            GemmProblem p[2];
+            p[0] = mk(xn, d, w.qkv[0], d, qkv, 3 * d, s_txt, 3 * d, d, EPI_BF16);
+            p[1] = mk(xn + (size_t)s_txt * d, d, w.qkv[1], d, qkv + (size_t)s_txt * 3 * d, 3 * d, s_img, 3 * d, d, EPI_BF16);
+            F2_TRY(run_gemm(m, p, 2, 0, "dbl.qkv"));
+        }
+        F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, s_txt, w.qn[0], w.kn[0], w.qn[1], w.kn[1], cos_tab, sin_tab,
+                                         vt, s_pad), "qk_norm_rope");
+        prof_before(m->ctx, PROF_ATTENTION);
+        const int ar = launch_attention(st, qkv, qkv + d, 3 * d, vt, s_pad, comb, d, S, H);
+        prof_after(m->ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
+        F2_LAUNCH(ar, "attention");
+        {
+            GemmProblem p[2];
+            p[0] = mk(comb, d, w.proj[0], d, hs, d, s_txt, d, d, EPI_GATE_RESID);
+            p[0].vec = mod_txt + 2 * d;
+            p[1] = mk(comb + (size_t)s_txt * d, d, w.proj[1], d, hs + (size_t)s_txt * d, d, s_img, d, d, EPI_GATE_RESID);
+            p[1].vec = mod_img + 2 * d;
+            F2_TRY(run_gemm(m, p, 2, 0, "dbl.proj"));
+        }
+        // feed-forward half: LN -> modulate(set 1) -> Linear(d->6d) SwiGLU -> Linear(3d->d)
+        F2_LAUNCH(launch_layernorm_modulate(st, hs, xn, S, d, s_txt, mod_txt + 3 * d, mod_txt + 4 * d, mod_img + 3 * d,
+                                            mod_img + 4 * d), "ln_mod(ff)");
+        {
+            GemmProblem p[2];
+            p[0] = mk(xn, d, w.mlp_in[0], d, nullptr, 0, s_txt, 6 * d, d, EPI_SWIGLU);
+            p[0].C2 = comb; p[0].ldc2 = 3 * d;
+            p[1] = mk(xn + (size_t)s_txt * d, d, w.mlp_in[1], d, nullptr, 0, s_img, 6 * d, d, EPI_SWIGLU);
+            p[1].C2 = comb + (size_t)s_txt * 3 * d; p[1].ldc2 = 3 * d;
+            F2_TRY(run_gemm(m, p, 2, 0, "dbl.mlp_in"));
+        }
+        {
+            GemmProblem p[2];
+            p[0] = mk(comb, 3 * d, w.mlp_out[0], 3 * d, hs, d, s_txt, d, 3 * d, EPI_GATE_RESID);
+            p[0].vec = mod_txt + 5 * d;
+            p[1] = mk(comb + (size_t)s_txt * 3 * d, 3 * d, w.mlp_out[1], 3 * d, hs + (size_t)s_txt * d, d, s_img, d, 3 * d,
+                      EPI_GATE_RESID);
+            p[1].vec = mod_img + 5 * d;
+            F2_TRY(run_gemm(m, p, 2, 0, "dbl.mlp_out"));
+        }
+    }
+
+    // ---- single-stream blocks on the concatenated stream (Flux2SingleBlock.swift:59-98,
+    // Flux2ParallelAttention.swift:72-123)
+    for (int i = 0; i < m->cfg.n_single; ++i) {
+        const flux2mi_dit::Sgl& w = m->sgl[i];
+        F2_LAUNCH(launch_layernorm_modulate(st, hs, xn, S, d, 0, mod_sgl, mod_sgl + d, mod_sgl, mod_sgl + d), "ln_mod(single)");
+        {
+            GemmProblem p = mk(xn, d, w.lin1, d, qkv, 3 * d, S, 9 * d, d, EPI_QKV_MLP);
+            p.n_split = 3 * d;
+            p.C2 = comb + d;  // SwiGLU hidden goes to columns d..4d of comb
+            p.ldc2 = 4 * d;
+            F2_TRY(run_gemm(m, &p, 1, PROF_LINEAR1, "single.linear1"));
+        }
+        F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, 0, w.qn, w.kn, w.qn, w.kn, cos_tab, sin_tab, vt, s_pad),
+                  "qk_norm_rope");
+        prof_before(m->ctx, PROF_ATTENTION);
+        const int ar = launch_attention(st, qkv, qkv + d, 3 * d, vt, s_pad, comb, 4 * d, S, H);
+        prof_after(m->ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
+        F2_LAUNCH(ar, "attention");
+        {
+            GemmProblem p = mk(comb, 4 * d, w.lin2, 4 * d, hs, d, S, d, 4 * d, EPI_GATE_RESID);
+            p.vec = mod_sgl + 2 * d;
+            F2_TRY(run_gemm(m, &p, 1, 0, "single.linear2"));
+        }
+    }
+
+    // ---- output: drop text tokens, AdaLayerNormContinuous, proj_out (:316-324)
+    F2_LAUNCH(launch_layernorm_modulate(st, hs + (size_t)s_txt * d, xn, s_out, d, 0, mod_fin, mod_fin + d, mod_fin, mod_fin + d),
+              "ln_mod(final)");
+    {
+        GemmProblem p = mk(xn, d, m->final_lin, d, out, 128, s_out, 128, d, EPI_F32);
+        F2_TRY(run_gemm(m, &p, 1, 0, "proj_out"));
+    }
+    return FLUX2MI_OK;
+}
+
+// ------------------------------------------------------------------ standalone ops (tests, microbenchmarks)
+extern "C" int flux2mi_op_gemm_bf16(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K) {
+    F2_REQUIRE(ctx && A && W && C, FLUX2MI_ERR_INVALID_ARG, "op_gemm: NULL argument");
+    GemmProblem p = mk(reinterpret_cast<const uint16_t*>(A), K, reinterpret_cast<const uint16_t*>(W), K, C, N, M, N, K, EPI_F32);
+    prof_before(ctx, PROF_DIT_GEMM);
+    const int r = launch_gemm(ctx->stream, &p, 1);
+    prof_after(ctx, PROF_DIT_GEMM, 2.0 * M * (double)N * K);
+    F2_LAUNCH(r, "op_gemm");
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv_in, void* out, int S, int heads) {
+    F2_REQUIRE(ctx && qkv_in && out && S > 0 && heads > 0, FLUX2MI_ERR_INVALID_ARG, "op_attention: bad argument");
+    const int d = heads * 128, s_pad = attn_s_pad(S);
+    // scratch: a private copy of qkv is not needed (q,k are used as given); only V^T is built.
+    F2_TRY(ctx->scratch.reserve((size_t)heads * 128 * s_pad * 2 + 256 * 4));
+    uint16_t* vt = ctx->scratch.as<uint16_t>();
+    F2_CHECK_HIP(hipMemsetAsync(vt, 0, (size_t)heads * 128 * s_pad * 2, ctx->stream));
+    // V -> V^T only (reuse the transpose half of launch_qk_norm_rope_vt through a helper)
+    F2_LAUNCH(launch_v_transpose_only(ctx->stream, reinterpret_cast<const uint16_t*>(qkv_in), 3 * d, S, heads, vt, s_pad),
+              "v_transpose");
+    const uint16_t* q = reinterpret_cast<const uint16_t*>(qkv_in);
+    prof_before(ctx, PROF_ATTENTION);
+    const int r = launch_attention(ctx->stream, q, q + d, 3 * d, vt, s_pad, reinterpret_cast<uint16_t*>(out), d, S, heads);
+    prof_after(ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
+    F2_LAUNCH(r, "op_attention");
+    return FLUX2MI_OK;
+}

@@ -1,0 +1,242 @@
+// elementwise.hip — small / HBM-bound kernels: sampler arithmetic, layout permutes,
+// timestep embedding, M=1 projections (modulation GEMVs), dtype conversion.
+#include "dev.h"
+#include "kernels.h"
+#include "../../include/flux2mi.h"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+inline unsigned ew_grid(int64_t n_items) {
+    int64_t b = (n_items + EW_BLOCK - 1) / EW_BLOCK;
+    if (b > 256 * 16) b = 256 * 16;  // grid-stride the rest (guide G11)
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+// ---- GEMV: out[n] (+)= sum_k W[n,k] * f(x[k]).  One wave per output row, 16 B/lane loads.
+// M=1 projections are weight-bandwidth bound (time MLP, AdaLN modulations:
+// Flux2Embeddings.swift:59-79, Flux2Modulation.swift:49-75).
+__global__ __launch_bounds__(256) void gemv_kernel(const uint16_t* __restrict__ W, const float* __restrict__ x,
+                                                   float* __restrict__ out, int N, int K, int silu_in,
+                                                   int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const uint16_t* wr = W + (size_t)n * K;
+    float acc = 0.f;
+    for (int k = lane * 8; k < K; k += 64 * 8) {
+        const uint4 w = *reinterpret_cast<const uint4*>(wr + k);
+        const float4 xa = *reinterpret_cast<const float4*>(x + k);
+        const float4 xb = *reinterpret_cast<const float4*>(x + k + 4);
+        float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        if (silu_in) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] = silu_f(xv[j]);
+        }
+        acc += lo_bf16(w.x) * xv[0] + hi_bf16(w.x) * xv[1] + lo_bf16(w.y) * xv[2] + hi_bf16(w.y) * xv[3] +
+               lo_bf16(w.z) * xv[4] + hi_bf16(w.z) * xv[5] + lo_bf16(w.w) * xv[6] + hi_bf16(w.w) * xv[7];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[n] = accumulate ? out[n] + acc : acc;
+}
+
+// ---- sinusoidal embedding: [cos(v f_i) | sin(v f_i)], f_i = exp(-ln(1e4) i/128), i < 128
+__global__ void sinusoid_kernel(float value, float* __restrict__ emb) {
+    const int i = threadIdx.x;  // 128 threads
+    const float f = expf(-9.210340371976184f * (float)i / 128.0f);
+    const float a = value * f;
+    emb[i] = cosf(a);
+    emb[128 + i] = sinf(a);
+}
+
+__global__ void silu_inplace_kernel(float* x, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] = silu_f(x[i]);
+}
+
+// ---- dtype conversion (weights arrive as f32 / bf16 / f16)
+__global__ void to_bf16_kernel(const void* __restrict__ in, int dtype, uint16_t* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v;
+        if (dtype == FLUX2MI_F32) v = reinterpret_cast<const float*>(in)[i];
+        else if (dtype == FLUX2MI_F16) v = (float)reinterpret_cast<const _Float16*>(in)[i];
+        else { out[i] = reinterpret_cast<const uint16_t*>(in)[i]; continue; }
+        out[i] = f32_to_bf16_bits(v);
+    }
+}
+__global__ void to_f32_kernel(const void* __restrict__ in, int dtype, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v;
+        if (dtype == FLUX2MI_F32) v = reinterpret_cast<const float*>(in)[i];
+        else if (dtype == FLUX2MI_F16) v = (float)reinterpret_cast<const _Float16*>(in)[i];
+        else v = bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(in)[i]);
+        out[i] = v;
+    }
+}
+
+// ---- SwiGLU row interleave: out[64b + j] = in[32b + j], out[64b + 32 + j] = in[hidden + 32b + j]
+__global__ void swiglu_interleave_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int hidden,
+                                         int K) {
+    const int r = blockIdx.x;  // output row
+    const int b = r >> 6, j = r & 63;
+    const int src = (j < 32) ? (b * 32 + j) : (hidden + b * 32 + (j - 32));
+    const uint4* s = reinterpret_cast<const uint4*>(in + (size_t)src * K);
+    uint4* d = reinterpret_cast<uint4*>(out + (size_t)r * K);
+    for (int c = threadIdx.x; c < K / 8; c += blockDim.x) d[c] = s[c];
+}
+
+// ---- sampler arithmetic (f32, 16 B/lane)
+__global__ void axpy_kernel(float* __restrict__ x, const float* __restrict__ v, float a, int64_t n4, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 xv = reinterpret_cast<float4*>(x)[i];
+        const float4 vv = reinterpret_cast<const float4*>(v)[i];
+        xv.x += a * vv.x; xv.y += a * vv.y; xv.z += a * vv.z; xv.w += a * vv.w;
+        reinterpret_cast<float4*>(x)[i] = xv;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] += a * v[i];
+}
+__global__ void lerp_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b,
+                            float t, int64_t n) {
+    const float u = 1.0f - t;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = u * a[i] + t * b[i];
+}
+__global__ void cfg_kernel(float* __restrict__ vc, const float* __restrict__ vu, float g, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        vc[i] = vu[i] + g * (vc[i] - vu[i]);
+}
+// RePaint: x = (1-m)*((1-s)*img + s*noise) + m*x, m [S,1]
+__global__ void repaint_kernel(float* __restrict__ x, const float* __restrict__ img, const float* __restrict__ noise,
+                               const float* __restrict__ mask, float s, int64_t n, int c) {
+    const float u = 1.0f - s;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float m = mask[i / c];
+        const float orig = u * img[i] + s * noise[i];
+        x[i] = (1.0f - m) * orig + m * x[i];
+    }
+}
+
+// ---- [rows, cols] f32 -> [cols, rows] (pack / unpack of patchified latents)
+__global__ void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int r = by + j, c = bx + threadIdx.x;
+        if (r < rows && c < cols) tile[j][threadIdx.x] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int c = bx + j, r = by + threadIdx.x;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[threadIdx.x][j];
+    }
+}
+
+// ---- packed [h16*w16,128] -> BN-denormalise -> unpatchify -> z [32, 2*h16, 2*w16]
+// channel index of the patchified tensor = c*4 + py*2 + px (LatentUtils.swift:119-142);
+// x*sqrt(var+1e-4)+mean (LatentUtils.swift:483-496).
+__global__ void latents_to_vae_kernel(const float* __restrict__ packed, const float* __restrict__ mean,
+                                      const float* __restrict__ var, float* __restrict__ z, int h16, int w16) {
+    const int total = h16 * w16 * 128;
+    const int H = 2 * h16, W = 2 * w16;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int pc = i & 127, tok = i >> 7;
+        const int ty = tok / w16, tx = tok % w16;
+        const int c = pc >> 2, py = (pc >> 1) & 1, px = pc & 1;
+        const float v = packed[i] * sqrtf(var[pc] + 1e-4f) + mean[pc];
+        z[((size_t)c * H + (2 * ty + py)) * W + 2 * tx + px] = v;
+    }
+}
+__global__ void vae_to_packed_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                     const float* __restrict__ var, float* __restrict__ packed, int h16, int w16) {
+    const int total = h16 * w16 * 128;
+    const int H = 2 * h16, W = 2 * w16;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int pc = i & 127, tok = i >> 7;
+        const int ty = tok / w16, tx = tok % w16;
+        const int c = pc >> 2, py = (pc >> 1) & 1, px = pc & 1;
+        const float v = z[((size_t)c * H + (2 * ty + py)) * W + 2 * tx + px];
+        packed[i] = (v - mean[pc]) / sqrtf(var[pc] + 1e-4f);
+    }
+}
+
+}  // namespace
+
+#define EW_DONE() return hipGetLastError() == hipSuccess ? 0 : 2
+
+int launch_gemv(hipStream_t stream, const uint16_t* W, const float* x, float* out, int N, int K, int silu_in,
+                int accumulate) {
+    if (N <= 0 || K <= 0 || (K & 7)) return 1;
+    hipLaunchKernelGGL(gemv_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, W, x, out, N, K, silu_in, accumulate);
+    EW_DONE();
+}
+int launch_sinusoid(hipStream_t stream, float value, float* emb) {
+    hipLaunchKernelGGL(sinusoid_kernel, dim3(1), dim3(128), 0, stream, value, emb);
+    EW_DONE();
+}
+int launch_silu_inplace(hipStream_t stream, float* x, int n) {
+    hipLaunchKernelGGL(silu_inplace_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, stream, x, n);
+    EW_DONE();
+}
+int launch_f32_to_bf16(hipStream_t stream, const float* in, uint16_t* out, int64_t n) {
+    return launch_convert_to_bf16(stream, in, FLUX2MI_F32, out, n);
+}
+int launch_convert_to_bf16(hipStream_t stream, const void* in, int dtype, uint16_t* out, int64_t n) {
+    if (n <= 0) return 1;
+    hipLaunchKernelGGL(to_bf16_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, stream, in, dtype, out, n);
+    EW_DONE();
+}
+int launch_convert_to_f32(hipStream_t stream, const void* in, int dtype, float* out, int64_t n) {
+    if (n <= 0) return 1;
+    hipLaunchKernelGGL(to_f32_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, stream, in, dtype, out, n);
+    EW_DONE();
+}
+int launch_swiglu_interleave_rows(hipStream_t stream, const uint16_t* in, uint16_t* out, int hidden, int K) {
+    if (hidden <= 0 || (hidden & 31) || (K & 7)) return 1;
+    hipLaunchKernelGGL(swiglu_interleave_kernel, dim3(2 * hidden), dim3(256), 0, stream, in, out, hidden, K);
+    EW_DONE();
+}
+int launch_axpy(hipStream_t stream, float* x, const float* v, float a, int64_t n) {
+    if (n <= 0) return 1;
+    const bool al = (((uintptr_t)x | (uintptr_t)v) & 15) == 0;
+    const int64_t n4 = al ? n / 4 : 0;
+    hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n4 > 0 ? n4 : n)), dim3(EW_BLOCK), 0, stream, x, v, a, n4, n);
+    EW_DONE();
+}
+int launch_lerp(hipStream_t stream, float* out, const float* a, const float* b, float t, int64_t n) {
+    if (n <= 0) return 1;
+    hipLaunchKernelGGL(lerp_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, stream, out, a, b, t, n);
+    EW_DONE();
+}
+int launch_cfg_combine(hipStream_t stream, float* vc, const float* vu, float g, int64_t n) {
+    if (n <= 0) return 1;
+    hipLaunchKernelGGL(cfg_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, stream, vc, vu, g, n);
+    EW_DONE();
+}
+int launch_repaint_blend(hipStream_t stream, float* x, const float* img, const float* noise, const float* mask,
+                         float sigma_next, int seq, int c) {
+    if (seq <= 0 || c <= 0) return 1;
+    const int64_t n = (int64_t)seq * c;
+    hipLaunchKernelGGL(repaint_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, stream, x, img, noise, mask, sigma_next,
+                       n, c);
+    EW_DONE();
+}
+int launch_transpose_2d(hipStream_t stream, const float* in, float* out, int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 1;
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, stream, in,
+                       out, rows, cols);
+    EW_DONE();
+}
+int launch_latents_to_vae_input(hipStream_t stream, const float* packed, const float* mean, const float* var,
+                                float* z, int h16, int w16) {
+    if (h16 <= 0 || w16 <= 0) return 1;
+    hipLaunchKernelGGL(latents_to_vae_kernel, dim3(ew_grid((int64_t)h16 * w16 * 128)), dim3(EW_BLOCK), 0, stream,
+                       packed, mean, var, z, h16, w16);
+    EW_DONE();
+}
+int launch_vae_latents_to_packed(hipStream_t stream, const float* z, const float* mean, const float* var,
+                                 float* packed, int h16, int w16) {
+    if (h16 <= 0 || w16 <= 0) return 1;
+    hipLaunchKernelGGL(vae_to_packed_kernel, dim3(ew_grid((int64_t)h16 * w16 * 128)), dim3(EW_BLOCK), 0, stream, z,
+                       mean, var, packed, h16, w16);
+    EW_DONE();
+}

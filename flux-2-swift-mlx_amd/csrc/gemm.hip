@@ -1,0 +1,307 @@
+// gemm.hip — bf16 MFMA GEMM for gfx950 with the DiT's fused epilogues.
+//
+//   C[M,N] = A[M,K] (bf16, row-major, lda) x W[N,K]^T (bf16, row-major [out,in], ldw)
+//
+// All `Linear` layers of the reference are bias-free y = x W^T with W stored [out,in]
+// (Transformer/Flux2Transformer.swift:70-111, Flux2Attention.swift:77-94,
+// Flux2FeedForward.swift:56,99, Flux2ParallelAttention.swift:56-64), so both MFMA
+// operands are K-contiguous and are staged identically.
+//
+// Structure (v1, "128x128x64, one barrier per K-tile"):
+//   * 256 threads = 4 waves (2x2), each wave owns a 64x64 sub-tile = 4x4 MFMA
+//     16x16x32 accumulators (64 f32 VGPRs).
+//   * A and W tiles (128 rows x 64 k, 16 KB each) are double-buffered in LDS
+//     (64 KB / workgroup -> 2 workgroups per CU -> 2 waves per SIMD).
+//   * global -> register (16 B/lane, 128-B row segments) issued before the MFMA
+//     block of the current tile and written to LDS after it (T14 split), so HBM/L2
+//     latency hides under the MFMAs; one __syncthreads per K-tile.
+//   * LDS rows are 128 B; the 16-B chunk index is XORed with (row>>1)&7 so that the
+//     ds_read_b128 lane groups are conflict-free (cdna guide §5.5 T2).
+//   * blockIdx -> tile mapping: XCD-aware (blocks b, b+8 share an L2) + grouped-M
+//     ordering so neighbouring tiles share A/W panels in the same L2.
+//   * up to two independent problems per launch (the txt and img streams of a
+//     double block have different weights and row counts).
+//
+// Requirements: K % 64 == 0, rows 16-byte aligned (lda, ldw multiples of 8).
+// M and N are arbitrary (loads are clamped, stores are masked).
+#include "dev.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+__device__ __forceinline__ void tile_coords(int local, int ntiles, int tiles_m, int tiles_n, int& tm, int& tn) {
+    // XCD remap (bijective for any ntiles): the blocks with equal (local % 8) share an
+    // XCD under round-robin dispatch; give each such group a contiguous chunk of tiles.
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = local & 7, within = local >> 3;
+    const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    // grouped-M ordering inside the chunk
+    constexpr int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int g = idx / per_group;
+    const int first_m = g * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int in_g = idx - g * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_128x128_kernel(GemmBatch batch) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * 2 * BM * BK * 2];  // [buf][A|W][128][64] bf16 = 64 KB
+
+    const int bid = blockIdx.x;
+    const int pi = (batch.nprob > 1 && bid >= batch.tile_start1) ? 1 : 0;
+    const GemmProblem& p = batch.p[pi];
+    const int local = bid - (pi ? batch.tile_start1 : 0);
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    int tm, tn;
+    tile_coords(local, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wid = t >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    // ---- global -> register staging assignment: 4 x 16 B per operand per thread
+    const uint16_t* a_src[4];
+    const uint16_t* w_src[4];
+    int lds_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = t + 256 * i;
+        const int row = idx >> 3, chunk = idx & 7;
+        const int ar = min(m0 + row, p.M - 1);
+        const int wr = min(n0 + row, p.N - 1);
+        a_src[i] = p.A + (size_t)ar * p.lda + chunk * 8;
+        w_src[i] = p.W + (size_t)wr * p.ldw + chunk * 8;
+        lds_off[i] = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    }
+    u32x4 a_reg[4], w_reg[4];
+    // (macros, not lambdas: by-reference lambda captures keep the staging registers in scratch)
+#define GEMM_LOAD_TILE(kt_)                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                   \
+        a_reg[i_] = *reinterpret_cast<const u32x4*>(a_src[i_] + (kt_) * BK);             \
+        w_reg[i_] = *reinterpret_cast<const u32x4*>(w_src[i_] + (kt_) * BK);             \
+    }
+#define GEMM_STORE_TILE(buf_)                                                            \
+    {                                                                                    \
+        uint8_t* base_ = smem + (buf_) * (2 * BM * BK * 2);                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                               \
+            *reinterpret_cast<u32x4*>(base_ + lds_off[i_]) = a_reg[i_];                  \
+            *reinterpret_cast<u32x4*>(base_ + BM * BK * 2 + lds_off[i_]) = w_reg[i_];    \
+        }                                                                                \
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read addresses (byte offsets inside a [128][64] bf16 tile)
+    const int frow = lane & 15, fq = lane >> 4;
+    const int sw = (frow >> 1) & 7;  // row base is a multiple of 16, so (row>>1)&7 == (frow>>1)&7
+    int a_off[4], w_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_off[i] = (wm * 64 + i * 16 + frow) * 128;
+        w_off[i] = (wn * 64 + i * 16 + frow) * 128;
+    }
+
+    const int nk = p.K / BK;
+    GEMM_LOAD_TILE(0)
+    GEMM_STORE_TILE(0)
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) { GEMM_LOAD_TILE(kt + 1) }
+        const uint8_t* sa = smem + buf * (2 * BM * BK * 2);
+        const uint8_t* sb = sa + BM * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int coff = (((kk * 4 + fq) ^ sw) << 4);
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + a_off[i] + coff);
+                bf[i] = *reinterpret_cast<const bf16x8*>(sb + w_off[i] + coff);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) GEMM_STORE_TILE(buf ^ 1)
+        __syncthreads();
+    }
+
+    // ---- epilogue.  acc[i][j][r]: row = m0 + wm*64 + i*16 + fq*4 + r, col = n0 + wn*64 + j*16 + frow
+    const int row_base = m0 + wm * 64 + fq * 4;
+    const int col_base = n0 + wn * 64 + frow;
+    int epi = p.epi;
+    if (epi == EPI_QKV_MLP) epi = (n0 >= p.n_split) ? EPI_SWIGLU : EPI_BF16;
+
+    if (epi == EPI_F32) {
+        float* C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row_base + i * 16 + r;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = col_base + j * 16;
+                        if (col < p.N) C[(size_t)row * p.ldc + col] = acc[i][j][r] * p.alpha;
+                    }
+                }
+            }
+    } else if (epi == EPI_BF16) {
+        uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row_base + i * 16 + r;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = col_base + j * 16;
+                        if (col < p.N) C[(size_t)row * p.ldc + col] = f32_to_bf16_bits(acc[i][j][r] * p.alpha);
+                    }
+                }
+            }
+    } else if (epi == EPI_GATE_RESID) {
+        // hs[row, col] += gate[col] * y  (applyGate + residual, Flux2Modulation.swift:119-122)
+        float* C = reinterpret_cast<float*>(p.C);
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = col_base + j * 16;
+            g[j] = (col < p.N) ? p.vec[col] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row_base + i * 16 + r;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = col_base + j * 16;
+                        if (col < p.N) {
+                            float* dst = C + (size_t)row * p.ldc + col;
+                            *dst = *dst + g[j] * acc[i][j][r];
+                        }
+                    }
+                }
+            }
+    } else if (epi == EPI_SWIGLU) {
+        // weight rows were interleaved at load time in blocks of 32: inside every aligned
+        // group of 64 output columns, cols 0..31 are `gate` and 32..63 the matching `value`
+        // rows (Flux2FeedForward.swift:59-67: gate = first half, value = second half).
+        uint16_t* C = reinterpret_cast<uint16_t*>(p.C2);
+        const int start = (p.epi == EPI_QKV_MLP) ? p.n_split : 0;
+        const int hbase = ((n0 + wn * 64 - start) >> 1) + frow;
+        const int hidden = (p.N - start) >> 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row_base + i * 16 + r;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int h = hbase + j * 16;
+                        if (h < hidden) {
+                            const float gate = acc[i][j][r], val = acc[i][j + 2][r];
+                            C[(size_t)row * p.ldc2 + h] = f32_to_bf16_bits(silu_f(gate) * val);
+                        }
+                    }
+                }
+            }
+    } else {  // EPI_BIAS_BF16: C = bf16(alpha*acc + bias[col] (+ resid[row,col]))
+        uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+        float bsv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = col_base + j * 16;
+            bsv[j] = (p.vec != nullptr && col < p.N) ? p.vec[col] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row_base + i * 16 + r;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = col_base + j * 16;
+                        if (col < p.N) {
+                            float v = acc[i][j][r] * p.alpha + bsv[j];
+                            if (p.resid) v += bf16_bits_to_f32(p.resid[(size_t)row * p.ldr + col]);
+                            C[(size_t)row * p.ldc + col] = f32_to_bf16_bits(v);
+                        }
+                    }
+                }
+            }
+    }
+}
+
+// Fallback for shapes the MFMA kernel does not take (K % 64 != 0), e.g. the VAE's
+// 32->32 post_quant_conv.  One thread per output element, f32 accumulate.
+__global__ void gemm_naive_kernel(GemmProblem p) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.M * p.N) return;
+    const int row = idx / p.N, col = idx % p.N;
+    float acc = 0.f;
+    for (int k = 0; k < p.K; ++k)
+        acc += bf16_bits_to_f32(p.A[(size_t)row * p.lda + k]) * bf16_bits_to_f32(p.W[(size_t)col * p.ldw + k]);
+    acc *= p.alpha;
+    if (p.epi == EPI_F32) {
+        reinterpret_cast<float*>(p.C)[(size_t)row * p.ldc + col] = acc;
+    } else if (p.epi == EPI_BF16) {
+        reinterpret_cast<uint16_t*>(p.C)[(size_t)row * p.ldc + col] = f32_to_bf16_bits(acc);
+    } else if (p.epi == EPI_BIAS_BF16) {
+        float v = acc + (p.vec ? p.vec[col] : 0.f);
+        if (p.resid) v += bf16_bits_to_f32(p.resid[(size_t)row * p.ldr + col]);
+        reinterpret_cast<uint16_t*>(p.C)[(size_t)row * p.ldc + col] = f32_to_bf16_bits(v);
+    }
+}
+
+}  // namespace
+
+int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
+    if (nprob < 1 || nprob > 2) return 1;
+    bool mfma_ok = true;
+    for (int i = 0; i < nprob; ++i) {
+        const GemmProblem& p = probs[i];
+        if (p.M <= 0 || p.N <= 0 || p.K <= 0) return 1;
+        if (p.K % BK != 0 || (p.lda & 7) || (p.ldw & 7)) mfma_ok = false;
+        if ((p.epi == EPI_SWIGLU || p.epi == EPI_QKV_MLP) && (p.N % 64 != 0 || p.n_split % BN != 0)) return 1;
+    }
+    if (!mfma_ok) {
+        for (int i = 0; i < nprob; ++i) {
+            const GemmProblem& p = probs[i];
+            if (p.epi != EPI_F32 && p.epi != EPI_BF16 && p.epi != EPI_BIAS_BF16) return 1;
+            const int total = p.M * p.N;
+            hipLaunchKernelGGL(gemm_naive_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
+    GemmBatch b;
+    b.nprob = nprob;
+    int tiles[2] = {0, 0};
+    for (int i = 0; i < nprob; ++i) {
+        b.p[i] = probs[i];
+        tiles[i] = ((probs[i].M + BM - 1) / BM) * ((probs[i].N + BN - 1) / BN);
+    }
+    if (nprob == 1) b.p[1] = probs[0];
+    b.tile_start1 = tiles[0];
+    hipLaunchKernelGGL(gemm_bf16_128x128_kernel, dim3(tiles[0] + tiles[1]), dim3(256), 0, stream, b);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}

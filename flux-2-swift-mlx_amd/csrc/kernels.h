@@ -1,0 +1,116 @@
+// kernels.h — launchers of the gfx950 kernels (defined in *.hip).  Every launcher
+// enqueues on `stream` and returns 0 on success (1 = bad argument, 2 = launch error).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---------------------------------------------------------------- GEMM (gemm.hip)
+enum GemmEpilogue {
+    EPI_F32 = 0,        // C f32  = alpha*acc
+    EPI_BF16 = 1,       // C bf16 = alpha*acc
+    EPI_GATE_RESID = 2, // C f32 += vec[col]*acc                (x += gate * f(y))
+    EPI_SWIGLU = 3,     // C2 bf16[row, h] = silu(gate)*value   (interleaved weight rows)
+    EPI_QKV_MLP = 4,    // cols < n_split: EPI_BF16 into C; cols >= n_split: EPI_SWIGLU into C2
+    EPI_BIAS_BF16 = 5   // C bf16 = alpha*acc + vec[col] (+ resid[row,col])
+};
+
+struct GemmProblem {
+    const uint16_t* A;      // bf16 [M,K], row stride lda
+    const uint16_t* W;      // bf16 [N,K], row stride ldw
+    void* C;
+    void* C2;
+    const float* vec;       // gate or bias (f32 [N]) or nullptr
+    const uint16_t* resid;  // EPI_BIAS_BF16: optional bf16 residual [M,N], row stride ldr
+    int M, N, K;
+    int lda, ldw, ldc, ldc2, ldr;
+    int n_split;
+    float alpha;
+    int epi;
+};
+struct GemmBatch {
+    GemmProblem p[2];
+    int nprob;
+    int tile_start1;
+};
+int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob);
+
+// ---------------------------------------------------------------- attention (attention.hip)
+// Joint (text+image) non-causal attention, head_dim 128, bf16 in/out, f32 softmax.
+//   q, k: bf16, row s at (q + s*ldqk + head*128); vt: bf16 [heads][128][s_pad] with the
+//   key-permuted layout produced by launch_qk_norm_rope_vt; out row s at out + s*ldo + head*128.
+int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
+                     int s_pad, uint16_t* out, int ldo, int S, int heads);
+static inline int attn_s_pad(int S) { return ((S + 63) / 64) * 64; }
+
+// ---------------------------------------------------------------- norms / rope (norm.hip)
+// y bf16[row,:] = LN(x f32[row,:]) * (1 + scale) + shift ; rows < split use (shift0, scale0),
+// rows >= split use (shift1, scale1).  eps 1e-6, no affine (Flux2TransformerBlock.swift:56-61).
+int launch_layernorm_modulate(hipStream_t stream, const float* x, uint16_t* y, int rows, int dim, int split,
+                              const float* shift0, const float* scale0, const float* shift1,
+                              const float* scale1);
+// In place on qkv bf16 [S, 3*dim] (q | k | v): per-head RMSNorm (eps 1e-6, learned scale)
+// then RoPE on q and k; V is written transposed + key-permuted into vt [heads][128][s_pad].
+// Rows < split use (qscale0, kscale0) — the text stream of a double block — rows >= split
+// use (qscale1, kscale1).
+int launch_qk_norm_rope_vt(hipStream_t stream, uint16_t* qkv, int ldqkv, int S, int heads, int split,
+                           const uint16_t* qscale0, const uint16_t* kscale0, const uint16_t* qscale1,
+                           const uint16_t* kscale1, const float* cos_tab, const float* sin_tab,
+                           uint16_t* vt, int s_pad);
+// V half of the above only (standalone attention op).
+int launch_v_transpose_only(hipStream_t stream, const uint16_t* qkv, int ldqkv, int S, int heads, uint16_t* vt,
+                            int s_pad);
+// cos/sin f32 [S,128] from position ids i32 [S,4] (Flux2RoPE.swift:129-169); rows [0,s_txt)
+// come from txt_ids, the rest from img_ids.
+int launch_rope_tables(hipStream_t stream, const int32_t* txt_ids, int s_txt, const int32_t* img_ids, int s_img,
+                       float* cos_tab, float* sin_tab);
+
+// ---------------------------------------------------------------- small ops (elementwise.hip)
+// out f32[n] (+)= sum_k W[n,k] * f(x[k]); f = silu when silu_in; one wave per output row.
+int launch_gemv(hipStream_t stream, const uint16_t* W, const float* x, float* out, int N, int K, int silu_in,
+                int accumulate);
+// emb f32[256] = [cos(1000 t f_i) | sin(1000 t f_i)] (Flux2Embeddings.swift:27-44)
+int launch_sinusoid(hipStream_t stream, float value, float* emb);
+int launch_silu_inplace(hipStream_t stream, float* x, int n);
+int launch_f32_to_bf16(hipStream_t stream, const float* in, uint16_t* out, int64_t n);
+int launch_convert_to_bf16(hipStream_t stream, const void* in, int dtype, uint16_t* out, int64_t n);
+int launch_convert_to_f32(hipStream_t stream, const void* in, int dtype, float* out, int64_t n);
+// out rows permuted: out[r,:] = in[perm(r),:], SwiGLU interleave of a [2h,K] matrix (see gemm.hip)
+int launch_swiglu_interleave_rows(hipStream_t stream, const uint16_t* in, uint16_t* out, int hidden, int K);
+int launch_axpy(hipStream_t stream, float* x, const float* v, float a, int64_t n);                 // x += a*v
+int launch_lerp(hipStream_t stream, float* out, const float* a, const float* b, float t, int64_t n); // (1-t)a + t b
+int launch_cfg_combine(hipStream_t stream, float* vc, const float* vu, float g, int64_t n);
+int launch_repaint_blend(hipStream_t stream, float* x, const float* img, const float* noise, const float* mask,
+                         float sigma_next, int seq, int c);
+int launch_transpose_2d(hipStream_t stream, const float* in, float* out, int rows, int cols);      // [rows,cols]->[cols,rows]
+int launch_latents_to_vae_input(hipStream_t stream, const float* packed, const float* mean, const float* var,
+                                float* z, int h16, int w16);
+int launch_vae_latents_to_packed(hipStream_t stream, const float* z, const float* mean, const float* var,
+                                 float* packed, int h16, int w16);
+
+// ---------------------------------------------------------------- VAE (vae_kernels.hip)
+struct ConvArgs {
+    const uint16_t* x;      // NHWC bf16 [Hin, Win, Cin]
+    const uint16_t* w;      // bf16 [Cout_pad][ks*ks][Cin]  (OHWI)
+    const float* bias;      // f32 [Cout]
+    const uint16_t* resid;  // optional NHWC bf16 [Ho, Wo, Cout]
+    uint16_t* y;            // NHWC bf16 [Ho, Wo, Cout] or nullptr
+    float* y_f32_nchw;      // optional f32 [Cout, Ho, Wo]
+    uint8_t* y_u8_hwc;      // optional u8 [Ho, Wo, Cout]: clip((v+1)*127.5, 0, 255) truncated
+    int Hin, Win, Cin, Cout;
+    int ks;                 // 1 or 3 (pad = ks/2)
+    int upsample;           // 1: the conv reads a nearest-2x upsampled view of x (Ho = 2*Hin)
+};
+int launch_conv2d(hipStream_t stream, const ConvArgs& a);
+// GroupNorm statistics of NHWC bf16 x -> per-channel affine (a_c, b_c) f32 with
+// y = a_c*x + b_c == GN(x)*gamma + beta  (32 groups, eps 1e-6, f32 statistics; ResnetBlock.swift:9-55).
+int launch_groupnorm_stats(hipStream_t stream, const uint16_t* x, int64_t pixels, int C, int groups,
+                           const float* gamma, const float* beta, float eps, float* partial /* scratch */,
+                           float* ab /* [2*C] */);
+int groupnorm_partial_floats(int64_t pixels, int groups);
+int launch_groupnorm_apply(hipStream_t stream, const uint16_t* x, uint16_t* y, int64_t pixels, int C,
+                           const float* ab, int silu);
+int launch_nchw_f32_to_nhwc_bf16(hipStream_t stream, const float* in, uint16_t* out, int C, int H, int W);
+int launch_softmax_rows(hipStream_t stream, const float* in, uint16_t* out, int rows, int cols);
+int launch_transpose_bf16(hipStream_t stream, const uint16_t* in, uint16_t* out, int rows, int cols);
+int launch_oihw_to_ohwi_bf16(hipStream_t stream, const uint16_t* in, uint16_t* out, int O, int I, int KH, int KW,
+                             int O_pad);

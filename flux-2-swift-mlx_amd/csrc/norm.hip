@@ -1,0 +1,214 @@
+// norm.hip — HBM-bound normalisation kernels of the DiT forward (gfx950).
+//   * LayerNorm(no affine, eps 1e-6) + AdaLN modulate -> bf16 GEMM operand
+//     (Flux2TransformerBlock.swift:95-106, Flux2Modulation.swift:96-112)
+//   * per-head RMSNorm + RoPE on Q,K in place; V -> transposed, key-permuted V^T
+//     (Flux2Attention.swift:137-157, 212-229, 442-461)
+//   * RoPE cos/sin tables from position ids (Flux2RoPE.swift:129-169)
+// All loads/stores are 8-16 B per lane on contiguous rows.
+#include "dev.h"
+#include "kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------ LayerNorm + modulate
+// One 256-thread workgroup per row; the row (dim <= 8192 f32) lives in registers.
+constexpr int LN_MAX_VEC = 8;  // 8 float4 per thread -> dim <= 8192
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void layernorm_modulate_kernel(const float* __restrict__ x,
+                                                                 uint16_t* __restrict__ y, int dim, int split,
+                                                                 const float* __restrict__ shift0,
+                                                                 const float* __restrict__ scale0,
+                                                                 const float* __restrict__ shift1,
+                                                                 const float* __restrict__ scale1) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const float* xr = x + (size_t)row * dim;
+    const int nvec = dim >> 2;
+    float4 v[LN_MAX_VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < nvec) {
+            v[i] = reinterpret_cast<const float4*>(xr)[c];
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+    }
+    const float mean = block_sum_256(s, red) / (float)dim;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < nvec) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            sq += a * a + b * b + cc * cc + d * d;
+        }
+    }
+    const float var = block_sum_256(sq, red) / (float)dim;
+    const float rstd = rsqrtf(var + 1e-6f);
+    const float* sh = (row < split) ? shift0 : shift1;
+    const float* sc = (row < split) ? scale0 : scale1;
+    uint16_t* yr = y + (size_t)row * dim;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < nvec) {
+            const float4 h = reinterpret_cast<const float4*>(sh)[c];
+            const float4 g = reinterpret_cast<const float4*>(sc)[c];
+            const float o0 = (v[i].x - mean) * rstd * (1.f + g.x) + h.x;
+            const float o1 = (v[i].y - mean) * rstd * (1.f + g.y) + h.y;
+            const float o2 = (v[i].z - mean) * rstd * (1.f + g.z) + h.z;
+            const float o3 = (v[i].w - mean) * rstd * (1.f + g.w) + h.w;
+            uint2 pk;
+            pk.x = pack_bf16x2(o0, o1);
+            pk.y = pack_bf16x2(o2, o3);
+            reinterpret_cast<uint2*>(yr)[c] = pk;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ QK RMSNorm + RoPE (in place)
+// One wave per (row, head, q|k) vector of 128: lane owns the RoPE pair (2*lane, 2*lane+1).
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(uint16_t* __restrict__ qkv, int ldqkv, int S, int heads,
+                                                           int split, const uint16_t* __restrict__ qs0,
+                                                           const uint16_t* __restrict__ ks0,
+                                                           const uint16_t* __restrict__ qs1,
+                                                           const uint16_t* __restrict__ ks1,
+                                                           const float* __restrict__ cos_tab,
+                                                           const float* __restrict__ sin_tab) {
+    const int lane = threadIdx.x & 63;
+    const long vec = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // ((row*2 + which)*heads + head)
+    const long total = (long)S * 2 * heads;
+    if (vec >= total) return;
+    const int head = (int)(vec % heads);
+    const int which = (int)((vec / heads) & 1);
+    const int row = (int)(vec / (2 * heads));
+    uint16_t* p = qkv + (size_t)row * ldqkv + which * heads * 128 + head * 128 + lane * 2;
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+    const float x0 = lo_bf16(u), x1 = hi_bf16(u);
+    const float ss = wave_sum(x0 * x0 + x1 * x1);
+    const float r = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+    const uint16_t* sc = (row < split) ? (which ? ks0 : qs0) : (which ? ks1 : qs1);
+    const uint32_t su = *reinterpret_cast<const uint32_t*>(sc + lane * 2);
+    const float n0 = x0 * r * lo_bf16(su), n1 = x1 * r * hi_bf16(su);
+    const float2 c = *reinterpret_cast<const float2*>(cos_tab + (size_t)row * 128 + lane * 2);
+    const float2 s = *reinterpret_cast<const float2*>(sin_tab + (size_t)row * 128 + lane * 2);
+    // x*cos + rotate_half(x)*sin with rotate_half = (-x1, x0)
+    const float o0 = n0 * c.x - n1 * s.x;
+    const float o1 = n1 * c.y + n0 * s.y;
+    *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(o0, o1);
+}
+
+// ------------------------------------------------------------------ V -> V^T (key-permuted)
+// vt[head][d][pos(key)] with, inside every group of 16 keys, key offset 8a+4h+b stored at
+// 8h+4a+b (the k order of an MFMA 32x32 accumulator reused as operand; see attention.hip).
+// One workgroup = 64 keys x 128 d of one head, transposed through LDS.
+__global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __restrict__ qkv, int ldqkv, int S,
+                                                          int heads, uint16_t* __restrict__ vt, int s_pad) {
+    __shared__ uint16_t tile[64][128 + 2];
+    const int head = blockIdx.y;
+    const int k0 = blockIdx.x * 64;
+    const uint16_t* vsrc = qkv + 2 * heads * 128 + head * 128;
+    // load 64 rows x 256 B: 1024 chunks of 16 B, 4 per thread
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int r = idx >> 4, c = idx & 15;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (k0 + r < S) val = *reinterpret_cast<const uint4*>(vsrc + (size_t)(k0 + r) * ldqkv + c * 8);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&tile[r][c * 8]);
+        dst[0] = val.x; dst[1] = val.y; dst[2] = val.z; dst[3] = val.w;
+    }
+    __syncthreads();
+    // write 128 d-rows x 64 keys: 1024 chunks of 8 keys (16 B), 4 per thread
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int d = idx >> 3, c = idx & 7;   // chunk c holds stored positions 8c .. 8c+7
+        uint16_t vals[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pos = c * 8 + j;                 // stored position within the 64-key tile
+            const int grp = pos & ~15, o = pos & 15;   // o = 8h + 4a + b
+            const int h = o >> 3, a = (o >> 2) & 1, b = o & 3;
+            const int key = grp + 8 * a + 4 * h + b;
+            vals[j] = tile[key][d];
+        }
+        uint4 pk;
+        pk.x = vals[0] | ((uint32_t)vals[1] << 16);
+        pk.y = vals[2] | ((uint32_t)vals[3] << 16);
+        pk.z = vals[4] | ((uint32_t)vals[5] << 16);
+        pk.w = vals[6] | ((uint32_t)vals[7] << 16);
+        *reinterpret_cast<uint4*>(vt + ((size_t)head * 128 + d) * s_pad + k0 + c * 8) = pk;
+    }
+}
+
+// ------------------------------------------------------------------ RoPE tables
+// cos/sin [S,128]: axis a (0..3) covers columns 32a..32a+31; pair j (0..15) of an axis uses
+// omega = theta^(-2j/32), theta = 2000, value repeated for columns 2j, 2j+1.
+__global__ void rope_tables_kernel(const int32_t* __restrict__ txt_ids, int s_txt,
+                                   const int32_t* __restrict__ img_ids, int s_img, float* __restrict__ cos_tab,
+                                   float* __restrict__ sin_tab) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (row, axis, j)
+    const int S = s_txt + s_img;
+    if (idx >= S * 64) return;
+    const int row = idx >> 6, aj = idx & 63, axis = aj >> 4, j = aj & 15;
+    const int32_t* ids = (row < s_txt) ? (txt_ids + (size_t)row * 4) : (img_ids + (size_t)(row - s_txt) * 4);
+    const float pos = (float)ids[axis];
+    const float inv_freq = 1.0f / powf(2000.0f, (float)(2 * j) / 32.0f);
+    const float ang = pos * inv_freq;
+    const float c = cosf(ang), s = sinf(ang);
+    const size_t o = (size_t)row * 128 + axis * 32 + j * 2;
+    cos_tab[o] = c; cos_tab[o + 1] = c;
+    sin_tab[o] = s; sin_tab[o + 1] = s;
+}
+
+}  // namespace
+
+int launch_layernorm_modulate(hipStream_t stream, const float* x, uint16_t* y, int rows, int dim, int split,
+                              const float* shift0, const float* scale0, const float* shift1,
+                              const float* scale1) {
+    if (rows <= 0 || dim <= 0 || (dim & 3) || dim > LN_MAX_VEC * 1024) return 1;
+    hipLaunchKernelGGL(layernorm_modulate_kernel, dim3(rows), dim3(256), 0, stream, x, y, dim, split, shift0,
+                       scale0, shift1, scale1);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_qk_norm_rope_vt(hipStream_t stream, uint16_t* qkv, int ldqkv, int S, int heads, int split,
+                           const uint16_t* qscale0, const uint16_t* kscale0, const uint16_t* qscale1,
+                           const uint16_t* kscale1, const float* cos_tab, const float* sin_tab,
+                           uint16_t* vt, int s_pad) {
+    if (S <= 0 || heads <= 0 || (ldqkv & 7) || s_pad < attn_s_pad(S)) return 1;
+    const long total = (long)S * 2 * heads;
+    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, qkv, ldqkv, S,
+                       heads, split, qscale0, kscale0, qscale1, kscale1, cos_tab, sin_tab);
+    hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, heads), dim3(256), 0, stream, qkv, ldqkv, S, heads,
+                       vt, s_pad);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_v_transpose_only(hipStream_t stream, const uint16_t* qkv, int ldqkv, int S, int heads, uint16_t* vt,
+                            int s_pad) {
+    if (S <= 0 || heads <= 0 || (ldqkv & 7) || s_pad < attn_s_pad(S)) return 1;
+    hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, heads), dim3(256), 0, stream, qkv, ldqkv, S, heads,
+                       vt, s_pad);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_rope_tables(hipStream_t stream, const int32_t* txt_ids, int s_txt, const int32_t* img_ids, int s_img,
+                       float* cos_tab, float* sin_tab) {
+    const int total = (s_txt + s_img) * 64;
+    if (total <= 0) return 1;
+    hipLaunchKernelGGL(rope_tables_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, txt_ids, s_txt, img_ids,
+                       s_img, cos_tab, sin_tab);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}

@@ -1,0 +1,384 @@
+// vae.cpp — AutoencoderKLFlux2.decode on MI355X (VAE/AutoencoderKL.swift:129-143,
+// VAE/VAEDecoder.swift:91-121, VAE/ResnetBlock.swift).  NHWC bf16 activations, OHWI bf16
+// conv weights (same layouts the reference uses with MLX), f32 bias / GroupNorm params.
+//
+// Decoder graph:  z -> post_quant_conv 1x1 -> conv_in 3x3 -> mid(Resnet, Attn, Resnet)
+//   -> 4 up blocks x 3 Resnets (+ nearest-2x + conv3x3 after blocks 0-2)
+//   -> GroupNorm -> SiLU -> conv_out 3x3 -> [3,H,W] f32 and/or u8 HWC.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+enum ParamKind { PK_CONV_W, PK_LINEAR_W, PK_F32 };
+
+struct Param {
+    std::string name;
+    int kind;
+    int64_t shape[4];
+    int ndim;
+    void* ptr = nullptr;  // conv: bf16 [O_pad][KK][I]; linear: bf16 [O][I]; f32 vectors
+    bool got = false;
+};
+
+struct ConvW { int w = -1, b = -1, cin = 0, cout = 0, ks = 0; };
+struct GNW { int g = -1, b = -1, c = 0; };
+struct LinW { int w = -1, b = -1; };
+struct ResnetW { GNW n1, n2; ConvW c1, c2, sc; bool has_sc = false; };
+
+}  // namespace
+
+struct flux2mi_vae {
+    flux2mi_ctx* ctx = nullptr;
+    flux2mi_vae_config cfg{};
+    std::vector<Param> params;
+    std::unordered_map<std::string, int> index;
+    bool finalized = false;
+
+    ConvW post_quant, conv_in, conv_out;
+    ResnetW mid0, mid1;
+    GNW attn_gn, norm_out;
+    LinW to_q, to_k, to_v, to_o;
+    ResnetW up[4][3];
+    ConvW upsample[3];
+    int bn_mean = -1, bn_var = -1;
+
+    DevBuf stage_raw, stage_bf16;
+    DevBuf act[4];                      // A, B, C, D ping-pong activations
+    DevBuf aq, ak, av, avt, scores, probs;
+    DevBuf gn_partial, gn_ab, zin;
+};
+
+namespace {
+
+int add_param(flux2mi_vae* v, const std::string& name, int kind, std::initializer_list<int64_t> shape) {
+    Param p;
+    p.name = name;
+    p.kind = kind;
+    p.ndim = (int)shape.size();
+    int i = 0;
+    for (int64_t s : shape) p.shape[i++] = s;
+    v->params.push_back(p);
+    v->index[name] = (int)v->params.size() - 1;
+    return (int)v->params.size() - 1;
+}
+ConvW add_conv(flux2mi_vae* v, const std::string& name, int cout, int cin, int ks) {
+    ConvW c;
+    c.cin = cin; c.cout = cout; c.ks = ks;
+    c.w = add_param(v, name + ".weight", PK_CONV_W, {cout, cin, ks, ks});
+    c.b = add_param(v, name + ".bias", PK_F32, {cout});
+    return c;
+}
+GNW add_gn(flux2mi_vae* v, const std::string& name, int c) {
+    GNW g;
+    g.c = c;
+    g.g = add_param(v, name + ".weight", PK_F32, {c});
+    g.b = add_param(v, name + ".bias", PK_F32, {c});
+    return g;
+}
+LinW add_lin(flux2mi_vae* v, const std::string& name, int out, int in) {
+    LinW l;
+    l.w = add_param(v, name + ".weight", PK_LINEAR_W, {out, in});
+    l.b = add_param(v, name + ".bias", PK_F32, {out});
+    return l;
+}
+ResnetW add_resnet(flux2mi_vae* v, const std::string& pre, int cin, int cout) {
+    ResnetW r;
+    r.n1 = add_gn(v, pre + "norm1", cin);
+    r.c1 = add_conv(v, pre + "conv1", cout, cin, 3);
+    r.n2 = add_gn(v, pre + "norm2", cout);
+    r.c2 = add_conv(v, pre + "conv2", cout, cout, 3);
+    r.has_sc = cin != cout;
+    if (r.has_sc) r.sc = add_conv(v, pre + "conv_shortcut", cout, cin, 1);
+    return r;
+}
+
+void build(flux2mi_vae* v) {
+    const flux2mi_vae_config& c = v->cfg;
+    const int L = c.latent_channels, mid = c.channels[3];
+    v->post_quant = add_conv(v, "post_quant_conv", L, L, 1);
+    v->conv_in = add_conv(v, "decoder.conv_in", mid, L, 3);
+    v->mid0 = add_resnet(v, "decoder.mid_block.resnets.0.", mid, mid);
+    const std::string a = "decoder.mid_block.attentions.0.";
+    v->attn_gn = add_gn(v, a + "group_norm", mid);
+    v->to_q = add_lin(v, a + "to_q", mid, mid);
+    v->to_k = add_lin(v, a + "to_k", mid, mid);
+    v->to_v = add_lin(v, a + "to_v", mid, mid);
+    v->to_o = add_lin(v, a + "to_out.0", mid, mid);
+    v->mid1 = add_resnet(v, "decoder.mid_block.resnets.1.", mid, mid);
+    int prev = mid;
+    char buf[128];
+    for (int i = 0; i < 4; ++i) {
+        const int co = c.channels[3 - i];  // reversed channel order (VAEDecoder.swift:49-78)
+        for (int j = 0; j < c.layers_per_block + 1; ++j) {
+            snprintf(buf, sizeof buf, "decoder.up_blocks.%d.resnets.%d.", i, j);
+            v->up[i][j] = add_resnet(v, buf, j == 0 ? prev : co, co);
+        }
+        prev = co;
+        if (i < 3) {
+            snprintf(buf, sizeof buf, "decoder.up_blocks.%d.upsamplers.0.conv", i);
+            v->upsample[i] = add_conv(v, buf, co, co, 3);
+        }
+    }
+    v->norm_out = add_gn(v, "decoder.conv_norm_out", c.channels[0]);
+    v->conv_out = add_conv(v, "decoder.conv_out", 3, c.channels[0], 3);
+    v->bn_mean = add_param(v, "bn.running_mean", PK_F32, {4 * L});
+    v->bn_var = add_param(v, "bn.running_var", PK_F32, {4 * L});
+}
+
+size_t dsize(int dtype) { return dtype == FLUX2MI_F32 ? 4 : 2; }
+inline int pad32(int x) { return ((x + 31) / 32) * 32; }
+
+}  // namespace
+
+extern "C" int flux2mi_vae_preset(const char* name, flux2mi_vae_config* out) {
+    F2_REQUIRE(name && out, FLUX2MI_ERR_INVALID_ARG, "vae_preset: NULL argument");
+    // Configuration/VAEConfig.swift:44-81
+    if (!strcmp(name, "standard")) *out = flux2mi_vae_config{{128, 256, 512, 512}, 32, 32, 2};
+    else if (!strcmp(name, "small")) *out = flux2mi_vae_config{{96, 192, 384, 384}, 32, 32, 2};
+    else {
+        flux2mi_set_error("vae_preset: unknown variant '%s'", name);
+        return FLUX2MI_ERR_INVALID_ARG;
+    }
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_vae_create(flux2mi_ctx* ctx, const flux2mi_vae_config* cfg, flux2mi_vae** out) {
+    F2_REQUIRE(ctx && cfg && out, FLUX2MI_ERR_INVALID_ARG, "vae_create: NULL argument");
+    for (int i = 0; i < 4; ++i)
+        F2_REQUIRE(cfg->channels[i] > 0 && cfg->channels[i] % 32 == 0 && cfg->channels[i] % cfg->groups == 0,
+                   FLUX2MI_ERR_INVALID_ARG, "vae_create: channels[%d]=%d must be a multiple of 32 and of groups", i,
+                   cfg->channels[i]);
+    F2_REQUIRE(cfg->latent_channels == 32 && cfg->layers_per_block == 2 && cfg->groups > 0 && cfg->groups <= 64,
+               FLUX2MI_ERR_INVALID_ARG, "vae_create: unsupported config");
+    F2_CHECK_HIP(hipSetDevice(ctx->device));
+    flux2mi_vae* v = new flux2mi_vae();
+    v->ctx = ctx;
+    v->cfg = *cfg;
+    build(v);
+    for (Param& p : v->params) {
+        size_t bytes = 0;
+        if (p.kind == PK_CONV_W) bytes = (size_t)pad32((int)p.shape[0]) * p.shape[1] * p.shape[2] * p.shape[3] * 2;
+        else if (p.kind == PK_LINEAR_W) bytes = (size_t)p.shape[0] * p.shape[1] * 2;
+        else bytes = (size_t)p.shape[0] * 4;
+        hipError_t e = hipMalloc(&p.ptr, bytes);
+        if (e != hipSuccess) {
+            flux2mi_set_error("vae_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            flux2mi_vae_destroy(v);
+            return FLUX2MI_ERR_OOM;
+        }
+    }
+    *out = v;
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_vae_destroy(flux2mi_vae* v) {
+    if (!v) return FLUX2MI_OK;
+    (void)hipSetDevice(v->ctx->device);
+    (void)hipStreamSynchronize(v->ctx->stream);
+    for (Param& p : v->params)
+        if (p.ptr) (void)hipFree(p.ptr);
+    DevBuf* bufs[] = {&v->stage_raw, &v->stage_bf16, &v->act[0], &v->act[1], &v->act[2], &v->act[3], &v->aq, &v->ak,
+                      &v->av, &v->avt, &v->scores, &v->probs, &v->gn_partial, &v->gn_ab, &v->zin};
+    for (DevBuf* b : bufs) b->release();
+    delete v;
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_vae_set_tensor(flux2mi_vae* v, const char* name, int dtype, const int64_t* shape, int ndim,
+                                      const void* data) {
+    F2_REQUIRE(v && name && shape && data, FLUX2MI_ERR_INVALID_ARG, "vae_set_tensor: NULL argument");
+    // encoder-side and bookkeeping tensors of the checkpoint are not part of the decode path
+    if (!strncmp(name, "encoder.", 8) || !strncmp(name, "quant_conv.", 11) || strstr(name, "num_batches_tracked"))
+        return FLUX2MI_OK;
+    auto it = v->index.find(name);
+    if (it == v->index.end()) {
+        flux2mi_set_error("vae_set_tensor: unknown key '%s'", name);
+        return FLUX2MI_ERR_INVALID_ARG;
+    }
+    Param& p = v->params[it->second];
+    F2_REQUIRE(ndim == p.ndim, FLUX2MI_ERR_SHAPE, "vae_set_tensor(%s): ndim %d, expected %d", name, ndim, p.ndim);
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        F2_REQUIRE(shape[i] == p.shape[i], FLUX2MI_ERR_SHAPE, "vae_set_tensor(%s): dim %d is %lld, expected %lld", name, i,
+                   (long long)shape[i], (long long)p.shape[i]);
+        n *= shape[i];
+    }
+    F2_CHECK_HIP(hipSetDevice(v->ctx->device));
+    hipStream_t st = v->ctx->stream;
+    F2_TRY(v->stage_raw.reserve((size_t)n * dsize(dtype)));
+    F2_CHECK_HIP(hipMemcpyAsync(v->stage_raw.ptr, data, (size_t)n * dsize(dtype), hipMemcpyDefault, st));
+    if (p.kind == PK_F32) {
+        F2_LAUNCH(launch_convert_to_f32(st, v->stage_raw.ptr, dtype, reinterpret_cast<float*>(p.ptr), n), "convert_to_f32");
+    } else {
+        F2_TRY(v->stage_bf16.reserve((size_t)n * 2));
+        F2_LAUNCH(launch_convert_to_bf16(st, v->stage_raw.ptr, dtype, v->stage_bf16.as<uint16_t>(), n), "convert_to_bf16");
+        if (p.kind == PK_LINEAR_W) {
+            F2_CHECK_HIP(hipMemcpyAsync(p.ptr, v->stage_bf16.ptr, (size_t)n * 2, hipMemcpyDeviceToDevice, st));
+        } else {
+            // OIHW (file) -> OHWI, O zero-padded to a multiple of 32 (WeightLoader.swift:495-497)
+            F2_LAUNCH(launch_oihw_to_ohwi_bf16(st, v->stage_bf16.as<uint16_t>(), reinterpret_cast<uint16_t*>(p.ptr),
+                                               (int)p.shape[0], (int)p.shape[1], (int)p.shape[2], (int)p.shape[3],
+                                               pad32((int)p.shape[0])), "oihw_to_ohwi");
+        }
+    }
+    F2_CHECK_HIP(hipStreamSynchronize(st));
+    p.got = true;
+    v->finalized = false;
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_vae_finalize(flux2mi_vae* v) {
+    F2_REQUIRE(v, FLUX2MI_ERR_INVALID_ARG, "vae_finalize: NULL");
+    for (const Param& p : v->params)
+        if (!p.got) {
+            flux2mi_set_error("vae_finalize: tensor '%s' missing", p.name.c_str());
+            return FLUX2MI_ERR_NOT_LOADED;
+        }
+    v->stage_raw.release();
+    v->stage_bf16.release();
+    v->finalized = true;
+    return FLUX2MI_OK;
+}
+
+extern "C" const float* flux2mi_vae_bn_mean(const flux2mi_vae* v) {
+    return (v && v->bn_mean >= 0) ? reinterpret_cast<const float*>(v->params[v->bn_mean].ptr) : nullptr;
+}
+extern "C" const float* flux2mi_vae_bn_var(const flux2mi_vae* v) {
+    return (v && v->bn_var >= 0) ? reinterpret_cast<const float*>(v->params[v->bn_var].ptr) : nullptr;
+}
+
+// ------------------------------------------------------------------ decode
+namespace {
+
+struct Dec {
+    flux2mi_vae* v;
+    hipStream_t st;
+    const uint16_t* W(int i) const { return reinterpret_cast<const uint16_t*>(v->params[i].ptr); }
+    const float* F(int i) const { return reinterpret_cast<const float*>(v->params[i].ptr); }
+
+    int conv(const ConvW& c, const uint16_t* x, int Hin, int Win, int upsample, const uint16_t* resid, uint16_t* y,
+             float* y_f32 = nullptr, uint8_t* y_u8 = nullptr) {
+        ConvArgs a;
+        memset(&a, 0, sizeof a);
+        a.x = x; a.w = W(c.w); a.bias = F(c.b); a.resid = resid; a.y = y; a.y_f32_nchw = y_f32; a.y_u8_hwc = y_u8;
+        a.Hin = Hin; a.Win = Win; a.Cin = c.cin; a.Cout = c.cout; a.ks = c.ks; a.upsample = upsample;
+        const double ho = upsample ? 2.0 * Hin : Hin, wo = upsample ? 2.0 * Win : Win;
+        prof_before(v->ctx, PROF_VAE_CONV);
+        const int r = launch_conv2d(st, a);
+        prof_after(v->ctx, PROF_VAE_CONV, 2.0 * ho * wo * c.cout * c.cin * c.ks * c.ks);
+        F2_LAUNCH(r, "conv2d");
+        return FLUX2MI_OK;
+    }
+    int gn(const GNW& g, const uint16_t* x, uint16_t* y, int64_t pixels, int silu) {
+        F2_TRY(v->gn_partial.reserve((size_t)groupnorm_partial_floats(pixels, v->cfg.groups) * 4));
+        F2_TRY(v->gn_ab.reserve((size_t)2 * g.c * 4));
+        F2_LAUNCH(launch_groupnorm_stats(st, x, pixels, g.c, v->cfg.groups, F(g.g), F(g.b), 1e-6f,
+                                         v->gn_partial.as<float>(), v->gn_ab.as<float>()), "groupnorm_stats");
+        F2_LAUNCH(launch_groupnorm_apply(st, x, y, pixels, g.c, v->gn_ab.as<float>(), silu), "groupnorm_apply");
+        return FLUX2MI_OK;
+    }
+    // x (A) -> A in place; scratch B, C, D
+    int resnet(const ResnetW& r, uint16_t* A, uint16_t* B, uint16_t* C, uint16_t* D, int H, int Wd) {
+        const int64_t px = (int64_t)H * Wd;
+        F2_TRY(gn(r.n1, A, B, px, 1));
+        F2_TRY(conv(r.c1, B, H, Wd, 0, nullptr, C));
+        F2_TRY(gn(r.n2, C, B, px, 1));
+        const uint16_t* shortcut = A;
+        if (r.has_sc) {
+            F2_TRY(conv(r.sc, A, H, Wd, 0, nullptr, D));
+            shortcut = D;
+        }
+        F2_TRY(conv(r.c2, B, H, Wd, 0, shortcut, A));
+        return FLUX2MI_OK;
+    }
+    int lin(const LinW& l, const uint16_t* x, uint16_t* y, int M, int C, const uint16_t* resid) {
+        GemmProblem p;
+        memset(&p, 0, sizeof p);
+        p.A = x; p.lda = C; p.W = W(l.w); p.ldw = C; p.C = y; p.ldc = C; p.M = M; p.N = C; p.K = C;
+        p.epi = EPI_BIAS_BF16; p.vec = F(l.b); p.resid = resid; p.ldr = C; p.alpha = 1.0f;
+        F2_LAUNCH(launch_gemm(st, &p, 1), "vae.linear");
+        return FLUX2MI_OK;
+    }
+    // single-head attention over P = H*W tokens (ResnetBlock.swift:257-313); A in place
+    int attention(uint16_t* A, uint16_t* B, int H, int Wd) {
+        const int C = v->attn_gn.c;
+        const int P = H * Wd;
+        const size_t pc = (size_t)P * C * 2;
+        F2_TRY(v->aq.reserve(pc)); F2_TRY(v->ak.reserve(pc)); F2_TRY(v->av.reserve(pc)); F2_TRY(v->avt.reserve(pc));
+        F2_TRY(v->scores.reserve((size_t)P * P * 4));
+        F2_TRY(v->probs.reserve((size_t)P * P * 2));
+        F2_TRY(gn(v->attn_gn, A, B, P, 0));
+        F2_TRY(lin(v->to_q, B, v->aq.as<uint16_t>(), P, C, nullptr));
+        F2_TRY(lin(v->to_k, B, v->ak.as<uint16_t>(), P, C, nullptr));
+        F2_TRY(lin(v->to_v, B, v->av.as<uint16_t>(), P, C, nullptr));
+        GemmProblem s;
+        memset(&s, 0, sizeof s);
+        s.A = v->aq.as<uint16_t>(); s.lda = C; s.W = v->ak.as<uint16_t>(); s.ldw = C; s.C = v->scores.ptr; s.ldc = P;
+        s.M = P; s.N = P; s.K = C; s.epi = EPI_F32; s.alpha = 1.0f / sqrtf((float)C);
+        F2_LAUNCH(launch_gemm(st, &s, 1), "vae.scores");
+        F2_LAUNCH(launch_softmax_rows(st, v->scores.as<float>(), v->probs.as<uint16_t>(), P, P), "vae.softmax");
+        F2_LAUNCH(launch_transpose_bf16(st, v->av.as<uint16_t>(), v->avt.as<uint16_t>(), P, C), "vae.v_transpose");
+        GemmProblem o;
+        memset(&o, 0, sizeof o);
+        o.A = v->probs.as<uint16_t>(); o.lda = P; o.W = v->avt.as<uint16_t>(); o.ldw = P; o.C = v->aq.ptr; o.ldc = C;
+        o.M = P; o.N = C; o.K = P; o.epi = EPI_BF16; o.alpha = 1.0f;
+        F2_LAUNCH(launch_gemm(st, &o, 1), "vae.pv");
+        F2_TRY(lin(v->to_o, v->aq.as<uint16_t>(), A, P, C, A));
+        return FLUX2MI_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" int flux2mi_vae_decode(flux2mi_vae* v, const float* z, int h, int w, float* out_f32, uint8_t* out_u8) {
+    F2_REQUIRE(v && z && h > 0 && w > 0, FLUX2MI_ERR_INVALID_ARG, "vae_decode: bad argument");
+    F2_REQUIRE(v->finalized, FLUX2MI_ERR_NOT_LOADED, "vae_decode: weights not finalized");
+    F2_REQUIRE(out_f32 || out_u8, FLUX2MI_ERR_INVALID_ARG, "vae_decode: no output requested");
+    F2_CHECK_HIP(hipSetDevice(v->ctx->device));
+    const flux2mi_vae_config& c = v->cfg;
+    // largest activation: channels[3-i] at (h<<i); the upsample conv output keeps the channel count
+    size_t max_elems = 0;
+    for (int i = 0; i < 4; ++i) {
+        const size_t hw = ((size_t)h << i) * ((size_t)w << i);
+        const size_t ch = (size_t)(i == 0 ? c.channels[3] : (c.channels[3 - i] > c.channels[4 - i] ? c.channels[3 - i] : c.channels[4 - i]));
+        if (hw * ch > max_elems) max_elems = hw * ch;
+    }
+    for (int i = 0; i < 4; ++i) F2_TRY(v->act[i].reserve(max_elems * 2));
+    F2_TRY(v->zin.reserve((size_t)h * w * 32 * 2));
+    Dec d{v, v->ctx->stream};
+    uint16_t* A = v->act[0].as<uint16_t>();
+    uint16_t* B = v->act[1].as<uint16_t>();
+    uint16_t* C = v->act[2].as<uint16_t>();
+    uint16_t* D = v->act[3].as<uint16_t>();
+
+    F2_LAUNCH(launch_nchw_f32_to_nhwc_bf16(d.st, z, v->zin.as<uint16_t>(), 32, h, w), "nchw->nhwc");
+    F2_TRY(d.conv(v->post_quant, v->zin.as<uint16_t>(), h, w, 0, nullptr, B));
+    F2_TRY(d.conv(v->conv_in, B, h, w, 0, nullptr, A));
+    F2_TRY(d.resnet(v->mid0, A, B, C, D, h, w));
+    F2_TRY(d.attention(A, B, h, w));
+    F2_TRY(d.resnet(v->mid1, A, B, C, D, h, w));
+    int H = h, W = w;
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < c.layers_per_block + 1; ++j) {
+            F2_TRY(d.resnet(v->up[i][j], A, B, C, D, H, W));
+        }
+        if (i < 3) {
+            F2_TRY(d.conv(v->upsample[i], A, H, W, 1, nullptr, B));
+            std::swap(A, B);
+            H *= 2;
+            W *= 2;
+        }
+    }
+    F2_TRY(d.gn(v->norm_out, A, B, (int64_t)H * W, 1));
+    F2_TRY(d.conv(v->conv_out, B, H, W, 0, nullptr, nullptr, out_f32, out_u8));
+    return FLUX2MI_OK;
+}

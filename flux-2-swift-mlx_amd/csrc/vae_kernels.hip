@@ -1,0 +1,389 @@
+// vae_kernels.hip — gfx950 kernels of the VAE decoder (VAE/VAEDecoder.swift:91-121,
+// VAE/ResnetBlock.swift): NHWC bf16 activations (the reference is NHWC too), f32
+// accumulation and f32 GroupNorm statistics.
+//
+//   * conv2d: implicit GEMM, M = output pixels, N = Cout, K = taps x Cin, MFMA 16x16x32.
+//     Workgroup = 4 waves x 32 pixels, BN in {32,64,96,128} output channels, K-step = one
+//     tap x 32 input channels.  Nearest-2x upsample (ResnetBlock.swift:217-254) is folded
+//     into the gather (input coordinate >> 1), bias / residual / final u8 conversion into
+//     the epilogue.
+//   * GroupNorm: two-stage statistics (per-workgroup f32 partials, f64 finalize) producing a
+//     per-channel affine (a_c, b_c); apply (+SiLU) is one bf16 pass.
+#include "dev.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int CBM = 128, CBK = 32;
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a, int Ho, int Wo, int cout_pad) {
+    constexpr int NT = BN / 16;
+    constexpr int A_BYTES = CBM * CBK * 2;  // 8 KB
+    constexpr int B_BYTES = BN * CBK * 2;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * (A_BYTES + B_BYTES)];
+
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int P = Ho * Wo;
+    const int tiles_n = (a.Cout + BN - 1) / BN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * CBM, n0 = tn * BN;
+    const int taps = a.ks * a.ks, pad = a.ks >> 1;
+    const int cblocks = a.Cin / CBK;
+    const int nsteps = taps * cblocks;
+    const int up = a.upsample;
+
+    // ---- A staging: 2 chunks/thread: row = idx>>2 (pixel), chunk = idx&3 (8 channels)
+    int a_y[2], a_x[2], a_lds[2], a_chunk[2];
+    bool a_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = t + 256 * i;
+        const int row = idx >> 2, chunk = idx & 3;
+        const int p = m0 + row;
+        a_ok[i] = p < P;
+        const int pp = a_ok[i] ? p : 0;
+        a_y[i] = pp / Wo;
+        a_x[i] = pp % Wo;
+        a_chunk[i] = chunk;
+        a_lds[i] = row * 64 + ((chunk ^ ((-(row >> 2)) & 3)) << 4);
+    }
+    // ---- B staging: BN rows x 4 chunks
+    constexpr int B_CHUNKS = BN * 4;
+    constexpr int B_PER_THREAD = (B_CHUNKS + 255) / 256;
+    int b_lds[B_PER_THREAD], b_row[B_PER_THREAD], b_chunk[B_PER_THREAD];
+    bool b_act[B_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < B_PER_THREAD; ++i) {
+        const int idx = t + 256 * i;
+        b_act[i] = idx < B_CHUNKS;
+        const int row = (idx >> 2) % BN, chunk = idx & 3;
+        b_row[i] = min(n0 + row, cout_pad - 1);
+        b_chunk[i] = chunk;
+        b_lds[i] = A_BYTES + row * 64 + ((chunk ^ ((-(row >> 2)) & 3)) << 4);
+    }
+
+    u32x4 a_reg[2], b_reg[B_PER_THREAD];
+#define CONV_LOAD_STEP(s_)                                                                                     \
+    {                                                                                                          \
+        const int tap_ = (s_) / cblocks, cb_ = (s_) - tap_ * cblocks;                                          \
+        const int ky_ = tap_ / a.ks, kx_ = tap_ - ky_ * a.ks;                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                     \
+            const int iy_ = a_y[i_] + ky_ - pad, ix_ = a_x[i_] + kx_ - pad;                                    \
+            const bool ok_ = a_ok[i_] && iy_ >= 0 && iy_ < Ho && ix_ >= 0 && ix_ < Wo;                         \
+            u32x4 v_ = {0u, 0u, 0u, 0u};                                                                 \
+            if (ok_) {                                                                                         \
+                const size_t off_ = ((size_t)(iy_ >> up) * a.Win + (ix_ >> up)) * a.Cin + cb_ * CBK + a_chunk[i_] * 8; \
+                v_ = *reinterpret_cast<const u32x4*>(a.x + off_);                                              \
+            }                                                                                                  \
+            a_reg[i_] = v_;                                                                                    \
+        }                                                                                                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < B_PER_THREAD; ++i_) {                                          \
+            if (b_act[i_]) {                                                                                   \
+                const size_t off_ = ((size_t)b_row[i_] * taps + tap_) * a.Cin + cb_ * CBK + b_chunk[i_] * 8;   \
+                b_reg[i_] = *reinterpret_cast<const u32x4*>(a.w + off_);                                       \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+#define CONV_STORE_STEP(buf_)                                                                                  \
+    {                                                                                                          \
+        uint8_t* base_ = smem + (buf_) * (A_BYTES + B_BYTES);                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) *reinterpret_cast<u32x4*>(base_ + a_lds[i_]) = a_reg[i_]; \
+        _Pragma("unroll") for (int i_ = 0; i_ < B_PER_THREAD; ++i_)                                            \
+            if (b_act[i_]) *reinterpret_cast<u32x4*>(base_ + b_lds[i_]) = b_reg[i_];                           \
+    }
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fslot = ((fq ^ ((-(frow >> 2)) & 3)) << 4);
+
+    CONV_LOAD_STEP(0)
+    CONV_STORE_STEP(0)
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) CONV_LOAD_STEP(s + 1)
+        const uint8_t* sa = smem + buf * (A_BYTES + B_BYTES);
+        const uint8_t* sb = sa + A_BYTES;
+        bf16x8 af[2], bfr[NT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            af[i] = *reinterpret_cast<const bf16x8*>(sa + (wid * 32 + i * 16 + frow) * 64 + fslot);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + (j * 16 + frow) * 64 + fslot);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        if (s + 1 < nsteps) CONV_STORE_STEP(buf ^ 1)
+        __syncthreads();
+    }
+
+    // ---- epilogue
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = n0 + j * 16 + frow;
+        if (col >= a.Cout) continue;
+        const float bias = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = m0 + wid * 32 + i * 16 + fq * 4 + r;
+                if (p >= P) continue;
+                float v = acc[i][j][r] + bias;
+                if (a.resid) v += bf16_bits_to_f32(a.resid[(size_t)p * a.Cout + col]);
+                if (a.y) a.y[(size_t)p * a.Cout + col] = f32_to_bf16_bits(v);
+                if (a.y_f32_nchw) a.y_f32_nchw[(size_t)col * P + p] = v;
+                if (a.y_u8_hwc) {
+                    // postprocessVAEOutput (Flux2Pipeline.swift:2438-2444): clip then truncating cast
+                    const float u = fminf(fmaxf((v + 1.0f) * 127.5f, 0.0f), 255.0f);
+                    a.y_u8_hwc[(size_t)p * a.Cout + col] = (uint8_t)u;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------- GroupNorm
+// stage 1: per-workgroup partial (sum, sumsq) per group.  Thread owns a fixed 8-channel
+// chunk and strides over pixels, so its group ids are loop-invariant.
+__global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* __restrict__ x, int64_t pixels, int C,
+                                                         int groups, int64_t px_per_block,
+                                                         float* __restrict__ partial) {
+    __shared__ float gsum[64], gsq[64];
+    if (threadIdx.x < 64) { gsum[threadIdx.x] = 0.f; gsq[threadIdx.x] = 0.f; }
+    __syncthreads();
+    const int cpb = C >> 3;             // 8-channel chunks per pixel
+    const int ppi = 256 / cpb;          // pixels per iteration
+    const int cc = threadIdx.x % cpb, pl = threadIdx.x / cpb;
+    const int64_t p0 = (int64_t)blockIdx.x * px_per_block;
+    const int64_t p1 = min(pixels, p0 + px_per_block);
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    if (pl < ppi) {
+        for (int64_t p = p0 + pl; p < p1; p += ppi) {
+            const uint4 v = *reinterpret_cast<const uint4*>(x + p * C + cc * 8);
+            const float f[8] = {lo_bf16(v.x), hi_bf16(v.x), lo_bf16(v.y), hi_bf16(v.y),
+                                lo_bf16(v.z), hi_bf16(v.z), lo_bf16(v.w), hi_bf16(v.w)};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+        }
+        const int cpg = C / groups;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (cc * 8 + j) / cpg;
+            atomicAdd(&gsum[g], s[j]);
+            atomicAdd(&gsq[g], q[j]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < groups) {
+        partial[((size_t)blockIdx.x * groups + threadIdx.x) * 2 + 0] = gsum[threadIdx.x];
+        partial[((size_t)blockIdx.x * groups + threadIdx.x) * 2 + 1] = gsq[threadIdx.x];
+    }
+}
+
+// stage 2: one workgroup; f64 combine -> per-channel a_c = rstd*gamma, b_c = beta - mean*a_c
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nblocks, int64_t pixels,
+                                                          int C, int groups, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ ab) {
+    __shared__ double dsum[64], dsq[64];
+    __shared__ float gmean[64], grstd[64];
+    const int t = threadIdx.x;
+    // 4 threads per group (groups <= 64)
+    const int g = t >> 2, part = t & 3;
+    double s = 0.0, q = 0.0;
+    if (g < groups) {
+        for (int b = part; b < nblocks; b += 4) {
+            s += (double)partial[((size_t)b * groups + g) * 2 + 0];
+            q += (double)partial[((size_t)b * groups + g) * 2 + 1];
+        }
+    }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2);
+    if (g < groups && part == 0) { dsum[g] = s; dsq[g] = q; }
+    __syncthreads();
+    if (t < groups) {
+        const double n = (double)pixels * (double)(C / groups);
+        const double mean = dsum[t] / n;
+        double var = dsq[t] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        gmean[t] = (float)mean;
+        grstd[t] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int cpg = C / groups;
+    for (int c = t; c < C; c += 256) {
+        const int gg = c / cpg;
+        const float a = grstd[gg] * gamma[c];
+        ab[c] = a;
+        ab[C + c] = beta[c] - gmean[gg] * a;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                       int64_t nchunks, int cpb, const float* __restrict__ ab, int C,
+                                                       int silu) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cpb) * 8;
+        const uint4 v = reinterpret_cast<const uint4*>(x)[i];
+        float f[8] = {lo_bf16(v.x), hi_bf16(v.x), lo_bf16(v.y), hi_bf16(v.y),
+                      lo_bf16(v.z), hi_bf16(v.z), lo_bf16(v.w), hi_bf16(v.w)};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float o = ab[c0 + j] * f[j] + ab[C + c0 + j];
+            if (silu) o = silu_f(o);
+            f[j] = o;
+        }
+        uint4 o;
+        o.x = pack_bf16x2(f[0], f[1]); o.y = pack_bf16x2(f[2], f[3]);
+        o.z = pack_bf16x2(f[4], f[5]); o.w = pack_bf16x2(f[6], f[7]);
+        reinterpret_cast<uint4*>(y)[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------- layout helpers
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int C, int HW) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < C * HW; i += gridDim.x * blockDim.x) {
+        const int c = i % C, p = i / C;
+        out[i] = f32_to_bf16_bits(in[(size_t)c * HW + p]);
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ in, uint16_t* __restrict__ out,
+                                                           int cols) {
+    __shared__ float red[4];
+    const float* r = in + (size_t)blockIdx.x * cols;
+    uint16_t* o = out + (size_t)blockIdx.x * cols;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, r[c]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wid] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) s += __expf(r[c] - mx);
+    s = wave_sum(s);
+    if (lane == 0) red[wid] = s;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int c = threadIdx.x; c < cols; c += 256) o[c] = f32_to_bf16_bits(__expf(r[c] - mx) * inv);
+}
+
+__global__ void transpose_bf16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int rows, int cols) {
+    __shared__ uint16_t tile[32][34];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int r = by + j, c = bx + threadIdx.x;
+        if (r < rows && c < cols) tile[j][threadIdx.x] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int c = bx + j, r = by + threadIdx.x;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[threadIdx.x][j];
+    }
+}
+
+// OIHW -> O(HW)I with O zero-padded to O_pad rows (WeightLoader.swift:495-497 does OIHW->OHWI)
+__global__ void oihw_to_ohwi_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int O, int I, int KK,
+                                    int O_pad) {
+    const int total = O_pad * KK * I;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ci = i % I, tap = (i / I) % KK, o = i / (I * KK);
+        out[i] = (o < O) ? in[((size_t)o * I + ci) * KK + tap] : (uint16_t)0;
+    }
+}
+
+}  // namespace
+
+#define VK_DONE() return hipGetLastError() == hipSuccess ? 0 : 2
+
+int launch_conv2d(hipStream_t stream, const ConvArgs& a) {
+    if ((a.ks != 1 && a.ks != 3) || a.Cin % CBK != 0 || a.Cout <= 0 || a.Hin <= 0 || a.Win <= 0) return 1;
+    const int Ho = a.upsample ? 2 * a.Hin : a.Hin, Wo = a.upsample ? 2 * a.Win : a.Win;
+    const int P = Ho * Wo;
+    const int tiles_m = (P + CBM - 1) / CBM;
+    const int cout_pad = ((a.Cout + 31) / 32) * 32;
+    int bn;
+    if (a.Cout % 128 == 0) bn = 128;
+    else if (a.Cout % 96 == 0) bn = 96;
+    else if (a.Cout % 64 == 0) bn = 64;
+    else bn = 32;
+    const int tiles_n = (a.Cout + bn - 1) / bn;
+    dim3 grid(tiles_m * tiles_n), block(256);
+    switch (bn) {
+        case 128: hipLaunchKernelGGL(conv2d_kernel<128>, grid, block, 0, stream, a, Ho, Wo, cout_pad); break;
+        case 96: hipLaunchKernelGGL(conv2d_kernel<96>, grid, block, 0, stream, a, Ho, Wo, cout_pad); break;
+        case 64: hipLaunchKernelGGL(conv2d_kernel<64>, grid, block, 0, stream, a, Ho, Wo, cout_pad); break;
+        default: hipLaunchKernelGGL(conv2d_kernel<32>, grid, block, 0, stream, a, Ho, Wo, cout_pad); break;
+    }
+    VK_DONE();
+}
+
+static inline int64_t gn_px_per_block(int64_t pixels) {
+    int64_t ppb = (pixels + 1023) / 1024;
+    if (ppb < 64) ppb = 64;
+    return ppb;
+}
+int groupnorm_partial_floats(int64_t pixels, int groups) {
+    const int64_t ppb = gn_px_per_block(pixels);
+    return (int)(((pixels + ppb - 1) / ppb) * groups * 2);
+}
+int launch_groupnorm_stats(hipStream_t stream, const uint16_t* x, int64_t pixels, int C, int groups,
+                           const float* gamma, const float* beta, float eps, float* partial, float* ab) {
+    if (pixels <= 0 || C <= 0 || (C & 7) || groups <= 0 || groups > 64 || C % groups || (C >> 3) > 256) return 1;
+    const int64_t ppb = gn_px_per_block(pixels);
+    const int nblocks = (int)((pixels + ppb - 1) / ppb);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblocks), dim3(256), 0, stream, x, pixels, C, groups, ppb, partial);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, nblocks, pixels, C, groups, gamma,
+                       beta, eps, ab);
+    VK_DONE();
+}
+int launch_groupnorm_apply(hipStream_t stream, const uint16_t* x, uint16_t* y, int64_t pixels, int C,
+                           const float* ab, int silu) {
+    if (pixels <= 0 || (C & 7)) return 1;
+    const int64_t nchunks = pixels * (C >> 3);
+    int64_t blocks = (nchunks + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y, nchunks, C >> 3, ab, C,
+                       silu);
+    VK_DONE();
+}
+int launch_nchw_f32_to_nhwc_bf16(hipStream_t stream, const float* in, uint16_t* out, int C, int H, int W) {
+    const int total = C * H * W;
+    if (total <= 0) return 1;
+    int blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(blocks), dim3(256), 0, stream, in, out, C, H * W);
+    VK_DONE();
+}
+int launch_softmax_rows(hipStream_t stream, const float* in, uint16_t* out, int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 1;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, in, out, cols);
+    VK_DONE();
+}
+int launch_transpose_bf16(hipStream_t stream, const uint16_t* in, uint16_t* out, int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 1;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, stream, in,
+                       out, rows, cols);
+    VK_DONE();
+}
+int launch_oihw_to_ohwi_bf16(hipStream_t stream, const uint16_t* in, uint16_t* out, int O, int I, int KH, int KW,
+                             int O_pad) {
+    const int total = O_pad * KH * KW * I;
+    if (total <= 0) return 1;
+    int blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(oihw_to_ohwi_kernel, dim3(blocks), dim3(256), 0, stream, in, out, O, I, KH * KW, O_pad);
+    VK_DONE();
+}

@@ -1,0 +1,268 @@
+"""Host-side mirror of the reference's public surface for the hot path:
+`Flux2Pipeline.generate*`, `Flux2StepHook`, `Flux2StepContext`,
+`Flux2GenerationResult` (Flux2Core/Pipeline/Flux2Pipeline.swift:16-87, 855-1176) and
+the RePaint chain (Flux2Chains/Flux2MaskedInpaintingChain.swift:300-431).
+
+The loop itself runs in C++ (`flux2mi_generate`, csrc/pipeline.cpp); this file maps the
+reference's argument names onto the C ABI so that tests read like the reference's.
+What is an explicit input here and implicit in the reference:
+  * text embeddings (`precomputed_embeddings`, bf16 [1,S_txt,J]) — the text encoders
+    are outside the path;
+  * noise — the reference draws MLX threefry noise from `seed`; here `noise`
+    ([1,128,H/16,W/16] f32) is explicit, or drawn with torch's Philox generator from
+    `seed` (NOT MLX-compatible; documented in DESIGN.md).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from ._lib import Flux2Error, check, lib
+from .api import Context, DiT, VAE, resolve_chain_dimensions, validate_dimensions
+
+
+@dataclass
+class Flux2StepContext:
+    """Flux2Pipeline.swift:42-57."""
+    stepIdx: int
+    totalSteps: int
+    sigma: float
+    sigmaNext: float
+    height: int
+    width: int
+    isI2I: bool
+
+
+# Flux2StepHook = (Flux2StepContext, latents [1,S,128] device tensor) -> latents
+Flux2StepHook = Callable[[Flux2StepContext, torch.Tensor], torch.Tensor]
+
+
+@dataclass
+class Flux2GenerationResult:
+    """Flux2Pipeline.swift:67-87 (image is u8 [H,W,3] instead of CGImage)."""
+    image: Optional[np.ndarray]
+    usedPrompt: str
+    wasUpsampled: bool
+    originalPrompt: str
+    latents: Optional[torch.Tensor] = None
+    effectiveSteps: int = 0
+    msDenoise: float = 0.0
+    msDecode: float = 0.0
+
+
+class Flux2Pipeline:
+    """`Flux2Pipeline(model:...)` restricted to the hot path: embeddings in, image out."""
+
+    def __init__(self, model="klein-4b", vae_variant="small", device: int = 0):
+        self.ctx = Context(device)
+        self.model = model
+        self.vae_variant = vae_variant
+        self.transformer: Optional[DiT] = None
+        self.vae: Optional[VAE] = None
+
+    # loadModels(progressCallback:) — weights are handed over as tensors by key
+    def load_models(self, dit_tensors=None, vae_tensors=None):
+        if dit_tensors is not None:
+            self.transformer = DiT(self.ctx, self.model).load(dit_tensors).finalize()
+        if vae_tensors is not None:
+            self.vae = VAE(self.ctx, self.vae_variant).load(vae_tensors).finalize()
+        return self
+
+    @property
+    def isLoaded(self) -> bool:
+        return self.transformer is not None and self.vae is not None
+
+    @property
+    def uses_guidance_embeds(self) -> bool:
+        return bool(self.transformer.cfg.guidance_embeds) if self.transformer else False
+
+    # ---- public generate* family -------------------------------------------------
+    def generate_text_to_image(self, prompt: str = "", height: int = 1024, width: int = 1024, steps: int = 28,
+                               guidance: float = 4.0, seed: Optional[int] = None, precomputed_embeddings=None,
+                               noise=None, checkpoint_interval: Optional[int] = None, on_progress=None,
+                               on_checkpoint=None, on_step: Optional[Flux2StepHook] = None) -> Flux2GenerationResult:
+        return self.generate_with_result("textToImage", prompt=prompt, height=height, width=width, steps=steps,
+                                         guidance=guidance, seed=seed, precomputed_embeddings=precomputed_embeddings,
+                                         noise=noise, checkpoint_interval=checkpoint_interval, on_progress=on_progress,
+                                         on_checkpoint=on_checkpoint, on_step=on_step)
+
+    def generate_image_to_image(self, prompt: str = "", reference_latents=None, reference_ids=None, **kw):
+        """`generateImageToImage(prompt:images:...)` with the references already encoded
+        (VAE encode is a 'next' row): reference_latents f32 [1,S_ref,128], reference_ids i32 [S_ref,4]."""
+        if reference_latents is None or reference_ids is None:
+            raise Flux2Error(L.ERR_INVALID_ARG, "imageToImage requires 1-3 encoded reference images")
+        return self.generate_with_result("imageToImage", prompt=prompt, reference_latents=reference_latents,
+                                         reference_ids=reference_ids, **kw)
+
+    def generate_with_result(self, mode: str = "textToImage", prompt: str = "", height: int = 1024,
+                             width: int = 1024, steps: int = 28, guidance: float = 4.0, seed: Optional[int] = None,
+                             precomputed_embeddings=None, negative_embeddings=None, cfg_scale: float = 1.0,
+                             noise=None, checkpoint_interval: Optional[int] = None, init_latents=None,
+                             strength: float = 1.0, on_progress=None, on_checkpoint=None,
+                             on_step: Optional[Flux2StepHook] = None, reference_latents=None, reference_ids=None,
+                             custom_sigmas: Optional[Sequence[float]] = None, skip_decode: bool = False,
+                             return_latents: bool = False) -> Flux2GenerationResult:
+        if self.transformer is None:
+            raise Flux2Error(L.ERR_NOT_LOADED, "Transformer")
+        if self.vae is None and not skip_decode:
+            raise Flux2Error(L.ERR_NOT_LOADED, "VAE")
+        if precomputed_embeddings is None:
+            raise Flux2Error(L.ERR_NOT_LOADED, "TextEncoder (pass precomputed_embeddings; the text encoders are outside the hot path)")
+        dev = self.ctx.device
+        H, W = validate_dimensions(height, width)
+        s_img = (H // 16) * (W // 16)
+        txt = precomputed_embeddings.to(device=dev, dtype=torch.bfloat16).reshape(-1, precomputed_embeddings.shape[-1]).contiguous()
+        if noise is None:
+            g = torch.Generator(device=dev)
+            g.manual_seed(0 if seed is None else int(seed))
+            noise = torch.randn((1, 128, H // 16, W // 16), generator=g, device=dev, dtype=torch.float32)
+        noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+        if tuple(noise.shape[-3:]) != (128, H // 16, W // 16):
+            raise Flux2Error(L.ERR_SHAPE, f"noise shape {tuple(noise.shape)} != [1,128,{H // 16},{W // 16}]")
+
+        p = L.GenerateParams()
+        p.height, p.width, p.steps, p.guidance = height, width, steps, guidance
+        p.txt_emb, p.s_txt = txt.data_ptr(), txt.shape[0]
+        keep = [txt, noise]
+        if negative_embeddings is not None:
+            neg = negative_embeddings.to(device=dev, dtype=torch.bfloat16).reshape(-1, negative_embeddings.shape[-1]).contiguous()
+            keep.append(neg)
+            p.neg_emb, p.s_neg, p.cfg_scale = neg.data_ptr(), neg.shape[0], cfg_scale
+        p.noise = noise.data_ptr()
+        p.strength = strength
+        if init_latents is not None:
+            il = init_latents.to(device=dev, dtype=torch.float32).reshape(-1, 128).contiguous()
+            if il.shape[0] != s_img:  # Flux2Pipeline.swift:1898-1901
+                raise Flux2Error(L.ERR_SHAPE, f"initLatents shape {tuple(init_latents.shape)} does not match latents shape [1, {s_img}, 128]")
+            keep.append(il)
+            p.init_latents = il.data_ptr()
+        if mode == "imageToImage" or reference_latents is not None:
+            rl = reference_latents.to(device=dev, dtype=torch.float32).reshape(-1, 128).contiguous()
+            ri = reference_ids.to(device=dev, dtype=torch.int32).contiguous()
+            keep += [rl, ri]
+            p.ref_latents, p.ref_ids, p.s_ref = rl.data_ptr(), ri.data_ptr(), rl.shape[0]
+        if custom_sigmas is not None:
+            cs = (C.c_float * len(custom_sigmas))(*[float(s) for s in custom_sigmas])
+            keep.append(cs)
+            p.custom_sigmas, p.n_custom_sigmas = cs, len(custom_sigmas)
+        p.checkpoint_interval = checkpoint_interval or 0
+        p.skip_decode = int(skip_decode)
+
+        stream = self.ctx.stream
+        hook_error: List[BaseException] = []
+
+        if on_step is not None:
+            def _hook(cptr, lat_ptr, _stream, _user):
+                try:
+                    c = cptr.contents
+                    ctx = Flux2StepContext(c.step_idx, c.total_steps, c.sigma, c.sigma_next, c.height, c.width, bool(c.is_i2i))
+                    # zero-copy view of the library's latent buffer
+                    lat = _tensor_from_ptr(lat_ptr, (1, s_img, 128), dev)
+                    with torch.cuda.stream(stream):
+                        out = on_step(ctx, lat)
+                        if out is not None and out.data_ptr() != lat.data_ptr():
+                            lat.copy_(out.reshape(1, s_img, 128))
+                    return 0
+                except BaseException as e:  # noqa: BLE001 - surfaced after the C call returns
+                    hook_error.append(e)
+                    return 1
+            cb = L.STEP_HOOK(_hook)
+            keep.append(cb)
+            p.on_step = cb
+        if on_progress is not None:
+            pcb = L.PROGRESS_CB(lambda s, t, _u: on_progress(s, t))
+            keep.append(pcb)
+            p.on_progress = pcb
+        if on_checkpoint is not None:
+            def _ck(step, ptr, h, w, _u):
+                arr = np.ctypeslib.as_array(ptr, shape=(h, w, 3)).copy()
+                on_checkpoint(step, arr)
+            ccb = L.CHECKPOINT_CB(_ck)
+            keep.append(ccb)
+            p.on_checkpoint = ccb
+
+        image = None
+        if not skip_decode:
+            image = np.empty((H, W, 3), dtype=np.uint8)
+            p.out_image = image.ctypes.data
+        lat_out = None
+        if return_latents or skip_decode:
+            lat_out = torch.empty((1, s_img, 128), dtype=torch.float32, device=dev)
+            p.out_latents = lat_out.data_ptr()
+
+        self.ctx._enter()
+        status = lib().flux2mi_generate(self.ctx.handle, self.transformer.handle,
+                                        self.vae.handle if self.vae is not None else None, C.byref(p))
+        self.ctx._exit()
+        if hook_error:
+            raise hook_error[0]
+        check(status)
+        return Flux2GenerationResult(image=image, usedPrompt=prompt, wasUpsampled=False, originalPrompt=prompt,
+                                     latents=lat_out, effectiveSteps=p.effective_steps, msDenoise=p.ms_denoise,
+                                     msDecode=p.ms_decode)
+
+    # ---- chain helpers (Flux2Pipeline+ChainHelpers.swift) ------------------------
+    resolveChainDimensions = staticmethod(resolve_chain_dimensions)
+
+    @staticmethod
+    def pack_mask_for_latent_blending(mask_hw: torch.Tensor, target_height: int, target_width: int) -> torch.Tensor:
+        """[H,W] in [0,1], 1 = inpaint -> [1,(H/16)(W/16),1] (+ChainHelpers.swift:148-236).  The reference
+        rasterises with CoreGraphics `.high` interpolation into 8 bits; this uses an exact area
+        average rounded to 8 bits (host-side pre-processing, not a hot-path kernel)."""
+        m = mask_hw.float().reshape(1, 1, *mask_hw.shape)
+        m = torch.nn.functional.adaptive_avg_pool2d(m, (target_height // 16, target_width // 16))
+        return (torch.round(m * 255.0) / 255.0).reshape(1, -1, 1)
+
+    def clearAll(self):
+        if self.transformer:
+            self.transformer.close()
+        if self.vae:
+            self.vae.close()
+        self.transformer = self.vae = None
+
+
+def _tensor_from_ptr(ptr: int, shape, device) -> torch.Tensor:
+    """Zero-copy f32 device tensor over library-owned memory (valid during the callback)."""
+    n = int(np.prod(shape))
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(h, device=device).view(*shape)
+
+
+class Flux2MaskedInpaintingChain:
+    """RePaint inpainting chain (Flux2Chains/Flux2MaskedInpaintingChain.swift:300-431) on
+    already-encoded inputs: image latents [1,S,128] (VAE-encoded, BN-normalised, packed),
+    mask [1,S,1] (1 = inpaint), blend noise [1,S,128] drawn once."""
+
+    def __init__(self, pipeline: Flux2Pipeline, image_latents: torch.Tensor, mask_latents: torch.Tensor,
+                 blend_noise: torch.Tensor):
+        self.pipeline = pipeline
+        dev = pipeline.ctx.device
+        self.image_latents = image_latents.to(dev, torch.float32).contiguous()
+        self.mask_latents = mask_latents.to(dev, torch.float32).contiguous()
+        self.blend_noise = blend_noise.to(dev, torch.float32).contiguous()
+
+    def on_step(self, ctx: Flux2StepContext, latents: torch.Tensor) -> torch.Tensor:
+        """:399-403 — orig = (1-s')*img + s'*noise ; x = (1-m)*orig + m*x, one fused kernel, in place."""
+        c = self.pipeline.ctx
+        check(lib().flux2mi_repaint_blend(c.handle, latents.data_ptr(), self.image_latents.data_ptr(),
+                                          self.blend_noise.data_ptr(), self.mask_latents.data_ptr(),
+                                          ctx.sigmaNext, latents.shape[-2], latents.shape[-1]))
+        return latents
+
+    def run(self, precomputed_embeddings, height: int, width: int, steps: int, guidance: float = 4.0,
+            strength: float = 1.0, noise=None, seed=None, **kw) -> Flux2GenerationResult:
+        return self.pipeline.generate_with_result(
+            "textToImage", height=height, width=width, steps=steps, guidance=guidance, seed=seed, noise=noise,
+            precomputed_embeddings=precomputed_embeddings,
+            init_latents=self.image_latents if strength < 1.0 else None, strength=strength,
+            on_step=self.on_step, **kw)

@@ -1,0 +1,245 @@
+/* flux2mi.h — C ABI of libflux2mi.so: the MI355X (gfx950) implementation of the
+ * Flux.2 denoise + VAE-decode hot path.
+ *
+ * The reference (VincentGourbin/flux-2-swift-mlx v2.4.0) has no FFI seam on this
+ * path: it sits behind the Swift class `Flux2Pipeline` and every tensor is an
+ * `MLXArray`.  This header is what a Swift shim module binds (see INTEGRATION.md;
+ * precedent for Swift -> C-ABI calls in the reference:
+ * Sources/Flux2Core/Utils/MLXCheckpoint.swift:23-118).  Each entry point cites the
+ * reference interface it replaces (paths relative to the reference's Sources/).
+ *
+ * Conventions
+ *   - plain C11: opaque handles, pointers and sizes; no C++/torch types.
+ *   - every function returns int status (FLUX2MI_OK == 0); flux2mi_last_error()
+ *     gives the thread-local message.  Nothing aborts the process.
+ *   - "device pointer" = HIP device memory of the context's GPU; the caller owns
+ *     input/output buffers, the library owns weights and workspace.
+ *   - one context = one GPU + one HIP stream = one generation in flight
+ *     (Flux2Pipeline is one-generation-at-a-time as well: Flux2Pipeline.swift:135).
+ *     All device work is enqueued on the context's stream; functions documented as
+ *     "async" return before the GPU finishes (flux2mi_ctx_sync to wait).
+ *   - batch is 1 per forward like the reference (Flux2Pipeline.swift:1937); batch
+ *     data-parallelism is one image per GPU/process.
+ */
+#ifndef FLUX2MI_H
+#define FLUX2MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLUX2MI_VERSION 100 /* 0.1.0 */
+
+enum flux2mi_status {
+    FLUX2MI_OK = 0,
+    FLUX2MI_ERR_INVALID_ARG = 1,   /* Flux2Error.invalidConfiguration (Flux2Core.swift:14-40) */
+    FLUX2MI_ERR_HIP = 2,           /* HIP runtime failure */
+    FLUX2MI_ERR_NOT_LOADED = 3,    /* Flux2Error.modelNotLoaded */
+    FLUX2MI_ERR_SHAPE = 4,         /* shape mismatch (e.g. initLatents, Flux2Pipeline.swift:1898-1901) */
+    FLUX2MI_ERR_CANCELLED = 5,     /* Flux2Error.generationCancelled (Flux2Pipeline.swift:1940-1942) */
+    FLUX2MI_ERR_UNSUPPORTED = 6,
+    FLUX2MI_ERR_OOM = 7            /* Flux2Error.insufficientMemory */
+};
+
+enum flux2mi_dtype { FLUX2MI_F32 = 0, FLUX2MI_BF16 = 1, FLUX2MI_F16 = 2 };
+
+typedef struct flux2mi_ctx flux2mi_ctx;
+typedef struct flux2mi_dit flux2mi_dit;
+typedef struct flux2mi_vae flux2mi_vae;
+
+int flux2mi_version(void);
+const char* flux2mi_last_error(void);
+
+/* ---- context ---------------------------------------------------------- */
+/* `hip_stream` may be NULL (the library creates a non-blocking stream) or an
+ * existing hipStream_t the caller wants the work ordered on. */
+int flux2mi_ctx_create(int device, void* hip_stream, flux2mi_ctx** out);
+int flux2mi_ctx_destroy(flux2mi_ctx* ctx);
+int flux2mi_ctx_sync(flux2mi_ctx* ctx);                 /* == MLX eval(): stream synchronise */
+void* flux2mi_ctx_stream(flux2mi_ctx* ctx);             /* hipStream_t */
+
+/* ---- scheduler (host) -------------------------------------------------- */
+/* FlowMatchEulerScheduler.swift:9-28 */
+float flux2mi_compute_empirical_mu(int image_seq_len, int num_steps);
+/* FlowMatchEulerScheduler.swift:65-115.  image_seq_len <= 0 selects the reference's
+ * default (4096).  Writes the strength-sliced sigma table (length *n_out, terminal
+ * 0 included) and tStart. */
+int flux2mi_set_timesteps(int num_inference_steps, int image_seq_len, float strength,
+                          float* sigmas_out, int capacity, int* n_out, int* t_start_out);
+/* FlowMatchEulerScheduler.swift:236-260 (terminal 0 appended unless already 0). */
+int flux2mi_set_custom_sigmas(const float* sigmas_in, int n_in, float* sigmas_out, int capacity,
+                              int* n_out);
+
+/* ---- latent utilities (host) -- Pipeline/LatentUtils.swift ------------- */
+void flux2mi_validate_dimensions(int height, int width, int* out_height, int* out_width); /* :382-394 */
+/* Pipeline/Flux2Pipeline+ChainHelpers.swift:112-129 */
+void flux2mi_resolve_chain_dimensions(int width, int height, int max_pixels, int* out_height,
+                                      int* out_width);
+int flux2mi_image_position_ids(int height, int width, int32_t* out_host, int capacity_rows);   /* :256-286 */
+int flux2mi_text_position_ids(int length, int32_t* out_host, int capacity_rows);               /* :291-298 */
+int flux2mi_reference_position_ids(const int* latent_heights, const int* latent_widths, int n_images,
+                                   int scale, int32_t* out_host, int capacity_rows);            /* :324-346 */
+
+/* ---- elementwise device ops (async) ------------------------------------ */
+/* FlowMatchEulerScheduler.step (:136-156): x += dt * v, dt = sigma_next - sigma. */
+int flux2mi_sched_step(flux2mi_ctx* ctx, float* x, const float* v, float dt, int64_t n);
+/* FlowMatchEulerScheduler.scaleNoise (:195-204): out = (1-sigma)*sample + sigma*noise. */
+int flux2mi_scale_noise(flux2mi_ctx* ctx, float* out, const float* sample, const float* noise,
+                        float sigma, int64_t n);
+/* classical CFG, Flux2Pipeline.swift:1955-1973: v = v_uncond + g*(v_cond - v_uncond), in place on v_cond. */
+int flux2mi_cfg_combine(flux2mi_ctx* ctx, float* v_cond, const float* v_uncond, float guidance, int64_t n);
+/* RePaint hook body, Flux2Chains/Flux2MaskedInpaintingChain.swift:399-403:
+ * x = (1-m)*((1-sigma_next)*img + sigma_next*noise) + m*x ; m is [S,1] broadcast over c. */
+int flux2mi_repaint_blend(flux2mi_ctx* ctx, float* x, const float* image_latents, const float* blend_noise,
+                          const float* mask, float sigma_next, int seq, int channels);
+/* LatentUtils.packPatchifiedToSequence (:76-86): [C,h,w] -> [h*w,C]. */
+int flux2mi_pack_patchified_to_sequence(flux2mi_ctx* ctx, const float* patchified, float* seq, int c, int h, int w);
+/* LatentUtils.unpackSequenceToPatchified (:95-110): [h*w,C] -> [C,h,w]. */
+int flux2mi_unpack_sequence_to_patchified(flux2mi_ctx* ctx, const float* seq, float* patchified, int c, int h, int w);
+/* Flux2Pipeline.swift:2059-2079 fused: unpack -> denormalizeLatentsWithBatchNorm
+ * (LatentUtils.swift:483-496, eps 1e-4) -> unpatchifyLatents (:119-142).
+ * packed [h16*w16,128] -> z [32, 2*h16, 2*w16]. */
+int flux2mi_latents_to_vae_input(flux2mi_ctx* ctx, const float* packed, const float* bn_mean,
+                                 const float* bn_var, float* z, int h16, int w16);
+/* Inverse (encodeImageToPackedSequence tail, +ChainHelpers.swift:90-99):
+ * z [32,2*h16,2*w16] -> patchify -> BN-normalise -> packed [h16*w16,128]. */
+int flux2mi_vae_latents_to_packed(flux2mi_ctx* ctx, const float* z, const float* bn_mean,
+                                  const float* bn_var, float* packed, int h16, int w16);
+
+/* ---- DiT (Flux2Transformer2DModel) -------------------------------------- */
+typedef struct flux2mi_dit_config {
+    int dim;              /* inner dim = heads * 128 */
+    int heads;
+    int n_double;         /* numLayers */
+    int n_single;         /* numSingleLayers */
+    int joint_dim;        /* jointAttentionDim */
+    int guidance_embeds;  /* Dev: 1, Klein: 0 */
+} flux2mi_dit_config;
+
+/* presets "klein-4b" | "klein-9b" | "dev" (Configuration/Flux2Config.swift:258-329). */
+int flux2mi_dit_preset(const char* name, flux2mi_dit_config* out);
+int flux2mi_dit_create(flux2mi_ctx* ctx, const flux2mi_dit_config* cfg, flux2mi_dit** out);
+int flux2mi_dit_destroy(flux2mi_dit* dit);
+/* Weight ingestion; replaces WeightLoader.mapTransformerWeights + applyTransformerWeights
+ * (Loading/WeightLoader.swift:81-295 BFL keys, :397-480 diffusers keys).  `name` is the
+ * checkpoint key in either scheme; `data` may be a host or a device pointer; dtype
+ * f32/bf16/f16 is converted to bf16 storage.  Fused layouts (qkv, SwiGLU interleave)
+ * are built here. */
+int flux2mi_dit_set_tensor(flux2mi_dit* dit, const char* name, int dtype, const int64_t* shape, int ndim,
+                           const void* data);
+int flux2mi_dit_finalize(flux2mi_dit* dit); /* error if a tensor is missing */
+int64_t flux2mi_dit_param_bytes(const flux2mi_dit* dit);
+/* Flux2Transformer2DModel.callAsFunction (Transformer/Flux2Transformer.swift:123-327), async.
+ *   latents   f32 [s_img, 128] device  (output tokens first, then reference tokens)
+ *   txt_emb   bf16 [s_txt, joint_dim] device
+ *   timestep  sigma in [0,1] (multiplied by 1000 inside, :145)
+ *   guidance  used only when cfg.guidance_embeds (pass the scale, e.g. 4.0)
+ *   img_ids   i32 [s_img,4], txt_ids i32 [s_txt,4] device, (T,H,W,L)
+ *   out       f32 [s_out,128] device: prediction for the first s_out image tokens
+ *             (I2I keeps only the output tokens, Flux2Pipeline.swift:1743). */
+int flux2mi_dit_forward(flux2mi_dit* dit, const float* latents, int s_img, const void* txt_emb, int s_txt,
+                        float timestep, float guidance, const int32_t* img_ids, const int32_t* txt_ids,
+                        float* out, int s_out);
+
+/* ---- VAE decoder (AutoencoderKLFlux2.decode) ---------------------------- */
+typedef struct flux2mi_vae_config {
+    int channels[4];       /* decoder block_out_channels, e.g. 128,256,512,512 (small: 96,192,384,384) */
+    int latent_channels;   /* 32 */
+    int groups;            /* 32 */
+    int layers_per_block;  /* 2 (decoder uses +1) */
+} flux2mi_vae_config;
+
+/* presets "standard" | "small" (Configuration/VAEConfig.swift:44-81). */
+int flux2mi_vae_preset(const char* name, flux2mi_vae_config* out);
+int flux2mi_vae_create(flux2mi_ctx* ctx, const flux2mi_vae_config* cfg, flux2mi_vae** out);
+int flux2mi_vae_destroy(flux2mi_vae* vae);
+/* diffusers keys, conv weights OIHW as in the file (WeightLoader.swift:486-560);
+ * encoder keys are accepted and ignored. */
+int flux2mi_vae_set_tensor(flux2mi_vae* vae, const char* name, int dtype, const int64_t* shape, int ndim,
+                           const void* data);
+int flux2mi_vae_finalize(flux2mi_vae* vae);
+const float* flux2mi_vae_bn_mean(const flux2mi_vae* vae); /* device f32 [128] */
+const float* flux2mi_vae_bn_var(const flux2mi_vae* vae);  /* device f32 [128] */
+/* AutoencoderKLFlux2.decode (VAE/AutoencoderKL.swift:129-143) + postprocessVAEOutput
+ * (Pipeline/Flux2Pipeline.swift:2425-2468), async.
+ *   z        f32 [32,h,w] device (NCHW like the reference)
+ *   out_f32  f32 [3,8h,8w] device or NULL
+ *   out_u8   u8 [8h,8w,3] device or NULL: clip((x+1)*127.5,0,255), truncating cast */
+int flux2mi_vae_decode(flux2mi_vae* vae, const float* z, int h, int w, float* out_f32, uint8_t* out_u8);
+
+/* ---- pipeline: Flux2Pipeline.generateWithResult hot section -------------- */
+/* Flux2StepContext (Pipeline/Flux2Pipeline.swift:42-57) */
+typedef struct flux2mi_step_context {
+    int step_idx;
+    int total_steps;
+    float sigma;
+    float sigma_next;
+    int height;
+    int width;
+    int is_i2i;
+} flux2mi_step_context;
+
+/* Flux2StepHook (:64).  Called on the generating thread after the Euler update of
+ * every step incl. the last (sigma_next == 0).  `latents` is the device buffer
+ * f32 [s_img,128]; modify it in place with work enqueued on `stream` (e.g.
+ * flux2mi_repaint_blend).  Non-zero return cancels (FLUX2MI_ERR_CANCELLED). */
+typedef int (*flux2mi_step_hook)(const flux2mi_step_context* ctx, float* latents, void* stream, void* user);
+/* Flux2ProgressCallback (:32): (currentStep, totalSteps), after the hook. */
+typedef void (*flux2mi_progress_cb)(int step, int total, void* user);
+/* Flux2CheckpointCallback (:35): decoded intermediate image, host u8 [H,W,3]. */
+typedef void (*flux2mi_checkpoint_cb)(int step, const uint8_t* rgb, int height, int width, void* user);
+
+typedef struct flux2mi_generate_params {
+    /* inputs */
+    int height, width;             /* rounded UP to x16 like validateDimensions */
+    int steps;
+    float guidance;                /* embedded guidance (Dev) */
+    const void* txt_emb;           /* bf16 [s_txt, joint_dim] device (precomputedEmbeddings) */
+    int s_txt;
+    const void* neg_emb;           /* classical CFG (base models): bf16 [s_neg, joint_dim] or NULL */
+    int s_neg;
+    float cfg_scale;               /* > 1 with neg_emb enables two-pass CFG */
+    const float* noise;            /* f32 [128,H/16,W/16] device: patchified-layout noise (explicit RNG) */
+    const float* init_latents;     /* f32 [S_img,128] device or NULL (img2img init, :1897-1907) */
+    float strength;                /* < 1 requires init_latents (:1210-1213) */
+    const float* ref_latents;      /* f32 [s_ref,128] device or NULL (I2I conditioning tokens) */
+    const int32_t* ref_ids;        /* i32 [s_ref,4] device */
+    int s_ref;
+    const float* custom_sigmas;    /* host, LoRA scheduler override (:1873-1878) or NULL */
+    int n_custom_sigmas;
+    int checkpoint_interval;       /* <= 0: none */
+    flux2mi_step_hook on_step; void* on_step_user;
+    flux2mi_progress_cb on_progress; void* on_progress_user;
+    flux2mi_checkpoint_cb on_checkpoint; void* on_checkpoint_user;
+    int skip_decode;               /* 1: stop after the denoise loop */
+    /* outputs */
+    uint8_t* out_image;            /* host u8 [H,W,3] or NULL */
+    float* out_latents;            /* device f32 [S_img,128] or NULL: final packed latents */
+    int out_height, out_width;
+    int effective_steps;
+    float ms_denoise;              /* phase "6. Denoising Loop" (HIP events) */
+    float ms_decode;               /* phases "7. VAE Decode" + "8. Post-processing" */
+} flux2mi_generate_params;
+
+int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae* vae, flux2mi_generate_params* p);
+
+/* ---- measurement aid ---------------------------------------------------- */
+/* HIP-event timing of one kernel class on the context's stream while the hot path
+ * runs (bench.py roofline leg).  kernel_class: 0 = single-block linear1 GEMM,
+ * 1 = all DiT GEMMs, 2 = attention, 3 = VAE conv. */
+int flux2mi_prof_begin(flux2mi_ctx* ctx, int kernel_class);
+int flux2mi_prof_end(flux2mi_ctx* ctx, int* n_launches, double* total_ms, double* flops);
+
+/* Standalone op entry points (tests / microbenchmarks; same kernels the forward uses). */
+/* C[M,N] (f32) = A[M,K] (bf16) * W[N,K]^T (bf16) */
+int flux2mi_op_gemm_bf16(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K);
+/* joint attention: qkv bf16 [S, 3*heads*128] (q|k|v, already normalised/rotated) -> out bf16 [S, heads*128] */
+int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv, void* out, int S, int heads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUX2MI_H */

@@ -1,0 +1,144 @@
+"""-m gpu: DiT forward parity, HIP path (C ABI) vs the fp32 oracle on identical
+bf16-rounded synthetic weights and inputs.
+
+Tolerance (stated): rel-L2 of the [S_img,128] prediction <= 2e-2 vs the fp32 oracle
+(bf16 GEMM operands / attention probabilities, f32 accumulation and residual stream)."""
+import pytest
+import torch
+
+from oracle import flux2_ref as R
+from tests.util import rel_l2, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _forward_both(flux2mi, ctx, cfg, s_txt, h, w, t=0.731, g=4.0, seed=1234, refs=None):
+    from flux2mi import synthetic as syn
+    from flux2mi.api import DiT
+
+    P = syn.make_dit_weights(cfg, seed=seed)
+    inp = syn.make_inputs(cfg, h, w, s_txt=s_txt)
+    lat = R.pack_patchified_to_sequence(inp["noise"])
+    img_ids = R.image_position_ids(h, w)
+    if refs is not None:
+        lat = torch.cat([lat, refs[0]], dim=1)
+        img_ids = torch.cat([img_ids, refs[1]], dim=0)
+    txt_ids = R.text_position_ids(s_txt)
+    dit = DiT(ctx, cfg).load(P).finalize()
+    out = dit.forward(lat.cuda(), inp["txt"].cuda(), t, g, img_ids.cuda(), txt_ids.cuda())
+    gt = torch.tensor([g]) if cfg["guidance"] else None
+    ref = R.dit_forward(P, cfg, lat, inp["txt"].float(), torch.tensor([t]), gt, img_ids, txt_ids)[0]
+    dit.close()
+    return out, ref
+
+
+def test_tiny_forward(flux2mi, ctx):
+    from flux2mi import synthetic as syn
+    out, ref = _forward_both(flux2mi, ctx, syn.DIT_PRESETS["tiny"], s_txt=16, h=128, w=128)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 2e-2
+
+
+def test_tiny_forward_ragged_sequence(flux2mi, ctx):
+    """S = 19 + 35 = 54: nothing is a multiple of a tile."""
+    from flux2mi import synthetic as syn
+    out, ref = _forward_both(flux2mi, ctx, syn.DIT_PRESETS["tiny"], s_txt=19, h=80, w=112)
+    assert rel_l2(out, ref) < 2e-2
+
+
+def test_tiny_forward_guidance_embeds(flux2mi, ctx):
+    from flux2mi import synthetic as syn
+    out, ref = _forward_both(flux2mi, ctx, syn.DIT_PRESETS["tiny-g"], s_txt=16, h=128, w=128, g=4.0)
+    assert rel_l2(out, ref) < 2e-2
+
+
+def test_tiny_forward_reference_tokens(flux2mi, ctx):
+    """I2I conditioning: reference tokens appended after the output tokens with T = 10."""
+    from flux2mi import synthetic as syn
+    g = torch.Generator().manual_seed(5)
+    ref_lat = torch.randn((1, 24, 128), generator=g)
+    ref_ids = R.reference_position_ids([4], [6])
+    out, ref = _forward_both(flux2mi, ctx, syn.DIT_PRESETS["tiny"], s_txt=16, h=128, w=128, refs=(ref_lat, ref_ids))
+    assert out.shape[0] == 64 + 24
+    assert rel_l2(out, ref) < 2e-2
+
+
+def test_diffusers_key_scheme_equals_bfl(flux2mi, ctx):
+    """The same weights ingested under diffusers names (split q/k/v, [scale|shift] norm_out)
+    give the same forward (WeightLoader.swift:397-480 vs :99-205)."""
+    from flux2mi import synthetic as syn
+    from flux2mi.api import DiT
+
+    cfg = syn.DIT_PRESETS["tiny"]
+    d = cfg["dim"]
+    P = syn.make_dit_weights(cfg)
+    D = {}
+    ren = {"img_in.weight": "x_embedder.weight", "txt_in.weight": "context_embedder.weight",
+           "time_in.in_layer.weight": "time_guidance_embed.timestep_embedder.linear_1.weight",
+           "time_in.out_layer.weight": "time_guidance_embed.timestep_embedder.linear_2.weight",
+           "double_stream_modulation_img.lin.weight": "double_stream_modulation_img.linear.weight",
+           "double_stream_modulation_txt.lin.weight": "double_stream_modulation_txt.linear.weight",
+           "single_stream_modulation.lin.weight": "single_stream_modulation.linear.weight",
+           "final_layer.linear.weight": "proj_out.weight"}
+    for k, v in P.items():
+        if k in ren:
+            D[ren[k]] = v
+        elif k == "final_layer.adaLN_modulation.1.weight":
+            D["norm_out.linear.weight"] = torch.cat([v[d:], v[:d]], dim=0)   # diffusers: [scale | shift]
+        elif k.startswith("double_blocks."):
+            i = k.split(".")[1]
+            pre = f"transformer_blocks.{i}."
+            tail = k.split(".", 2)[2]
+            m = {"img_attn.proj.weight": "attn.to_out.0.weight", "txt_attn.proj.weight": "attn.to_add_out.weight",
+                 "img_attn.norm.query_norm.scale": "attn.norm_q.weight", "img_attn.norm.key_norm.scale": "attn.norm_k.weight",
+                 "txt_attn.norm.query_norm.scale": "attn.norm_added_q.weight", "txt_attn.norm.key_norm.scale": "attn.norm_added_k.weight",
+                 "img_mlp.0.weight": "ff.linear_in.weight", "img_mlp.2.weight": "ff.linear_out.weight",
+                 "txt_mlp.0.weight": "ff_context.linear_in.weight", "txt_mlp.2.weight": "ff_context.linear_out.weight"}
+            if tail == "img_attn.qkv.weight":
+                for n, part in zip(("to_q", "to_k", "to_v"), v.chunk(3, dim=0)):
+                    D[pre + f"attn.{n}.weight"] = part.contiguous()
+            elif tail == "txt_attn.qkv.weight":
+                for n, part in zip(("add_q_proj", "add_k_proj", "add_v_proj"), v.chunk(3, dim=0)):
+                    D[pre + f"attn.{n}.weight"] = part.contiguous()
+            else:
+                D[pre + m[tail]] = v
+        elif k.startswith("single_blocks."):
+            i = k.split(".")[1]
+            pre = f"single_transformer_blocks.{i}.attn."
+            tail = k.split(".", 2)[2]
+            m = {"linear1.weight": "to_qkv_mlp_proj.weight", "linear2.weight": "to_out.weight",
+                 "norm.query_norm.scale": "norm_q.weight", "norm.key_norm.scale": "norm_k.weight"}
+            D[pre + m[tail]] = v
+        else:
+            raise AssertionError(k)
+    inp = syn.make_inputs(cfg, 128, 128, s_txt=16)
+    lat = R.pack_patchified_to_sequence(inp["noise"]).cuda()
+    ii, ti = R.image_position_ids(128, 128).cuda(), R.text_position_ids(16).cuda()
+    a = DiT(ctx, cfg).load(P).finalize()
+    b = DiT(ctx, cfg).load(D).finalize()
+    oa = a.forward(lat, inp["txt"].cuda(), 0.5, 0.0, ii, ti)
+    ob = b.forward(lat, inp["txt"].cuda(), 0.5, 0.0, ii, ti)
+    assert torch.equal(oa, ob)
+    a.close(); b.close()
+
+
+def test_missing_tensor_is_an_error(flux2mi, ctx):
+    from flux2mi import synthetic as syn
+    from flux2mi.api import DiT
+
+    cfg = syn.DIT_PRESETS["tiny"]
+    P = syn.make_dit_weights(cfg)
+    P.pop("single_blocks.1.linear2.weight")
+    d = DiT(ctx, cfg).load(P)
+    with pytest.raises(flux2mi.Flux2Error) as e:
+        d.finalize()
+    assert "single_blocks.1.linear2.weight" in str(e.value)
+    d.close()
+
+
+def test_production_width_blocks(flux2mi, ctx):
+    """Klein-4B width (d 3072, H 24, J 7680) with 1 double + 1 single block, 256x256 (S 768)."""
+    cfg = dict(dim=3072, heads=24, n_double=1, n_single=1, joint_dim=7680, guidance=False)
+    out, ref = _forward_both(flux2mi, ctx, cfg, s_txt=512, h=256, w=256)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 2e-2

@@ -1,0 +1,165 @@
+"""-m gpu: the sampler loop through `flux2mi_generate` (C++ host driver + HIP kernels)
+vs the oracle's restatement of generateWithResult, on the tiny config.
+
+Tolerances (stated): per-step latent rel-L2 <= 3e-2 (grows with steps), final u8 image
+mean |diff| <= 3 levels."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import flux2_ref as R
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny(flux2mi, ctx):
+    from flux2mi import synthetic as syn
+    from flux2mi.pipeline import Flux2Pipeline
+
+    cfg, vcfg = syn.DIT_PRESETS["tiny"], syn.VAE_PRESETS["tiny"]
+    P, VP = syn.make_dit_weights(cfg), syn.make_vae_weights(vcfg)
+    pipe = Flux2Pipeline(model=cfg, vae_variant=vcfg).load_models(P, VP)
+    inp = syn.make_inputs(cfg, 128, 128, s_txt=16)
+    return dict(cfg=cfg, vcfg=vcfg, P=P, VP=VP, pipe=pipe, inp=inp)
+
+
+def _img_diff(a: np.ndarray, b: torch.Tensor):
+    return (torch.from_numpy(a).int() - b.int()).abs().float()
+
+
+def test_t2i_trajectory_and_image(tiny):
+    t = tiny
+    traj = []
+    def observer(ctx, lat):
+        traj.append(lat.detach().clone().cpu())
+        return lat
+    progress = []
+    res = t["pipe"].generate_text_to_image(height=128, width=128, steps=4, precomputed_embeddings=t["inp"]["txt"],
+                                           noise=t["inp"]["noise"], on_step=observer,
+                                           on_progress=lambda s, n: progress.append((s, n)))
+    ref = R.generate(t["P"], t["cfg"], t["VP"], t["vcfg"], t["inp"]["txt"].float(), t["inp"]["noise"], 128, 128, 4)
+    assert res.effectiveSteps == 4 and progress == [(1, 4), (2, 4), (3, 4), (4, 4)]
+    assert len(traj) == 4
+    for k in range(4):
+        assert rel_l2(traj[k], ref["latents"][k]) < 3e-2, k
+    d = _img_diff(res.image, ref["image"])
+    assert d.mean() < 3.0
+
+
+def test_round_up_dimensions(tiny):
+    """validateDimensions rounds UP to x16 (LatentUtils.swift:382-394): 120x100 -> 128x112."""
+    t = tiny
+    from flux2mi import synthetic as syn
+    inp = syn.make_inputs(t["cfg"], 128, 112, s_txt=16)
+    res = t["pipe"].generate_text_to_image(height=120, width=100, steps=2, precomputed_embeddings=inp["txt"],
+                                           noise=inp["noise"])
+    assert res.image.shape == (128, 112, 3)
+
+
+def test_img2img_strength_and_repaint_hook(tiny):
+    """Config E in miniature: init latents + strength 0.7 + RePaint blend every step incl. the last."""
+    from flux2mi.pipeline import Flux2MaskedInpaintingChain
+    t = tiny
+    g = torch.Generator().manual_seed(99)
+    S = 64
+    image_latents = torch.randn((1, S, 128), generator=g)
+    blend_noise = torch.randn((1, S, 128), generator=g)
+    mask = torch.zeros((8, 8))
+    mask[2:6, 2:6] = 1.0
+    mask[1, 2:6] = 0.5   # soft edge
+    mask = mask.reshape(1, S, 1)
+    chain = Flux2MaskedInpaintingChain(t["pipe"], image_latents, mask, blend_noise)
+    res = chain.run(t["inp"]["txt"], 128, 128, steps=10, strength=0.7, noise=t["inp"]["noise"], return_latents=True)
+    hook = lambda c, x: R.repaint_blend(x, image_latents, blend_noise, mask, c["sigmaNext"])
+    ref = R.generate(t["P"], t["cfg"], t["VP"], t["vcfg"], t["inp"]["txt"].float(), t["inp"]["noise"], 128, 128, 10,
+                     init_latents=image_latents, strength=0.7, on_step=hook)
+    assert res.effectiveSteps == 7 == len(ref["latents"])
+    lat = res.latents.cpu()
+    assert rel_l2(lat, ref["final_latents"]) < 3e-2
+    # sigma_next == 0 on the last step: outside the mask the clean source latent is restored exactly
+    keep = (mask == 0).expand_as(lat)
+    assert torch.equal(lat[keep], image_latents[keep])
+    assert _img_diff(res.image, ref["image"]).mean() < 3.0
+
+
+def test_i2i_reference_tokens(tiny):
+    t = tiny
+    g = torch.Generator().manual_seed(5)
+    ref_lat = torch.randn((1, 24, 128), generator=g)
+    ref_ids = R.reference_position_ids([4], [6])
+    res = t["pipe"].generate_image_to_image(reference_latents=ref_lat, reference_ids=ref_ids, height=128, width=128,
+                                            steps=3, precomputed_embeddings=t["inp"]["txt"], noise=t["inp"]["noise"],
+                                            return_latents=True)
+    ref = R.generate(t["P"], t["cfg"], t["VP"], t["vcfg"], t["inp"]["txt"].float(), t["inp"]["noise"], 128, 128, 3,
+                     ref_latents=ref_lat, ref_ids=ref_ids)
+    assert rel_l2(res.latents, ref["final_latents"]) < 3e-2
+
+
+def test_classical_cfg(tiny):
+    t = tiny
+    g = torch.Generator().manual_seed(8)
+    neg = torch.randn((1, 12, t["cfg"]["joint_dim"]), generator=g).to(torch.bfloat16)
+    res = t["pipe"].generate_with_result(height=128, width=128, steps=2, precomputed_embeddings=t["inp"]["txt"],
+                                         negative_embeddings=neg, cfg_scale=3.0, noise=t["inp"]["noise"],
+                                         skip_decode=True)
+    ref = R.generate(t["P"], t["cfg"], None, None, t["inp"]["txt"].float(), t["inp"]["noise"], 128, 128, 2,
+                     neg_emb=neg.float(), cfg_scale=3.0, decode=False)
+    assert rel_l2(res.latents, ref["final_latents"]) < 4e-2
+
+
+def test_custom_sigmas_and_checkpoints(tiny):
+    t = tiny
+    shots = []
+    res = t["pipe"].generate_with_result(height=128, width=128, steps=4, precomputed_embeddings=t["inp"]["txt"],
+                                         noise=t["inp"]["noise"], custom_sigmas=[1.0, 0.6, 0.3, 0.1],
+                                         checkpoint_interval=2, on_checkpoint=lambda s, im: shots.append((s, im.shape)),
+                                         return_latents=True)
+    ref = R.generate(t["P"], t["cfg"], t["VP"], t["vcfg"], t["inp"]["txt"].float(), t["inp"]["noise"], 128, 128, 4,
+                     custom_sigmas=[1.0, 0.6, 0.3, 0.1])
+    assert res.effectiveSteps == 4   # terminal 0 appended
+    assert shots == [(2, (128, 128, 3)), (4, (128, 128, 3))]
+    assert rel_l2(res.latents, ref["final_latents"]) < 3e-2
+
+
+def test_error_contracts(tiny, flux2mi):
+    t = tiny
+    with pytest.raises(flux2mi.Flux2Error):   # strength < 1 without initLatents (Flux2Pipeline.swift:1210-1213)
+        t["pipe"].generate_with_result(height=128, width=128, steps=4, precomputed_embeddings=t["inp"]["txt"],
+                                       noise=t["inp"]["noise"], strength=0.5)
+    with pytest.raises(flux2mi.Flux2Error):   # initLatents shape mismatch (:1898-1901)
+        t["pipe"].generate_with_result(height=128, width=128, steps=4, precomputed_embeddings=t["inp"]["txt"],
+                                       noise=t["inp"]["noise"], strength=0.5, init_latents=torch.zeros(1, 10, 128))
+    with pytest.raises(flux2mi.Flux2Error):   # zero denoising steps (:1893-1896)
+        t["pipe"].generate_with_result(height=128, width=128, steps=4, precomputed_embeddings=t["inp"]["txt"],
+                                       noise=t["inp"]["noise"], strength=0.1, init_latents=torch.zeros(1, 64, 128))
+    def cancel(c, x):
+        raise KeyboardInterrupt("cancel")
+    with pytest.raises(KeyboardInterrupt):    # hook cancellation surfaces, process survives
+        t["pipe"].generate_with_result(height=128, width=128, steps=4, precomputed_embeddings=t["inp"]["txt"],
+                                       noise=t["inp"]["noise"], on_step=cancel)
+    # and the pipeline still works afterwards
+    res = t["pipe"].generate_text_to_image(height=128, width=128, steps=1, precomputed_embeddings=t["inp"]["txt"],
+                                           noise=t["inp"]["noise"])
+    assert res.image.shape == (128, 128, 3)
+
+
+def test_klein4b_full_depth_forward_256(flux2mi, ctx):
+    """BASELINE config A geometry: Klein-4B (5+20 blocks), 256x256, S = 768, one forward."""
+    from flux2mi import synthetic as syn
+    from flux2mi.api import DiT
+
+    cfg = syn.DIT_PRESETS["klein-4b"]
+    P = syn.make_dit_weights(cfg, device="cuda")
+    inp = syn.make_inputs(cfg, 256, 256, s_txt=512)
+    lat = R.pack_patchified_to_sequence(inp["noise"])
+    ii, ti = R.image_position_ids(256, 256), R.text_position_ids(512)
+    dit = DiT(ctx, "klein-4b").load(P).finalize()
+    out = dit.forward(lat.cuda(), inp["txt"].cuda(), 0.877, 0.0, ii.cuda(), ti.cuda())
+    Pc = {k: v.cpu() for k, v in P.items()}
+    del P
+    ref = R.dit_forward(Pc, cfg, lat, inp["txt"].float(), torch.tensor([0.877]), None, ii, ti)[0]
+    dit.close()
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 3e-2
