@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — Flux.2 Klein-4B 1024x1024 @ 28 steps on N MI355X (BASELINE.json configs[1]).
+
+One bench "step" = one batch of N images (one per GPU, batch-level data parallel): the
+28 denoise steps of the DiT, VAE decode and the D2H copy of the u8 image, with text
+embeddings and noise resident in HBM when the timed region starts.  Per batch the ranks
+exchange exactly two collectives (RCCL over xGMI): broadcast of the text embeddings from
+rank 0 and all-gather of the decoded images.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with
+  value     = total denoise steps of all ranks / wall time of the timed region (incl. decode)
+  roofline  = dominant kernel (single-stream linear1 GEMM) measured with HIP events on the
+              library's stream during the timed region, vs the 2.5 PF dense bf16 MFMA peak
+  cpu_baseline = the restated fp32 oracle (NOT MLX) timed on the host cores on a bounded sample.
+Weights are synthetic (seeded N(0,0.02), bf16) — there are no checkpoints on the box.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed batches (one image per GPU each)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="klein-4b")
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--denoise-steps", type=int, default=28)
+    ap.add_argument("--vae", default="standard", choices=["standard", "small"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-class", type=int, default=0, help="kernel class timed with HIP events (0 = linear1 GEMM)")
+    args = ap.parse_args()
+
+    import torch
+
+    import flux2mi
+    from flux2mi import parallel as par
+    from flux2mi import synthetic as syn
+    from flux2mi.pipeline import Flux2Pipeline
+
+    rank, world, local = par.init_distributed()
+    assert world == max(1, args.gpus) or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    dev_index = local if world > 1 else 0
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+
+    cfg = syn.DIT_PRESETS[args.model]
+    vcfg = syn.VAE_PRESETS[args.vae]
+    H, W, T = args.height, args.width, args.denoise_steps
+    s_txt = 512
+    s_img = (H // 16) * (W // 16)
+    S = s_txt + s_img
+    d = cfg["dim"]
+
+    # ---- model: synthetic weights generated on the GPU, replicated per rank
+    t0 = time.time()
+    pipe = Flux2Pipeline(model=args.model, vae_variant=args.vae, device=dev_index)
+    P = syn.make_dit_weights(cfg, seed=1234, device=dev)
+    VP = syn.make_vae_weights(vcfg, seed=4321, device=dev)
+    pipe.load_models(P, VP)
+    if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
+        del P
+    del VP
+    torch.cuda.synchronize()
+    t_load = time.time() - t0
+
+    # ---- inputs resident in HBM: per-rank noise (seed 42 + rank), text embeddings on rank 0
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(42 + rank)
+    noise = torch.randn((1, 128, H // 16, W // 16), generator=gen, device=dev, dtype=torch.float32)
+    emb_shape = (world, s_txt, cfg["joint_dim"])
+    emb_all = None
+    if rank == 0:
+        g7 = torch.Generator(device=dev)
+        g7.manual_seed(7)
+        emb_all = torch.randn(emb_shape, generator=g7, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    guidance = 4.0
+
+    def one_batch():
+        emb = par.broadcast_text_embeddings(emb_all, emb_shape, dev, src=0)          # collective 1
+        res = pipe.generate_text_to_image(height=H, width=W, steps=T, guidance=guidance,
+                                          precomputed_embeddings=emb[rank if world > 1 else 0], noise=noise)
+        img = torch.from_numpy(res.image).to(dev).unsqueeze(0)
+        imgs = par.all_gather_images(img)                                            # collective 2
+        return res, imgs
+
+    for _ in range(args.warmup):
+        one_batch()
+
+    par.barrier()
+    torch.cuda.synchronize()
+    pipe.ctx.prof_begin(args.prof_class)
+    t_start = time.perf_counter()
+    ms_denoise = ms_decode = 0.0
+    for _ in range(args.steps):
+        res, imgs = one_batch()
+        ms_denoise += res.msDenoise
+        ms_decode += res.msDecode
+    torch.cuda.synchronize()
+    par.barrier()
+    elapsed = time.perf_counter() - t_start
+    n_launch, prof_ms, prof_flops = pipe.ctx.prof_end()
+    elapsed = par.all_reduce_max(elapsed, dev)
+
+    if rank != 0:
+        return
+
+    K = args.steps
+    total_denoise_steps = world * K * T
+    value = total_denoise_steps / elapsed
+    sec_per_image = elapsed / K   # latency of one image (every rank produces one per batch)
+
+    # ---- roofline of the dominant kernel: single-stream linear1 GEMM [S,d] x [9d,d]^T
+    flops_per_launch = prof_flops / max(n_launch, 1)
+    avg_ms = prof_ms / max(n_launch, 1)
+    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    peak = 2500.0  # TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md chip table)
+    roofline = {"bound": "mfma", "kernel": "gemm_bf16_128x128_kernel (single_blocks.linear1)",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
+                "flops_per_launch": flops_per_launch}
+
+    # whole-step algorithmic FLOPs for context
+    blocks = cfg["n_double"] + cfg["n_single"]
+    step_flops = blocks * (26.0 * S * d * d + 4.0 * S * S * d) + 2.0 * (s_img * 128 * d * 2 + s_txt * cfg["joint_dim"] * d)
+    step_ms = ms_denoise / (K * T)
+
+    cpu_baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(P, cfg, syn)
+
+    out = {
+        "metric": "denoise-steps/sec (Flux.2 Klein-4B 1024x1024 @ 28 steps; seconds/image reported alongside)",
+        "value": round(value, 4),
+        "unit": "denoise-steps/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * elapsed / K, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": f"Flux.2 {args.model} bf16, {H}x{W}, {T} denoise steps + {args.vae} VAE decode + D2H, "
+                               f"1 image per GPU per bench step (BASELINE.json configs[1])",
+                   "images_per_bench_step": world, "s_txt": s_txt, "s_img": s_img, "parallelism": f"dp{world}"},
+        "seconds_per_image": round(sec_per_image, 4),
+        "denoise_ms_per_denoise_step": round(step_ms, 3),
+        "decode_ms_per_image": round(ms_decode / K, 3),
+        "dit_step_tflops": round(step_flops / (step_ms * 1e-3) / 1e12, 2) if step_ms > 0 else None,
+        "dit_step_mfma_frac": round(step_flops / (step_ms * 1e-3) / 1e12 / peak, 4) if step_ms > 0 else None,
+        "model_load_s": round(t_load, 2),
+        "roofline": roofline,
+        "cpu_baseline": cpu_baseline,
+    }
+    print(json.dumps(out))
+
+
+def run_cpu_baseline(P_dev, cfg, syn):
+    """The restated oracle (torch CPU fp32 — NOT the reference's MLX path, which cannot run
+    here) on a bounded sample: ONE DiT forward of the same model at 256x256 (S = 768,
+    4.9 TFLOP).  Reported in the metric's unit for that sample."""
+    import torch
+
+    from oracle import flux2_ref as R
+
+    cores = torch.get_num_threads()
+    Pc = {k: v.cpu() for k, v in P_dev.items()}
+    inp = syn.make_inputs(cfg, 256, 256, s_txt=512)
+    lat = R.pack_patchified_to_sequence(inp["noise"])
+    ii, ti = R.image_position_ids(256, 256), R.text_position_ids(512)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        R.dit_forward(Pc, cfg, lat, inp["txt"].float(), torch.tensor([0.9]), None, ii, ti)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 5), "unit": "denoise-steps/s", "cores": cores, "kind": "port",
+            "sample": "1 DiT forward of the restated fp32 oracle (torch CPU), Klein-4B, 256x256 (S=768, 4.92 TFLOP); "
+                      "the 1024x1024 step is 7.1x more FLOPs", "seconds": round(dt, 2)}
+
+
+if __name__ == "__main__":
+    main()

@@ -3,6 +3,7 @@ ordering only; every compute call goes through libflux2mi.so."""
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -98,6 +99,7 @@ class Context:
         h = C.c_void_p()
         check(lib().flux2mi_ctx_create(device, C.c_void_p(self.stream.cuda_stream), C.byref(h)))
         self.handle = h
+        self._children = []  # weakrefs of DiT / VAE objects: they must be destroyed before the context
 
     # stream ordering against torch's current stream (no host sync)
     def _enter(self):
@@ -111,6 +113,11 @@ class Context:
 
     def close(self):
         if self.handle:
+            for ref in list(self._children):
+                child = ref()
+                if child is not None:
+                    child.close()
+            self._children = []
             lib().flux2mi_ctx_destroy(self.handle)
             self.handle = None
 
@@ -233,6 +240,7 @@ class DiT:
         h = C.c_void_p()
         check(lib().flux2mi_dit_create(ctx.handle, C.byref(cfg), C.byref(h)))
         self.handle = h
+        ctx._children.append(weakref.ref(self))
 
     def load(self, tensors: Dict[str, torch.Tensor]):
         """Checkpoint tensors by key (BFL or diffusers naming), host or device memory."""
@@ -263,9 +271,9 @@ class DiT:
         return out
 
     def close(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:
             lib().flux2mi_dit_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:
@@ -291,6 +299,7 @@ class VAE:
         h = C.c_void_p()
         check(lib().flux2mi_vae_create(ctx.handle, C.byref(cfg), C.byref(h)))
         self.handle = h
+        ctx._children.append(weakref.ref(self))
 
     def load(self, tensors: Dict[str, torch.Tensor]):
         _set_tensors(lib().flux2mi_vae_set_tensor, self.handle, tensors)
@@ -323,9 +332,9 @@ class VAE:
         return of, ou
 
     def close(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:
             lib().flux2mi_vae_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:
