@@ -40,14 +40,14 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
 
 def broadcast_text_embeddings(emb: Optional[torch.Tensor], shape: Sequence[int], device, src: int = 0) -> torch.Tensor:
     """Rank `src` holds the text encoder output; everyone gets a copy.  bf16 is moved as
-    int16 bits so that gloo (CPU tests) and RCCL take the same path."""
+    raw bytes so that gloo (CPU tests) and RCCL take the same path."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return emb.to(device)
     if dist.get_rank() == src:
         buf = emb.to(device=device, dtype=torch.bfloat16).contiguous()
     else:
         buf = torch.empty(tuple(shape), dtype=torch.bfloat16, device=device)
-    bits = buf.view(torch.int16)
+    bits = buf.view(torch.uint8)  # raw bytes: gloo (CPU tests) and RCCL take the same path
     dist.broadcast(bits, src=src)
     return bits.view(torch.bfloat16)
 

@@ -1,0 +1,52 @@
+"""CPU: the N>1 data-parallel path with world_size 2 over gloo (the GPU run uses the same code
+over RCCL): sharding, text-embedding broadcast, image all-gather, max-over-ranks timing."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import flux2mi  # noqa: F401
+    from flux2mi import parallel as par
+
+    r, w, _ = par.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    shape = (world, 16, 384)
+    emb = None
+    if rank == 0:
+        emb = torch.randn(shape, generator=torch.Generator().manual_seed(7)).to(torch.bfloat16)
+    got = par.broadcast_text_embeddings(emb, shape, "cpu")
+    ref = torch.randn(shape, generator=torch.Generator().manual_seed(7)).to(torch.bfloat16)
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    # every rank "decodes" its image(s): image i = slot*world + rank
+    n_local = 2
+    local = torch.stack([torch.full((4, 6, 3), (s * world + rank), dtype=torch.uint8) for s in range(n_local)])
+    allimgs = par.all_gather_images(local)
+    assert tuple(allimgs.shape) == (world * n_local, 4, 6, 3)
+    assert [int(allimgs[i, 0, 0, 0]) for i in range(world * n_local)] == list(range(world * n_local))
+    assert par.shard_indices(5, rank, world) == [i for i in range(5) if i % world == rank]
+    par.barrier()
+    assert par.all_reduce_max(1.0 + rank, "cpu") == float(world)
+    q.put(rank)
+
+
+def test_dp_world_size_2_gloo():
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5) for _ in range(world)) == list(range(world))
