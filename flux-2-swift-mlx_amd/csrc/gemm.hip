@@ -26,6 +26,9 @@
 // M and N are arbitrary (loads are clamped, stores are masked).
 #include "dev.h"
 #include "kernels.h"
+#include <stdlib.h>
+
+int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob);
 
 namespace {
 
@@ -292,6 +295,18 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
             hipLaunchKernelGGL(gemm_naive_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p);
         }
         return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
+    // large problems -> 256x256 LDS-DMA kernel (gemm256.hip); FLUX2MI_GEMM=128|256 forces a kernel
+    {
+        static const int force = [] {
+            const char* e = getenv("FLUX2MI_GEMM");
+            return e ? atoi(e) : 0;
+        }();
+        long tiles256 = 0;
+        for (int i = 0; i < nprob; ++i)
+            tiles256 += (long)((probs[i].M + 255) / 256) * ((probs[i].N + 255) / 256);
+        const bool big = tiles256 >= 100;
+        if (force == 256 || (force != 128 && big)) return launch_gemm256(stream, probs, nprob);
     }
     GemmBatch b;
     b.nprob = nprob;

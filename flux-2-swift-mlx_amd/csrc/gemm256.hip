@@ -1,0 +1,347 @@
+// gemm256.hip — the large-tile bf16 GEMM: 256x256x64 tile, 8 waves, LDS-DMA staging that
+// stays in flight across barriers (counted vmcnt), 4 MFMA phases per K-tile.
+//
+// Same contract and epilogues as gemm.hip (C = A W^T, W [out,in]); used for the DiT's large
+// problems, where it replaces the 128x128 kernel whose LDS write traffic (ds_write_b128 of
+// both operands) competed with the fragment reads.
+//
+// Geometry
+//   * 512 threads = 8 waves as 2 (M) x 4 (N); wave tile 128 x 64 = 8 x 4 MFMA 16x16x32
+//     accumulators (128 f32 registers).
+//   * LDS = 2 stages x 4 half-tile slots x 16 KB = 128 KB (1 workgroup per CU, 2 waves/SIMD).
+//     A K-tile (64 k) is staged as four half-tiles, cut along what a PHASE consumes:
+//        A0 = for each wave-row, its first 64 rows;  A1 = its second 64 rows;
+//        B0 = for each wave-column, its first 32 weight rows;  B1 = its second 32.
+//     so a slot is free again right after the phase that reads it.
+//   * global -> LDS by global_load_lds_dwordx4 (1 KB per wave-instruction, 2 per thread per
+//     half-tile).  The LDS image stays lane-linear; the bank swizzle (16-B chunk ^ (row>>1)&7)
+//     is applied to the per-lane SOURCE address and to the fragment reads (guide rule 21).
+//   * schedule: half-tiles form one sequence e = 4u + {A0,B0,B1,A1} (u = K-tile).  Phase
+//     phi = 4t + p issues element phi + 7 and consumes: p0 A0,B0 -> quadrant (m0,n0);
+//     p1 B1 -> (m0,n1); p2 A1 -> (m1,n1); p3 nothing new -> (m1,n0).  At the end of every
+//     phase `s_waitcnt vmcnt(10)` (5 younger half-tiles x 2 loads may stay in flight) + one
+//     raw s_barrier make element phi + 2 — exactly what phase phi + 1 reads — visible.
+//     WAR: a slot is re-filled at least one barrier after the phase that read it.
+//     The last two K-tiles wait vmcnt(0) (nothing younger is issued any more).
+#include "dev.h"
+#include "kernels.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
+constexpr int SLOT_BYTES = 128 * BK2 * 2;      // 16 KB
+constexpr int STAGE2_BYTES = 4 * SLOT_BYTES;   // 64 KB
+enum { KIND_A0 = 0, KIND_B0 = 1, KIND_B1 = 2, KIND_A1 = 3 };
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void tile_coords256(int local, int ntiles, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = local & 7, within = local >> 3;
+    const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    constexpr int GM = 6;
+    const int per_group = GM * tiles_n;
+    const int g = idx / per_group;
+    const int first_m = g * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int in_g = idx - g * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+}
+
+// STAGGER: waves 4-7 (wave-row 1; they share SIMDs with waves 0-3) run half a phase behind
+// waves 0-3: every phase has two barriers (reads | MFMAs) and the second group takes one extra
+// barrier up front, so one group's MFMA segment runs beside the other group's LDS-read segment
+// on each SIMD instead of both reading, then both computing (MI355X guide, "Two waves per
+// SIMD" item 9).  Data published by LDS-DMA is then only guaranteed one phase later for the
+// leading group, hence vmcnt(8) instead of vmcnt(10).
+template <bool STAGGER, int ABL>  // ABL: timing-only ablations (1 = no LDS reads in loop, 2 = no DMA in loop, 3 = both)
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch batch) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE2_BYTES];  // 128 KB, the ONLY LDS object
+
+    const int bid = blockIdx.x;
+    const int pi = (batch.nprob > 1 && bid >= batch.tile_start1) ? 1 : 0;
+    const GemmProblem& p = batch.p[pi];
+    const int local = bid - (pi ? batch.tile_start1 : 0);
+    const int tiles_m = (p.M + BM2 - 1) / BM2, tiles_n = (p.N + BN2 - 1) / BN2;
+    int tm, tn;
+    tile_coords256(local, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM2, n0 = tn * BN2;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wid = t >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+
+    // ---- LDS-DMA source addresses: per kind, 2 instructions per thread.
+    // instruction j of wave w fills slot bytes [(j*8+w)*1024, +1024): rows (j*8+w)*8 .. +8,
+    // lane -> row + (lane>>3), LDS chunk c' = lane&7 holds global chunk c' ^ ((row>>1)&7).
+    const uint16_t* src[4][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rho = (j * 8 + wid) * 8 + (lane >> 3);             // slot row 0..127
+        const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
+        const int a_row0 = (rho >> 6) * 128 + (rho & 63);            // A0: wave-row's first 64 rows
+        const int b_row0 = (rho >> 5) * 64 + (rho & 31);             // B0: wave-col's first 32 rows
+        src[KIND_A0][j] = p.A + (size_t)min(m0 + a_row0, p.M - 1) * p.lda + chunk * 8;
+        src[KIND_A1][j] = p.A + (size_t)min(m0 + a_row0 + 64, p.M - 1) * p.lda + chunk * 8;
+        src[KIND_B0][j] = p.W + (size_t)min(n0 + b_row0, p.N - 1) * p.ldw + chunk * 8;
+        src[KIND_B1][j] = p.W + (size_t)min(n0 + b_row0 + 32, p.N - 1) * p.ldw + chunk * 8;
+    }
+    const int lds_wave = wid * 1024;  // + j*8192 + slot*SLOT_BYTES + stage*STAGE2_BYTES
+    const int nk = p.K / BK2;
+    const int total_elems = nk * 4;
+
+#define G2_ISSUE(kind_, u_)                                                                                   \
+    {                                                                                                         \
+        const int u__ = (u_);                                                                                 \
+        if (u__ < nk) {                                                                                       \
+            uint8_t* dst__ = smem + (u__ & 1) * STAGE2_BYTES + (kind_) * SLOT_BYTES + lds_wave;               \
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[kind_][0] + u__ * BK2), (lptr_t)(dst__), 16, 0, 0);      \
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[kind_][1] + u__ * BK2), (lptr_t)(dst__ + 8192), 16, 0, 0); \
+        }                                                                                                     \
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment read offsets inside a slot
+    const int frow = lane & 15, fq = lane >> 4;
+    const int sw = (frow >> 1) & 7;
+    const int a_frag = (wm * 64 + frow) * 128;   // + i*16*128
+    const int b_frag = (wn * 32 + frow) * 128;   // + j*16*128
+    const int c0 = ((0 + fq) ^ sw) << 4, c1 = ((4 + fq) ^ sw) << 4;   // kk = 0, 1
+
+    bf16x8 a[4][2], b0[2][2], b1[2][2];
+
+#define G2_READ_A(slot_)                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                     \
+        const uint8_t* r__ = st + (slot_) * SLOT_BYTES + a_frag + i_ * 2048;               \
+        a[i_][0] = *reinterpret_cast<const bf16x8*>(r__ + c0);                             \
+        a[i_][1] = *reinterpret_cast<const bf16x8*>(r__ + c1);                             \
+    }
+#define G2_READ_B(dst_, slot_)                                                             \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                     \
+        const uint8_t* r__ = st + (slot_) * SLOT_BYTES + b_frag + j_ * 2048;               \
+        dst_[j_][0] = *reinterpret_cast<const bf16x8*>(r__ + c0);                          \
+        dst_[j_][1] = *reinterpret_cast<const bf16x8*>(r__ + c1);                          \
+    }
+#define G2_MFMA(mh_, nh_, bsrc_)                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                 \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                             \
+                acc[(mh_) * 4 + i_][(nh_) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(          \
+                    a[i_][kk_], bsrc_[j_][kk_], acc[(mh_) * 4 + i_][(nh_) * 2 + j_], 0, 0, 0);           \
+    __builtin_amdgcn_s_setprio(0);
+#define G2_SYNC()                        \
+    asm volatile("" ::: "memory");       \
+    __builtin_amdgcn_s_barrier();        \
+    asm volatile("" ::: "memory");
+#define G2_READS_DONE()                                          \
+    if (STAGGER) {                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        G2_SYNC()                                                \
+    }
+#define G2_PHASE_END()                                                          \
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
+    else if (STAGGER) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          \
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                      \
+    G2_SYNC()
+
+    // ---- prologue: elements 0..6 = K-tile 0 (A0,B0,B1,A1) + K-tile 1 (A0,B0,B1)
+    G2_ISSUE(KIND_A0, 0) G2_ISSUE(KIND_B0, 0) G2_ISSUE(KIND_B1, 0) G2_ISSUE(KIND_A1, 0)
+    G2_ISSUE(KIND_A0, 1) G2_ISSUE(KIND_B0, 1) G2_ISSUE(KIND_B1, 1)
+    {
+        const bool drain = nk < 3;
+        G2_PHASE_END()
+    }
+    const int wm_u = __builtin_amdgcn_readfirstlane(wid) >> 2;  // provably wave-uniform
+    if (STAGGER && wm_u == 1) { G2_SYNC() }
+
+    if (ABL & 1) {  // operands read once; wrong results by design
+        const uint8_t* st = smem;
+        G2_READ_B(b0, KIND_B0) G2_READ_B(b1, KIND_B1) G2_READ_A(KIND_A0)
+    }
+#define G2_ISSUE_L(k_, u_) if (!(ABL & 2)) G2_ISSUE(k_, u_)
+#define G2_READ_A_L(s_) if (!(ABL & 1)) { G2_READ_A(s_) }
+#define G2_READ_B_L(d_, s_) if (!(ABL & 1)) { G2_READ_B(d_, s_) }
+    for (int kt = 0; kt < nk; ++kt) {
+        const uint8_t* st = smem + (kt & 1) * STAGE2_BYTES;
+        const bool drain = kt + 2 >= nk;
+        // phase 0: issue A1(kt+1); consume A0, B0 -> quadrant (m0, n0)
+        G2_ISSUE_L(KIND_A1, kt + 1)
+        G2_READ_B_L(b0, KIND_B0)
+        G2_READ_A_L(KIND_A0)
+        G2_READS_DONE()
+        G2_MFMA(0, 0, b0)
+        G2_PHASE_END()
+        // phase 1: issue A0(kt+2); consume B1 -> (m0, n1)
+        G2_ISSUE_L(KIND_A0, kt + 2)
+        G2_READ_B_L(b1, KIND_B1)
+        G2_READS_DONE()
+        G2_MFMA(0, 1, b1)
+        G2_PHASE_END()
+        // phase 2: issue B0(kt+2); consume A1 -> (m1, n1)
+        G2_ISSUE_L(KIND_B0, kt + 2)
+        G2_READ_A_L(KIND_A1)
+        G2_READS_DONE()
+        G2_MFMA(1, 1, b1)
+        G2_PHASE_END()
+        // phase 3: issue B1(kt+2); b0 still in registers -> (m1, n0)
+        G2_ISSUE_L(KIND_B1, kt + 2)
+        G2_READS_DONE()
+        G2_MFMA(1, 0, b0)
+        G2_PHASE_END()
+    }
+    if (STAGGER && wm_u == 0) { G2_SYNC() }
+#undef G2_ISSUE
+#undef G2_READ_A
+#undef G2_READ_B
+#undef G2_MFMA
+#undef G2_PHASE_END
+#undef G2_READS_DONE
+#undef G2_SYNC
+
+    // ---- epilogue.  acc[i][j][r]: row = m0 + wm*128 + i*16 + fq*4 + r, col = n0 + wn*64 + j*16 + frow
+    const int row_base = m0 + wm * 128 + fq * 4;
+    const int col_base = n0 + wn * 64 + frow;
+    int epi = p.epi;
+    if (epi == EPI_QKV_MLP) epi = (n0 >= p.n_split) ? EPI_SWIGLU : EPI_BF16;
+
+    if (epi == EPI_F32) {
+        float* C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row_base + i * 16 + r;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = col_base + j * 16;
+                        if (col < p.N) C[(size_t)row * p.ldc + col] = acc[i][j][r] * p.alpha;
+                    }
+                }
+            }
+    } else if (epi == EPI_BF16) {
+        uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row_base + i * 16 + r;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = col_base + j * 16;
+                        if (col < p.N) C[(size_t)row * p.ldc + col] = f32_to_bf16_bits(acc[i][j][r] * p.alpha);
+                    }
+                }
+            }
+    } else if (epi == EPI_GATE_RESID) {
+        float* C = reinterpret_cast<float*>(p.C);
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = col_base + j * 16;
+            g[j] = (col < p.N) ? p.vec[col] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row_base + i * 16 + r;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = col_base + j * 16;
+                        if (col < p.N) {
+                            float* dst = C + (size_t)row * p.ldc + col;
+                            *dst = *dst + g[j] * acc[i][j][r];
+                        }
+                    }
+                }
+            }
+    } else if (epi == EPI_SWIGLU) {
+        uint16_t* C = reinterpret_cast<uint16_t*>(p.C2);
+        const int start = (p.epi == EPI_QKV_MLP) ? p.n_split : 0;
+        const int hbase = ((n0 + wn * 64 - start) >> 1) + frow;
+        const int hidden = (p.N - start) >> 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row_base + i * 16 + r;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int h = hbase + j * 16;
+                        if (h < hidden) {
+                            const float gate = acc[i][j][r], val = acc[i][j + 2][r];
+                            C[(size_t)row * p.ldc2 + h] = f32_to_bf16_bits(silu_f(gate) * val);
+                        }
+                    }
+                }
+            }
+    } else {  // EPI_BIAS_BF16
+        uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+        float bsv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = col_base + j * 16;
+            bsv[j] = (p.vec != nullptr && col < p.N) ? p.vec[col] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row_base + i * 16 + r;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = col_base + j * 16;
+                        if (col < p.N) {
+                            float v = acc[i][j][r] * p.alpha + bsv[j];
+                            if (p.resid) v += bf16_bits_to_f32(p.resid[(size_t)row * p.ldr + col]);
+                            C[(size_t)row * p.ldc + col] = f32_to_bf16_bits(v);
+                        }
+                    }
+                }
+            }
+    }
+}
+
+}  // namespace
+
+// returns 0 ok / 2 launch error; the caller has validated the problems
+int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
+    GemmBatch b;
+    b.nprob = nprob;
+    int tiles[2] = {0, 0};
+    for (int i = 0; i < nprob; ++i) {
+        b.p[i] = probs[i];
+        tiles[i] = ((probs[i].M + BM2 - 1) / BM2) * ((probs[i].N + BN2 - 1) / BN2);
+    }
+    if (nprob == 1) b.p[1] = probs[0];
+    b.tile_start1 = tiles[0];
+    static const int stagger = [] {
+        const char* e = getenv("FLUX2MI_GEMM_STAGGER");
+        return e ? atoi(e) : 1;
+    }();
+    static const int abl = [] {
+        const char* e = getenv("FLUX2MI_GEMM_ABLATE");
+        return e ? atoi(e) : 0;
+    }();
+    const dim3 grid(tiles[0] + tiles[1]), block(512);
+    if (abl == 1) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 1>), grid, block, 0, stream, b);
+    else if (abl == 2) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 2>), grid, block, 0, stream, b);
+    else if (abl == 3) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 3>), grid, block, 0, stream, b);
+    else if (stagger) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0>), grid, block, 0, stream, b);
+    else hipLaunchKernelGGL((gemm_bf16_256x256_kernel<false, 0>), grid, block, 0, stream, b);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}

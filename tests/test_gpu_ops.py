@@ -101,3 +101,47 @@ def test_latent_layout_ops(ctx):
     assert rel_l2(z, zr) < 1e-6
     packed = ctx.vae_latents_to_packed(z, mean.cuda(), var.cuda())
     assert rel_l2(packed, seq) < 1e-5
+
+
+def test_gemm_256_tile_kernel_forced_on_ragged_shapes():
+    """The 256x256 LDS-DMA kernel (gemm256.hip) on ragged / small shapes: forced through
+    FLUX2MI_GEMM=256 in a child process (the selector is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+import flux2mi
+from flux2mi.api import Context
+ctx = Context(0)
+worst = 0.0
+for (M, N, K) in [(256, 256, 64), (300, 520, 128), (80, 256, 192), (1000, 777, 448), (513, 1024, 3072), (2560, 2560, 256)]:
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn((M, K), generator=g).to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g) * 0.05).to(torch.bfloat16)
+    out = ctx.op_gemm_bf16(a.cuda(), w.cuda()).cpu()
+    ref = a.float() @ w.float().t()
+    rel = float((out - ref).norm() / ref.norm())
+    worst = max(worst, rel)
+    assert rel < 2e-3, (M, N, K, rel)
+# asymmetric identity check (transposed C write would show)
+n = 256
+a = torch.eye(n).to(torch.bfloat16)
+w = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) %% 251 - 125).to(torch.bfloat16)
+assert torch.equal(ctx.op_gemm_bf16(a.cuda(), w.cuda()).cpu(), w.float().t())
+print("ok", worst)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FLUX2MI_GEMM="256")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_gemm_large_auto_dispatch(ctx):
+    """Large problem -> automatically takes the 256x256 kernel; exact-integer data, exact result."""
+    M, N, K = 2560, 2816, 512
+    g = torch.Generator().manual_seed(1)
+    a = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16)
+    w = torch.randint(-3, 4, (N, K), generator=g).to(torch.bfloat16)
+    out = ctx.op_gemm_bf16(a.cuda(), w.cuda()).cpu()
+    assert torch.equal(out, a.float() @ w.float().t())

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Microbenchmark of the GEMM kernels on the DiT's production shapes (random data), with
+hipBLASLt (torch.matmul) timed beside them as the vendor reference point.  Dev tool."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+import flux2mi
+from flux2mi.api import Context
+
+SHAPES = [  # (M, N, K, name)
+    (4608, 27648, 3072, "single.linear1"),
+    (4608, 3072, 12288, "single.linear2"),
+    (4608, 9216, 3072, "double.qkv"),
+    (4608, 3072, 3072, "double.proj"),
+    (4608, 18432, 3072, "double.mlp_in"),
+    (4608, 3072, 9216, "double.mlp_out"),
+    (4096, 4096, 4096, "square4k"),
+    (8192, 8192, 8192, "square8k"),
+]
+
+
+def time_fn(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    ctx = Context(0)
+    check = "--check" in sys.argv
+    print(f"FLUX2MI_GEMM={os.environ.get('FLUX2MI_GEMM', '(auto)')}")
+    for M, N, K, name in SHAPES:
+        a = torch.randn((M, K), device="cuda").to(torch.bfloat16)
+        w = (torch.randn((N, K), device="cuda") * 0.05).to(torch.bfloat16)
+        with torch.cuda.stream(ctx.stream):
+            ms = time_fn(lambda: ctx.op_gemm_bf16(a, w))
+        ms_t = time_fn(lambda: torch.matmul(a, w.t()))
+        fl = 2.0 * M * N * K
+        line = f"{name:16s} M{M} N{N} K{K}: ours {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF | hipBLASLt {ms_t:7.3f} ms {fl / ms_t / 1e9:7.1f} TF"
+        if check:
+            out = ctx.op_gemm_bf16(a, w)
+            ref = torch.matmul(a.float(), w.float().t())
+            line += f" | rel {float((out - ref).norm() / ref.norm()):.2e}"
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
