@@ -124,7 +124,7 @@ def main():
     avg_ms = prof_ms / max(n_launch, 1)
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     peak = 2500.0  # TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md chip table)
-    roofline = {"bound": "mfma", "kernel": "gemm_bf16_128x128_kernel (single_blocks.linear1)",
+    roofline = {"bound": "mfma", "kernel": "gemm_bf16_256x256_kernel (single_blocks.linear1: [S,d] x [9d,d]^T, fused qkv store + SwiGLU)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": None,
                 "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),

@@ -113,42 +113,49 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
             }
         }
 
-        // ---- online softmax (base-2), per query = per lane pair (lane, lane^32)
-        float mx = -INFINITY;
+        // ---- online softmax (base-2), per query = per lane pair (lane, lane^32).
+        // VALU budget matters as much as MFMA here (the wave issues both in order): the raw
+        // scores are only max-reduced; scale and running max go into one fma per element in
+        // front of exp2; O and l are rescaled only when some lane's running max grew (exact:
+        // alpha == 1 otherwise), which after the first tiles is rare.
         const bool tail = (kt + 1) * BKV > S;
+        if (tail) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s = sa[kb][r] * scale_log2e;
-                if (tail) {
+                for (int r = 0; r < 16; ++r) {
                     const int key = kt * BKV + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= S) s = -INFINITY;
+                    if (key >= S) sa[kb][r] = -INFINITY;
                 }
-                sa[kb][r] = s;
-                mx = fmaxf(mx, s);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        }
+        float mx = fmaxf(sa[0][0], sa[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sa[0][r], sa[1][r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2e;     // scale > 0 commutes with max
+        if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {   // wave-uniform branch
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
         float rs = 0.f;
         bf16x8 pf[2][2];
+        const float neg_m = -m_run;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float pv = __builtin_amdgcn_exp2f(sa[kb][s2 * 8 + j] - m_new);
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[kb][s2 * 8 + j], scale_log2e, neg_m));
                     rs += pv;
                     pf[kb][s2][j] = (__bf16)pv;
                 }
-        l_run = l_run * alpha + rs;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        l_run += rs;
 
         // ---- O^T += V^T P^T  (A = V^T rows d, B = P^T)
 #pragma unroll

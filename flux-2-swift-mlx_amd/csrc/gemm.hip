@@ -29,6 +29,8 @@
 #include <stdlib.h>
 
 int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob);
+int launch_gemm256_w4(hipStream_t stream, const GemmProblem* probs, int nprob);
+int launch_gemm256_r4(hipStream_t stream, const GemmProblem* probs, int nprob);
 
 namespace {
 
@@ -306,7 +308,13 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
         for (int i = 0; i < nprob; ++i)
             tiles256 += (long)((probs[i].M + 255) / 256) * ((probs[i].N + 255) / 256);
         const bool big = tiles256 >= 100;
-        if (force == 256 || (force != 128 && big)) return launch_gemm256(stream, probs, nprob);
+        static const int ver = [] {
+            const char* e = getenv("FLUX2MI_GEMM_V");
+            return e ? atoi(e) : 2;
+        }();
+        if (force == 256 || (force != 128 && big))
+            return ver == 4 ? launch_gemm256_r4(stream, probs, nprob)
+                 : ver == 3 ? launch_gemm256_w4(stream, probs, nprob) : launch_gemm256(stream, probs, nprob);
     }
     GemmBatch b;
     b.nprob = nprob;

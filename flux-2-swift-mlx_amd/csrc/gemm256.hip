@@ -167,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         const uint8_t* st = smem;
         G2_READ_B(b0, KIND_B0) G2_READ_B(b1, KIND_B1) G2_READ_A(KIND_A0)
     }
-#define G2_ISSUE_L(k_, u_) if (!(ABL & 2)) G2_ISSUE(k_, u_)
+#define G2_ISSUE_L(k_, u_) if (ABL == 4) G2_ISSUE(k_, ((u_) < nk ? ((u_) & 1) : nk)) else if (!(ABL & 2)) G2_ISSUE(k_, u_)
 #define G2_READ_A_L(s_) if (!(ABL & 1)) { G2_READ_A(s_) }
 #define G2_READ_B_L(d_, s_) if (!(ABL & 1)) { G2_READ_B(d_, s_) }
     for (int kt = 0; kt < nk; ++kt) {
@@ -341,6 +341,7 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
     if (abl == 1) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 1>), grid, block, 0, stream, b);
     else if (abl == 2) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 2>), grid, block, 0, stream, b);
     else if (abl == 3) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 3>), grid, block, 0, stream, b);
+    else if (abl == 4) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 4>), grid, block, 0, stream, b);
     else if (stagger) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0>), grid, block, 0, stream, b);
     else hipLaunchKernelGGL((gemm_bf16_256x256_kernel<false, 0>), grid, block, 0, stream, b);
     return hipGetLastError() == hipSuccess ? 0 : 2;
