@@ -140,7 +140,7 @@ def main():
         cpu_baseline = run_cpu_baseline(P, cfg, syn)
 
     out = {
-        "metric": "denoise-steps/sec (Flux.2 Klein-4B 1024x1024 @ 28 steps; seconds/image reported alongside)",
+        "metric": f"denoise-steps/sec (Flux.2 {args.model} {H}x{W} @ {T} steps; seconds/image reported alongside)",
         "value": round(value, 4),
         "unit": "denoise-steps/s",
         "n_gpus": world,

@@ -134,19 +134,34 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_256x256_r4_kernel(GemmBatch 
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i_][j_]) : "v"(fa_[i_]), "v"(fb_[j_]));
     // group g = the 8 MFMAs of accumulator row g with at most ONE other instruction per MFMA gap:
     // 2 fragment prefetches, 1 LDS write of data(s+2), 1 global load of data(s+4) (same staging register).
-#define W4_GROUP(RD, WR, LD, fc_a, fc_b, fn_a, fn_b, g_, st_, voff_, sb_, woff_)   \
+#define W4_GROUP_W(RD, WR, fc_a, fc_b, fn_a, fn_b, g_, stx_, woffx_, sty_, woffy_)   \
     W4_M(fc_a, fc_b, g_, 0)                                                \
     if (RD) W4_DSR(fn_a[g_], ha, g_ * 1024)                                \
     W4_M(fc_a, fc_b, g_, 1)                                                \
     if (RD) W4_DSR(fn_b[g_], hb, g_ * 1024)                                \
     W4_M(fc_a, fc_b, g_, 2)                                                \
-    if (WR) R4_DSW(wa, st_, woff_)                                         \
+    if (WR) R4_DSW(wa, stx_, woffx_)                                       \
     W4_M(fc_a, fc_b, g_, 3)                                                \
-    if (LD) R4_GLOAD(st_, voff_, sb_)                                      \
     W4_M(fc_a, fc_b, g_, 4)                                                \
+    if (WR) R4_DSW(wa, sty_, woffy_)                                       \
     W4_M(fc_a, fc_b, g_, 5)                                                \
     W4_M(fc_a, fc_b, g_, 6)                                                \
     W4_M(fc_a, fc_b, g_, 7)
+#define W4_GROUP_L(RD, LD, fc_a, fc_b, fn_a, fn_b, g_, stx_, voffx_, sbx_, sty_, voffy_, sby_)   \
+    W4_M(fc_a, fc_b, g_, 0)                                                \
+    if (RD) W4_DSR(fn_a[g_], ha, g_ * 1024)                                \
+    W4_M(fc_a, fc_b, g_, 1)                                                \
+    if (RD) W4_DSR(fn_b[g_], hb, g_ * 1024)                                \
+    W4_M(fc_a, fc_b, g_, 2)                                                \
+    if (LD) R4_GLOAD(stx_, voffx_, sbx_)                                   \
+    W4_M(fc_a, fc_b, g_, 3)                                                \
+    W4_M(fc_a, fc_b, g_, 4)                                                \
+    if (LD) R4_GLOAD(sty_, voffy_, sby_)                                   \
+    W4_M(fc_a, fc_b, g_, 5)                                                \
+    W4_M(fc_a, fc_b, g_, 6)                                                \
+    W4_M(fc_a, fc_b, g_, 7)
+    // the 8 LDS writes go in the first half of the sub-step (retired long before the next TOP's
+    // lgkmcnt(0)), the 8 global loads that refill the same staging registers in the second half
 #define W4_BODY(RD, WR, LD, fc_a, fc_b, fn_a, fn_b, stA_, stW_, s_)                           \
     {                                                                                         \
         const int sb__ = (s_);                                                                \
@@ -155,14 +170,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_256x256_r4_kernel(GemmBatch 
         const uint32_t wa = wr_addr + (uint32_t)(((sb__ + 2) & 3) * HS_BYTES);                \
         const uint8_t* sa = gA + (size_t)(sb__ + 4) * (KS * 2);                               \
         const uint8_t* sw = gW + (size_t)(sb__ + 4) * (KS * 2);                               \
-        W4_GROUP(RD, WR, LD, fc_a, fc_b, fn_a, fn_b, 0, stA_[0], voffA[0], sa, 0)                     \
-        W4_GROUP(RD, WR, LD, fc_a, fc_b, fn_a, fn_b, 1, stW_[0], voffW[0], sw, PART_BYTES)            \
-        W4_GROUP(RD, WR, LD, fc_a, fc_b, fn_a, fn_b, 2, stA_[1], voffA[1], sa, 1024)                  \
-        W4_GROUP(RD, WR, LD, fc_a, fc_b, fn_a, fn_b, 3, stW_[1], voffW[1], sw, PART_BYTES + 1024)     \
-        W4_GROUP(RD, WR, LD, fc_a, fc_b, fn_a, fn_b, 4, stA_[2], voffA[2], sa, 2048)                  \
-        W4_GROUP(RD, WR, LD, fc_a, fc_b, fn_a, fn_b, 5, stW_[2], voffW[2], sw, PART_BYTES + 2048)     \
-        W4_GROUP(RD, WR, LD, fc_a, fc_b, fn_a, fn_b, 6, stA_[3], voffA[3], sa, 3072)                  \
-        W4_GROUP(RD, WR, LD, fc_a, fc_b, fn_a, fn_b, 7, stW_[3], voffW[3], sw, PART_BYTES + 3072)     \
+        W4_GROUP_W(RD, WR, fc_a, fc_b, fn_a, fn_b, 0, stA_[0], 0, stW_[0], PART_BYTES)                  \
+        W4_GROUP_W(RD, WR, fc_a, fc_b, fn_a, fn_b, 1, stA_[1], 1024, stW_[1], PART_BYTES + 1024)        \
+        W4_GROUP_W(RD, WR, fc_a, fc_b, fn_a, fn_b, 2, stA_[2], 2048, stW_[2], PART_BYTES + 2048)        \
+        W4_GROUP_W(RD, WR, fc_a, fc_b, fn_a, fn_b, 3, stA_[3], 3072, stW_[3], PART_BYTES + 3072)        \
+        W4_GROUP_L(RD, LD, fc_a, fc_b, fn_a, fn_b, 4, stA_[0], voffA[0], sa, stW_[0], voffW[0], sw)     \
+        W4_GROUP_L(RD, LD, fc_a, fc_b, fn_a, fn_b, 5, stA_[1], voffA[1], sa, stW_[1], voffW[1], sw)     \
+        W4_GROUP_L(RD, LD, fc_a, fc_b, fn_a, fn_b, 6, stA_[2], voffA[2], sa, stW_[2], voffW[2], sw)     \
+        W4_GROUP_L(RD, LD, fc_a, fc_b, fn_a, fn_b, 7, stA_[3], voffA[3], sa, stW_[3], voffW[3], sw)     \
     }
 #define W4_TOP(N_)                                                                 \
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(" #N_ ")" ::: "memory");  \
@@ -212,7 +227,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_256x256_r4_kernel(GemmBatch 
 #undef R4_WRITE_ALL
 #undef W4_DSR
 #undef W4_M
-#undef W4_GROUP
+#undef W4_GROUP_W
+#undef W4_GROUP_L
 #undef W4_BODY
 #undef W4_TOP
 

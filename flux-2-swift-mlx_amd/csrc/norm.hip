@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void layernorm_modulate_kernel(const float* __
 }
 
 // ------------------------------------------------------------------ QK RMSNorm + RoPE (in place)
-// One wave per (row, head, q|k) vector of 128: lane owns the RoPE pair (2*lane, 2*lane+1).
+// 16 lanes per (row, head, q|k) vector of 128: a lane owns 8 consecutive elements = 4 RoPE
+// pairs (16-B accesses); a wave handles 4 vectors, a workgroup 16.  Sum of squares by a
+// 4-step xor-shuffle inside each 16-lane group.
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(uint16_t* __restrict__ qkv, int ldqkv, int S, int heads,
                                                            int split, const uint16_t* __restrict__ qs0,
                                                            const uint16_t* __restrict__ ks0,
@@ -85,27 +87,48 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(uint16_t* __restrict_
                                                            const uint16_t* __restrict__ ks1,
                                                            const float* __restrict__ cos_tab,
                                                            const float* __restrict__ sin_tab) {
-    const int lane = threadIdx.x & 63;
-    const long vec = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // ((row*2 + which)*heads + head)
+    const int sub = threadIdx.x & 15;
+    const long vec = (long)blockIdx.x * 16 + (threadIdx.x >> 4);  // ((row*2 + which)*heads + head)
     const long total = (long)S * 2 * heads;
-    if (vec >= total) return;
-    const int head = (int)(vec % heads);
-    const int which = (int)((vec / heads) & 1);
-    const int row = (int)(vec / (2 * heads));
-    uint16_t* p = qkv + (size_t)row * ldqkv + which * heads * 128 + head * 128 + lane * 2;
-    const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
-    const float x0 = lo_bf16(u), x1 = hi_bf16(u);
-    const float ss = wave_sum(x0 * x0 + x1 * x1);
+    const bool live = vec < total;
+    const long v = live ? vec : total - 1;
+    const int head = (int)(v % heads);
+    const int which = (int)((v / heads) & 1);
+    const int row = (int)(v / (2 * heads));
+    uint16_t* p = qkv + (size_t)row * ldqkv + which * heads * 128 + head * 128 + sub * 8;
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    float x[8] = {lo_bf16(u.x), hi_bf16(u.x), lo_bf16(u.y), hi_bf16(u.y),
+                  lo_bf16(u.z), hi_bf16(u.z), lo_bf16(u.w), hi_bf16(u.w)};
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     const float r = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
     const uint16_t* sc = (row < split) ? (which ? ks0 : qs0) : (which ? ks1 : qs1);
-    const uint32_t su = *reinterpret_cast<const uint32_t*>(sc + lane * 2);
-    const float n0 = x0 * r * lo_bf16(su), n1 = x1 * r * hi_bf16(su);
-    const float2 c = *reinterpret_cast<const float2*>(cos_tab + (size_t)row * 128 + lane * 2);
-    const float2 s = *reinterpret_cast<const float2*>(sin_tab + (size_t)row * 128 + lane * 2);
-    // x*cos + rotate_half(x)*sin with rotate_half = (-x1, x0)
-    const float o0 = n0 * c.x - n1 * s.x;
-    const float o1 = n1 * c.y + n0 * s.y;
-    *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(o0, o1);
+    const uint4 su = *reinterpret_cast<const uint4*>(sc + sub * 8);
+    const float w[8] = {lo_bf16(su.x), hi_bf16(su.x), lo_bf16(su.y), hi_bf16(su.y),
+                        lo_bf16(su.z), hi_bf16(su.z), lo_bf16(su.w), hi_bf16(su.w)};
+    const float4 c0 = *reinterpret_cast<const float4*>(cos_tab + (size_t)row * 128 + sub * 8);
+    const float4 c1 = *reinterpret_cast<const float4*>(cos_tab + (size_t)row * 128 + sub * 8 + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(sin_tab + (size_t)row * 128 + sub * 8);
+    const float4 s1 = *reinterpret_cast<const float4*>(sin_tab + (size_t)row * 128 + sub * 8 + 4);
+    const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float n0 = x[2 * j] * r * w[2 * j], n1 = x[2 * j + 1] * r * w[2 * j + 1];
+        // x*cos + rotate_half(x)*sin with rotate_half = (-x1, x0)
+        o[2 * j] = n0 * cs[2 * j] - n1 * sn[2 * j];
+        o[2 * j + 1] = n1 * cs[2 * j + 1] + n0 * sn[2 * j + 1];
+    }
+    if (live) {
+        uint4 pk;
+        pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]);
+        pk.z = pack_bf16x2(o[4], o[5]); pk.w = pack_bf16x2(o[6], o[7]);
+        *reinterpret_cast<uint4*>(p) = pk;
+    }
 }
 
 // ------------------------------------------------------------------ V -> V^T (key-permuted)
@@ -189,7 +212,7 @@ int launch_qk_norm_rope_vt(hipStream_t stream, uint16_t* qkv, int ldqkv, int S, 
                            uint16_t* vt, int s_pad) {
     if (S <= 0 || heads <= 0 || (ldqkv & 7) || s_pad < attn_s_pad(S)) return 1;
     const long total = (long)S * 2 * heads;
-    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, qkv, ldqkv, S,
+    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, qkv, ldqkv, S,
                        heads, split, qscale0, kscale0, qscale1, kscale1, cos_tab, sin_tab);
     hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, heads), dim3(256), 0, stream, qkv, ldqkv, S, heads,
                        vt, s_pad);
