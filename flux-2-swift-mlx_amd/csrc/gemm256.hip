@@ -25,7 +25,9 @@
 //     The last two K-tiles wait vmcnt(0) (nothing younger is issued any more).
 #include "dev.h"
 #include "kernels.h"
+#include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 
 namespace {
 
@@ -57,7 +59,7 @@ __device__ __forceinline__ void tile_coords256(int local, int ntiles, int tiles_
 // on each SIMD instead of both reading, then both computing (MI355X guide, "Two waves per
 // SIMD" item 9).  Data published by LDS-DMA is then only guaranteed one phase later for the
 // leading group, hence vmcnt(8) instead of vmcnt(10).
-template <bool STAGGER, int ABL>  // ABL: timing-only ablations (1 = no LDS reads in loop, 2 = no DMA in loop, 3 = both)
+template <bool STAGGER, int ABL, bool HALFBAR = false, bool DIAG = false>  // ABL: timing-only ablations (1 = no LDS reads in loop, 2 = no DMA in loop, 3 = both)
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch batch) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE2_BYTES];  // 128 KB, the ONLY LDS object
 
@@ -138,6 +140,27 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
                 acc[(mh_) * 4 + i_][(nh_) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(          \
                     a[i_][kk_], bsrc_[j_][kk_], acc[(mh_) * 4 + i_][(nh_) * 2 + j_], 0, 0, 0);           \
     __builtin_amdgcn_s_setprio(0);
+    // DIAG: timing-only build (FLUX2MI_GEMM_DIAG=1): s_memtime stamps around the four segments of a
+    // phase, summed per wave and written to p.C2 (a debug buffer no kernel reads); never shipped.
+    unsigned long long dg_t = 0, dg_r = 0, dg_w1 = 0, dg_m = 0, dg_w2 = 0, dg_dma = 0, dg_rd = 0;
+#define G2_STAMP(acc_)                                                                          \
+    if (DIAG) {                                                                                 \
+        unsigned long long n__;                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n__)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        acc_ += n__ - dg_t;                                                                     \
+        dg_t = n__;                                                                             \
+    }
+#define G2_STAMP_NW(acc_)                                                                       \
+    if (DIAG) {                                                                                 \
+        unsigned long long n__;                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n__)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        acc_ += n__ - dg_t;                                                                     \
+        dg_t = n__;                                                                             \
+    }
 #define G2_SYNC()                        \
     asm volatile("" ::: "memory");       \
     __builtin_amdgcn_s_barrier();        \
@@ -145,14 +168,56 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
 #define G2_READS_DONE()                                          \
     if (STAGGER) {                                               \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        G2_STAMP(dg_r)                                           \
         G2_SYNC()                                                \
+        G2_STAMP(dg_w1)                                          \
     }
 #define G2_PHASE_END()                                                          \
-    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
+    if (ABL & 8) {}                                                             \
+    else if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            \
     else if (STAGGER) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          \
     else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                      \
-    G2_SYNC()
+    G2_STAMP(dg_m)                                                              \
+    G2_SYNC()                                                                   \
+    G2_STAMP(dg_w2)
 
+    const int wm_u = __builtin_amdgcn_readfirstlane(wid) >> 2;  // provably wave-uniform
+#define G2_ISSUE_L(k_, u_) if (ABL == 4) G2_ISSUE(k_, ((u_) < nk ? ((u_) & 1) : nk)) else if (!(ABL & 2)) G2_ISSUE(k_, u_)
+#define G2_READ_A_L(s_) if (!(ABL & 1)) { G2_READ_A(s_) }
+#define G2_READ_B_L(d_, s_) if (!(ABL & 1)) { G2_READ_B(d_, s_) }
+    if (HALFBAR) {
+        // Variant with TWO barriers per K-tile (after phases 1 and 3), lockstep waves.  A slot may
+        // only be refilled after a barrier that follows its last read, so phase phi issues element
+        // phi + 6:  p0 -> B1(t+1), p1 -> A1(t+1), p2 -> A0(t+2), p3 -> B0(t+2); vmcnt(6) before each
+        // barrier leaves the 3 youngest half-tiles in flight.
+        G2_ISSUE(KIND_A0, 0) G2_ISSUE(KIND_B0, 0) G2_ISSUE(KIND_B1, 0) G2_ISSUE(KIND_A1, 0)
+        G2_ISSUE(KIND_A0, 1) G2_ISSUE(KIND_B0, 1)
+        if (nk < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        G2_SYNC()
+        for (int kt = 0; kt < nk; ++kt) {
+            const uint8_t* st = smem + (kt & 1) * STAGE2_BYTES;
+            const bool drain = kt + 2 >= nk;
+            G2_ISSUE_L(KIND_B1, kt + 1)
+            G2_READ_B_L(b0, KIND_B0)
+            G2_READ_A_L(KIND_A0)
+            G2_MFMA(0, 0, b0)
+            G2_ISSUE_L(KIND_A1, kt + 1)
+            G2_READ_B_L(b1, KIND_B1)
+            G2_MFMA(0, 1, b1)
+            if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            G2_SYNC()
+            G2_ISSUE_L(KIND_A0, kt + 2)
+            G2_READ_A_L(KIND_A1)
+            G2_MFMA(1, 1, b1)
+            G2_ISSUE_L(KIND_B0, kt + 2)
+            G2_MFMA(1, 0, b0)
+            if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            G2_SYNC()
+        }
+    } else {
     // ---- prologue: elements 0..6 = K-tile 0 (A0,B0,B1,A1) + K-tile 1 (A0,B0,B1)
     G2_ISSUE(KIND_A0, 0) G2_ISSUE(KIND_B0, 0) G2_ISSUE(KIND_B1, 0) G2_ISSUE(KIND_A1, 0)
     G2_ISSUE(KIND_A0, 1) G2_ISSUE(KIND_B0, 1) G2_ISSUE(KIND_B1, 1)
@@ -160,21 +225,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         const bool drain = nk < 3;
         G2_PHASE_END()
     }
-    const int wm_u = __builtin_amdgcn_readfirstlane(wid) >> 2;  // provably wave-uniform
     if (STAGGER && wm_u == 1) { G2_SYNC() }
 
     if (ABL & 1) {  // operands read once; wrong results by design
         const uint8_t* st = smem;
         G2_READ_B(b0, KIND_B0) G2_READ_B(b1, KIND_B1) G2_READ_A(KIND_A0)
     }
-#define G2_ISSUE_L(k_, u_) if (ABL == 4) G2_ISSUE(k_, ((u_) < nk ? ((u_) & 1) : nk)) else if (!(ABL & 2)) G2_ISSUE(k_, u_)
-#define G2_READ_A_L(s_) if (!(ABL & 1)) { G2_READ_A(s_) }
-#define G2_READ_B_L(d_, s_) if (!(ABL & 1)) { G2_READ_B(d_, s_) }
+    if (DIAG) { unsigned long long z__ = 0; G2_STAMP(z__) dg_r = dg_w1 = dg_m = dg_w2 = dg_dma = dg_rd = z__ * 0; }
     for (int kt = 0; kt < nk; ++kt) {
         const uint8_t* st = smem + (kt & 1) * STAGE2_BYTES;
         const bool drain = kt + 2 >= nk;
         // phase 0: issue A1(kt+1); consume A0, B0 -> quadrant (m0, n0)
         G2_ISSUE_L(KIND_A1, kt + 1)
+        G2_STAMP_NW(dg_dma)
         G2_READ_B_L(b0, KIND_B0)
         G2_READ_A_L(KIND_A0)
         G2_READS_DONE()
@@ -182,23 +245,31 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         G2_PHASE_END()
         // phase 1: issue A0(kt+2); consume B1 -> (m0, n1)
         G2_ISSUE_L(KIND_A0, kt + 2)
+        G2_STAMP_NW(dg_dma)
         G2_READ_B_L(b1, KIND_B1)
         G2_READS_DONE()
         G2_MFMA(0, 1, b1)
         G2_PHASE_END()
         // phase 2: issue B0(kt+2); consume A1 -> (m1, n1)
         G2_ISSUE_L(KIND_B0, kt + 2)
+        G2_STAMP_NW(dg_dma)
         G2_READ_A_L(KIND_A1)
         G2_READS_DONE()
         G2_MFMA(1, 1, b1)
         G2_PHASE_END()
         // phase 3: issue B1(kt+2); b0 still in registers -> (m1, n0)
         G2_ISSUE_L(KIND_B1, kt + 2)
+        G2_STAMP_NW(dg_dma)
         G2_READS_DONE()
         G2_MFMA(1, 0, b0)
         G2_PHASE_END()
     }
+    }
     if (STAGGER && wm_u == 0) { G2_SYNC() }
+    if (DIAG && p.C2 != nullptr && lane == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.C2) + ((size_t)blockIdx.x * 8 + wid) * 4;
+        dbg[0] = dg_r; dbg[1] = dg_w1; dbg[2] = dg_m; dbg[3] = dg_w2 + (dg_dma << 32);
+    }
 #undef G2_ISSUE
 #undef G2_READ_A
 #undef G2_READ_B
@@ -206,6 +277,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
 #undef G2_PHASE_END
 #undef G2_READS_DONE
 #undef G2_SYNC
+#undef G2_STAMP
 
     // ---- epilogue.  acc[i][j][r]: row = m0 + wm*128 + i*16 + fq*4 + r, col = n0 + wn*64 + j*16 + frow
     const int row_base = m0 + wm * 128 + fq * 4;
@@ -329,19 +401,52 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
     }
     if (nprob == 1) b.p[1] = probs[0];
     b.tile_start1 = tiles[0];
-    static const int stagger = [] {
-        const char* e = getenv("FLUX2MI_GEMM_STAGGER");
-        return e ? atoi(e) : 1;
-    }();
+
     static const int abl = [] {
         const char* e = getenv("FLUX2MI_GEMM_ABLATE");
         return e ? atoi(e) : 0;
     }();
+    static const int stagger = [] {
+        const char* e = getenv("FLUX2MI_GEMM_STAGGER");
+        return e ? atoi(e) : 1;
+    }();
     const dim3 grid(tiles[0] + tiles[1]), block(512);
+    static const int diag = [] {
+        const char* e = getenv("FLUX2MI_GEMM_DIAG");
+        return e ? atoi(e) : 0;
+    }();
+    if (diag && nprob == 1 && probs[0].epi == EPI_F32) {
+        // segment-share diagnostic: per-wave cycle sums for (reads+DMA issue, barrier 1, MFMA+vmcnt, barrier 2)
+        static unsigned long long* dbg = nullptr;
+        const size_t n = (size_t)grid.x * 8 * 4;
+        if (!dbg) (void)hipMalloc((void**)&dbg, 4096 * 8 * 4 * 8);
+        if (dbg && grid.x <= 4096) {
+            b.p[0].C2 = dbg;
+            (void)hipMemsetAsync(dbg, 0, n * 8, stream);
+            if (abl == 8) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 8, false, true>), grid, block, 0, stream, b);
+            else hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, true>), grid, block, 0, stream, b);
+            std::vector<unsigned long long> h(n);
+            (void)hipMemcpyAsync(h.data(), dbg, n * 8, hipMemcpyDeviceToHost, stream);
+            (void)hipStreamSynchronize(stream);
+            double s[2][4] = {{0}};
+            for (size_t w = 0; w < (size_t)grid.x * 8; ++w)
+                for (int k = 0; k < 4; ++k) s[(w & 7) >> 2][k] += (double)(k == 3 ? (h[w * 4 + k] & 0xffffffffull) : h[w * 4 + k]);
+            double dma[2] = {0, 0};
+            for (size_t w = 0; w < (size_t)grid.x * 8; ++w) dma[(w & 7) >> 2] += (double)(h[w * 4 + 3] >> 32);
+            const double nw = (double)grid.x * 4;
+            const int nkt = probs[0].K / 64;
+            for (int g = 0; g < 2; ++g)
+                fprintf(stderr, "[gemm diag] group %d per K-tile cycles: dma-issue %.0f  reads+lgkm-wait %.0f  barrier1 %.0f  mfma+vmcnt %.0f  barrier2 %.0f  (total %.0f)\n", g,
+                        dma[g] / nw / nkt, s[g][0] / nw / nkt, s[g][1] / nw / nkt, s[g][2] / nw / nkt, s[g][3] / nw / nkt,
+                        (s[g][0] + s[g][1] + s[g][2] + s[g][3]) / nw / nkt);
+            return 0;
+        }
+    }
     if (abl == 1) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 1>), grid, block, 0, stream, b);
     else if (abl == 2) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 2>), grid, block, 0, stream, b);
     else if (abl == 3) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 3>), grid, block, 0, stream, b);
     else if (abl == 4) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 4>), grid, block, 0, stream, b);
+    else if (stagger == 2) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<false, 0, true>), grid, block, 0, stream, b);
     else if (stagger) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0>), grid, block, 0, stream, b);
     else hipLaunchKernelGGL((gemm_bf16_256x256_kernel<false, 0>), grid, block, 0, stream, b);
     return hipGetLastError() == hipSuccess ? 0 : 2;
