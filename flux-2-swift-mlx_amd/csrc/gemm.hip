@@ -31,6 +31,7 @@
 int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob);
 int launch_gemm256_w4(hipStream_t stream, const GemmProblem* probs, int nprob);
 int launch_gemm256_r4(hipStream_t stream, const GemmProblem* probs, int nprob);
+int launch_gemm_ws(hipStream_t stream, const GemmProblem* probs, int nprob);
 
 namespace {
 
@@ -313,7 +314,8 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
             return e ? atoi(e) : 2;
         }();
         if (force == 256 || (force != 128 && big))
-            return ver == 4 ? launch_gemm256_r4(stream, probs, nprob)
+            return ver == 5 ? launch_gemm_ws(stream, probs, nprob)
+                 : ver == 4 ? launch_gemm256_r4(stream, probs, nprob)
                  : ver == 3 ? launch_gemm256_w4(stream, probs, nprob) : launch_gemm256(stream, probs, nprob);
     }
     GemmBatch b;

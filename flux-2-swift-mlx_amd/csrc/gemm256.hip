@@ -59,6 +59,7 @@ __device__ __forceinline__ void tile_coords256(int local, int ntiles, int tiles_
 // on each SIMD instead of both reading, then both computing (MI355X guide, "Two waves per
 // SIMD" item 9).  Data published by LDS-DMA is then only guaranteed one phase later for the
 // leading group, hence vmcnt(8) instead of vmcnt(10).
+// ABL bits (timing only): 1 no fragment reads, 2 no DMA, 4 DMA from an L2-resident source, 8 no vmcnt waits, 16 no MFMA
 template <bool STAGGER, int ABL, bool HALFBAR = false, bool DIAG = false>  // ABL: timing-only ablations (1 = no LDS reads in loop, 2 = no DMA in loop, 3 = both)
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch batch) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE2_BYTES];  // 128 KB, the ONLY LDS object
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     }
 #define G2_MFMA(mh_, nh_, bsrc_)                                                                         \
     __builtin_amdgcn_s_setprio(1);                                                                       \
+    if (!(ABL & 16))                                                                                     \
     _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                                  \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                 \
             _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                             \
@@ -446,6 +448,7 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
     else if (abl == 2) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 2>), grid, block, 0, stream, b);
     else if (abl == 3) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 3>), grid, block, 0, stream, b);
     else if (abl == 4) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 4>), grid, block, 0, stream, b);
+    else if (abl == 17) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 17>), grid, block, 0, stream, b);
     else if (stagger == 2) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<false, 0, true>), grid, block, 0, stream, b);
     else if (stagger) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0>), grid, block, 0, stream, b);
     else hipLaunchKernelGGL((gemm_bf16_256x256_kernel<false, 0>), grid, block, 0, stream, b);
