@@ -38,8 +38,9 @@ def test_t2i_and_repaint_vs_golden(tiny):
     from flux2mi.pipeline import Flux2MaskedInpaintingChain
     g = np.load("tests/golden/tiny_dit.npz")
     t = tiny
-    res = t["pipe"].generate_text_to_image(height=128, width=128, steps=4, precomputed_embeddings=t["inp"]["txt"],
-                                           noise=t["inp"]["noise"], return_latents=True)
+    res = t["pipe"].generate_with_result("textToImage", height=128, width=128, steps=4,
+                                         precomputed_embeddings=t["inp"]["txt"], noise=t["inp"]["noise"],
+                                         return_latents=True)
     assert _rel(res.latents[0].cpu().numpy(), g["t2i_final_latents"]) < 3e-2
     assert np.abs(res.image.astype(int) - g["t2i_image"].astype(int)).mean() < 3.0
     gen = torch.Generator().manual_seed(99)
