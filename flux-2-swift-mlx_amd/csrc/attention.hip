@@ -65,11 +65,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
         v_lds[i] = K_TILE_BYTES + vr * 128 + ((vc ^ ((vr >> 1) & 7)) << 4);
     }
     u32x4 kreg[4], vreg[4];
+    // K rows are addressed by a per-thread pointer that advances one tile per iteration; only a
+    // tile that reaches past S (the last one) pays for the row clamp.
+    const uint16_t* k_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k_src[i] = kbase + (size_t)min(k_row[i], S - 1) * ldqk + k_chunk[i] * 8;
+    const size_t k_step = (size_t)BKV * ldqk;
 #define ATTN_LOAD_TILE(kt_)                                                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
-        const int kr_ = min((kt_) * BKV + k_row[i_], S - 1);                                             \
-        kreg[i_] = *reinterpret_cast<const u32x4*>(kbase + (size_t)kr_ * ldqk + k_chunk[i_] * 8);        \
-        vreg[i_] = *reinterpret_cast<const u32x4*>(v_src[i_] + (kt_) * BKV);                             \
+    if (((kt_) + 1) * BKV <= S) {                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                               \
+            kreg[i_] = *reinterpret_cast<const u32x4*>(k_src[i_] + (size_t)(kt_) * k_step);              \
+            vreg[i_] = *reinterpret_cast<const u32x4*>(v_src[i_] + (kt_) * BKV);                         \
+        }                                                                                                \
+    } else {                                                                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                               \
+            const int kr_ = min((kt_) * BKV + k_row[i_], S - 1);                                         \
+            kreg[i_] = *reinterpret_cast<const u32x4*>(kbase + (size_t)kr_ * ldqk + k_chunk[i_] * 8);    \
+            vreg[i_] = *reinterpret_cast<const u32x4*>(v_src[i_] + (kt_) * BKV);                         \
+        }                                                                                                \
     }
 #define ATTN_STORE_TILE(buf_)                                                                            \
     {                                                                                                    \
@@ -102,12 +115,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
         f32x16 sa[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sa[kb][r] = 0.f;
             const int row = kb * 32 + l31;
             const uint8_t* rp = sk + row * 256;
+            {   // k-step 0 starts the chain from an inline-constant zero accumulator (no 16 v_mov)
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(rp + (((0 * 2 + hi) ^ (row & 15)) << 4));
+                sa[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], f32x16{}, 0, 0, 0);
+            }
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
+            for (int ks = 1; ks < 8; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(rp + (((ks * 2 + hi) ^ (row & 15)) << 4));
                 sa[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sa[kb], 0, 0, 0);
             }
@@ -128,9 +143,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
                     if (key >= S) sa[kb][r] = -INFINITY;
                 }
         }
-        float mx = fmaxf(sa[0][0], sa[1][0]);
+        // 32 scores -> 16 x v_max3_f32 (asm: hipcc would put a canonicalising v_max in front of
+        // every fmaxf that reads an MFMA result)
+        float mx;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(sa[0][0]), "v"(sa[0][1]), "v"(sa[1][0]));
+        asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(sa[1][1]), "v"(sa[0][2]));
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sa[0][r], sa[1][r]));
+        for (int r = 3; r < 16; r += 2) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(sa[0][r]), "v"(sa[0][r + (r < 15 ? 1 : 0)]));
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(sa[1][r]), "v"(sa[1][r + 1]));
         mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2e;     // scale > 0 commutes with max
         if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {   // wave-uniform branch
             const float m_new = fmaxf(m_run, mx);
