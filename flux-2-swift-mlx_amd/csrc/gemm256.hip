@@ -200,18 +200,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         for (int kt = 0; kt < nk; ++kt) {
             const uint8_t* st = smem + (kt & 1) * STAGE2_BYTES;
             const bool drain = kt + 2 >= nk;
-            G2_ISSUE_L(KIND_B1, kt + 1)
             G2_READ_B_L(b0, KIND_B0)
             G2_READ_A_L(KIND_A0)
+            G2_READ_B_L(b1, KIND_B1)
+            G2_ISSUE_L(KIND_B1, kt + 1)
             G2_MFMA(0, 0, b0)
             G2_ISSUE_L(KIND_A1, kt + 1)
-            G2_READ_B_L(b1, KIND_B1)
             G2_MFMA(0, 1, b1)
             if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             G2_SYNC()
-            G2_ISSUE_L(KIND_A0, kt + 2)
             G2_READ_A_L(KIND_A1)
+            G2_ISSUE_L(KIND_A0, kt + 2)
             G2_MFMA(1, 1, b1)
             G2_ISSUE_L(KIND_B0, kt + 2)
             G2_MFMA(1, 0, b0)
@@ -238,24 +238,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         const uint8_t* st = smem + (kt & 1) * STAGE2_BYTES;
         const bool drain = kt + 2 >= nk;
         // phase 0: issue A1(kt+1); consume A0, B0 -> quadrant (m0, n0)
+        G2_READ_B_L(b0, KIND_B0)      // fragment reads first: their LDS latency runs under the DMA queue wait
+        G2_READ_A_L(KIND_A0)
         G2_ISSUE_L(KIND_A1, kt + 1)
         G2_STAMP_NW(dg_dma)
-        G2_READ_B_L(b0, KIND_B0)
-        G2_READ_A_L(KIND_A0)
         G2_READS_DONE()
         G2_MFMA(0, 0, b0)
         G2_PHASE_END()
         // phase 1: issue A0(kt+2); consume B1 -> (m0, n1)
+        G2_READ_B_L(b1, KIND_B1)
         G2_ISSUE_L(KIND_A0, kt + 2)
         G2_STAMP_NW(dg_dma)
-        G2_READ_B_L(b1, KIND_B1)
         G2_READS_DONE()
         G2_MFMA(0, 1, b1)
         G2_PHASE_END()
         // phase 2: issue B0(kt+2); consume A1 -> (m1, n1)
+        G2_READ_A_L(KIND_A1)
         G2_ISSUE_L(KIND_B0, kt + 2)
         G2_STAMP_NW(dg_dma)
-        G2_READ_A_L(KIND_A1)
         G2_READS_DONE()
         G2_MFMA(1, 1, b1)
         G2_PHASE_END()
