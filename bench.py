@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--denoise-steps", type=int, default=28)
     ap.add_argument("--vae", default="standard", choices=["standard", "small"])
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
+                    help="transformer block-GEMM format; the headline (BASELINE.json configs[1]) is bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-class", type=int, default=0, help="kernel class timed with HIP events (0 = linear1 GEMM)")
     args = ap.parse_args()
@@ -63,7 +65,7 @@ def main():
 
     # ---- model: synthetic weights generated on the GPU, replicated per rank
     t0 = time.time()
-    pipe = Flux2Pipeline(model=args.model, vae_variant=args.vae, device=dev_index)
+    pipe = Flux2Pipeline(model=args.model, vae_variant=args.vae, device=dev_index, quantization=args.weights)
     P = syn.make_dit_weights(cfg, seed=1234, device=dev)
     VP = syn.make_vae_weights(vcfg, seed=4321, device=dev)
     pipe.load_models(P, VP)
@@ -123,7 +125,8 @@ def main():
     flops_per_launch = prof_flops / max(n_launch, 1)
     avg_ms = prof_ms / max(n_launch, 1)
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-    peak = 2500.0  # TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md chip table)
+    # TFLOP/s dense MFMA, MI355X_MICROARCH.md chip table: bf16 2500, fp8 5000
+    peak = 5000.0 if args.weights == "fp8" else 2500.0
     roofline = {"bound": "mfma", "kernel": "gemm_bf16_256x256_kernel (single_blocks.linear1: [S,d] x [9d,d]^T, fused qkv store + SwiGLU)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": None,
@@ -150,9 +153,9 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16",
+        "dtype": "bf16" if args.weights == "bf16" else "fp8 (e4m3 block GEMMs; bf16 attention, f32 residual)",
         "data": "synthetic",
-        "config": {"workload": f"Flux.2 {args.model} bf16, {H}x{W}, {T} denoise steps + {args.vae} VAE decode + D2H, "
+        "config": {"workload": f"Flux.2 {args.model} {args.weights}, {H}x{W}, {T} denoise steps + {args.vae} VAE decode + D2H, "
                                f"1 image per GPU per bench step (BASELINE.json configs[1])",
                    "images_per_bench_step": world, "s_txt": s_txt, "s_img": s_img, "parallelism": f"dp{world}"},
         "seconds_per_image": round(sec_per_image, 4),

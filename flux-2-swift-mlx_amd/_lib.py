@@ -27,7 +27,7 @@ F32, BF16, F16 = 0, 1, 2
 
 class DitConfig(C.Structure):
     _fields_ = [("dim", C.c_int), ("heads", C.c_int), ("n_double", C.c_int), ("n_single", C.c_int),
-                ("joint_dim", C.c_int), ("guidance_embeds", C.c_int)]
+                ("joint_dim", C.c_int), ("guidance_embeds", C.c_int), ("weight_format", C.c_int)]
 
 
 class VaeConfig(C.Structure):
@@ -109,6 +109,7 @@ PROTOTYPES = {
     "flux2mi_prof_begin": (_I, [_P, _I]),
     "flux2mi_prof_end": (_I, [_P, _PI, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "flux2mi_op_gemm_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I]),
+    "flux2mi_op_gemm_fp8": (_I, [_P, _P, _P, _P, _I, _I, _I]),
     "flux2mi_op_attention": (_I, [_P, _P, _P, _I, _I]),
 }
 

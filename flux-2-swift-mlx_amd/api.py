@@ -205,6 +205,16 @@ class Context:
         self._exit()
         return out
 
+    def op_gemm_fp8(self, a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        a, w = _req(a, torch.bfloat16, "A"), _req(w, torch.bfloat16, "W")
+        m, k = a.shape
+        n = w.shape[0]
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+        self._enter()
+        check(lib().flux2mi_op_gemm_fp8(self.handle, _ptr(a), _ptr(w), _ptr(out), m, n, k))
+        self._exit()
+        return out
+
     def op_attention(self, qkv: torch.Tensor, heads: int) -> torch.Tensor:
         qkv = _req(qkv, torch.bfloat16, "qkv")
         s = qkv.shape[0]
@@ -227,8 +237,13 @@ def _set_tensors(fn, handle, tensors: Dict[str, torch.Tensor]):
 class DiT:
     """Flux2Transformer2DModel (flux2mi_dit)."""
 
-    def __init__(self, ctx: Context, config):
+    def __init__(self, ctx: Context, config, weights: str = "bf16"):
+        """`weights`: "bf16" (default) or "fp8" — e4m3 block-GEMM weights + per-token fp8 activations
+        (the MI355X counterpart of the reference's quantised transformer variants,
+        Configuration/QuantizationConfig.swift:40-73)."""
         self.ctx = ctx
+        if weights not in ("bf16", "fp8"):
+            raise ValueError(f"weights must be 'bf16' or 'fp8', got {weights!r}")
         cfg = L.DitConfig()
         if isinstance(config, str):
             check(lib().flux2mi_dit_preset(config.encode(), C.byref(cfg)))
@@ -236,6 +251,7 @@ class DiT:
             cfg.dim, cfg.heads = config["dim"], config["heads"]
             cfg.n_double, cfg.n_single = config["n_double"], config["n_single"]
             cfg.joint_dim, cfg.guidance_embeds = config["joint_dim"], int(bool(config["guidance"]))
+        cfg.weight_format = 1 if weights == "fp8" else 0
         self.cfg = cfg
         h = C.c_void_p()
         check(lib().flux2mi_dit_create(ctx.handle, C.byref(cfg), C.byref(h)))

@@ -21,6 +21,16 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float lo_bf16(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float hi_bf16(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
+// OCP e4m3 pack of 4 floats (already divided by the scale); clamped to +-448 (the cast has no saturation)
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

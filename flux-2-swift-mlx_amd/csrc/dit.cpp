@@ -10,6 +10,10 @@
 //   comb  bf16 [S, 4d]     single blocks: attention output (cols 0..d) | SwiGLU hidden (d..4d)
 //                          double blocks: attention output [S,d] (ld d) and FF hidden [S,3d]
 //   mods  f32              temb, per-stream (shift,scale,gate) vectors, final (shift,scale)
+// weight_format 1 (fp8): the block GEMM weights (qkv, proj, mlp, linear1/2) are e4m3 bytes with a
+// f32 scale per output channel; their A operands are e4m3 too, quantised per token:
+//   xq    e4m3 [S, 4d] + xs f32 [S]   LN+modulate output / quantised comb rows
+// Embedders, modulation GEMVs and proj_out stay bf16.
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -33,7 +37,10 @@ struct Slot {
 };
 
 struct Buf {
-    uint16_t* ptr = nullptr;
+    uint16_t* ptr = nullptr;  // bf16 [rows, cols]; nullptr for an fp8 buffer
+    uint8_t* q = nullptr;     // weight_format 1: e4m3 [rows, cols]
+    float* scale = nullptr;   //                  per output channel (row) scale
+    bool fp8 = false;
     int rows = 0, cols = 0;
     int got_rows = 0;
     std::string label;
@@ -53,22 +60,24 @@ struct flux2mi_dit {
     uint16_t *img_in = nullptr, *txt_in = nullptr, *time_in = nullptr, *time_out = nullptr;
     uint16_t *guid_in = nullptr, *guid_out = nullptr;
     uint16_t *mod_img = nullptr, *mod_txt = nullptr, *mod_single = nullptr, *final_mod = nullptr, *final_lin = nullptr;
-    struct Dbl { uint16_t *qkv[2], *proj[2], *qn[2], *kn[2], *mlp_in[2], *mlp_out[2]; };  // [0]=txt, [1]=img
-    struct Sgl { uint16_t *lin1, *lin2, *qn, *kn; };
+    struct W { const uint16_t* w = nullptr; const float* scale = nullptr; };  // bf16 pointer, or e4m3 bytes + scales
+    struct Dbl { W qkv[2], proj[2], mlp_in[2], mlp_out[2]; uint16_t *qn[2], *kn[2]; };  // [0]=txt, [1]=img
+    struct Sgl { W lin1, lin2; uint16_t *qn, *kn; };
     std::vector<Dbl> dbl;
     std::vector<Sgl> sgl;
 
     // staging for ingestion
-    DevBuf stage_raw, stage_bf16;
+    DevBuf stage_raw, stage_bf16, stage_w;
     // forward workspace
-    DevBuf hs, xn, qkv, vt, comb, mods, rope, lat_bf16;
+    DevBuf hs, xn, qkv, vt, comb, mods, rope, lat_bf16, xq, xs;
     int ws_S = 0;
 };
 
 namespace {
 
-int add_buf(flux2mi_dit* m, int rows, int cols, const std::string& label) {
+int add_buf(flux2mi_dit* m, int rows, int cols, const std::string& label, bool gemm_weight = false) {
     Buf b;
+    b.fp8 = gemm_weight && m->cfg.weight_format == 1;
     b.rows = rows;
     b.cols = cols;
     b.label = label;
@@ -83,8 +92,8 @@ void add_slot(flux2mi_dit* m, const std::string& name, int buf, int row_off, int
 void build_registry(flux2mi_dit* m) {
     const int d = m->cfg.dim, J = m->cfg.joint_dim;
     auto simple = [&](int rows, int cols, const std::string& label, std::initializer_list<const char*> names,
-                      int transform = T_DIRECT) {
-        const int b = add_buf(m, rows, cols, label);
+                      int transform = T_DIRECT, bool gemm_weight = false) {
+        const int b = add_buf(m, rows, cols, label, gemm_weight);
         for (const char* n : names) add_slot(m, n, b, 0, rows, cols, transform);
         return b;
     };
@@ -117,7 +126,7 @@ void build_registry(flux2mi_dit* m) {
             const char* bs = s ? "img" : "txt";
             // fused qkv [3d, d]
             snprintf(a, sizeof a, "dbl%d.%s.qkv", i, bs);
-            const int bq = add_buf(m, 3 * d, d, a);
+            const int bq = add_buf(m, 3 * d, d, a, true);
             snprintf(a, sizeof a, "double_blocks.%d.%s_attn.qkv.weight", i, bs);
             add_slot(m, a, bq, 0, 3 * d, d, T_DIRECT);
             const char* dq[3] = {s ? "to_q" : "add_q_proj", s ? "to_k" : "add_k_proj", s ? "to_v" : "add_v_proj"};
@@ -127,7 +136,7 @@ void build_registry(flux2mi_dit* m) {
             }
             snprintf(a, sizeof a, "double_blocks.%d.%s_attn.proj.weight", i, bs);
             snprintf(c, sizeof c, "transformer_blocks.%d.attn.%s.weight", i, s ? "to_out.0" : "to_add_out");
-            simple(d, d, a, {a, c});
+            simple(d, d, a, {a, c}, T_DIRECT, true);
             snprintf(a, sizeof a, "double_blocks.%d.%s_attn.norm.query_norm.scale", i, bs);
             snprintf(c, sizeof c, "transformer_blocks.%d.attn.%s.weight", i, s ? "norm_q" : "norm_added_q");
             simple(1, 128, a, {a, c});
@@ -136,19 +145,19 @@ void build_registry(flux2mi_dit* m) {
             simple(1, 128, a, {a, c});
             snprintf(a, sizeof a, "double_blocks.%d.%s_mlp.0.weight", i, bs);
             snprintf(c, sizeof c, "transformer_blocks.%d.%s.linear_in.weight", i, s ? "ff" : "ff_context");
-            simple(6 * d, d, a, {a, c}, T_SWIGLU);
+            simple(6 * d, d, a, {a, c}, T_SWIGLU, true);
             snprintf(a, sizeof a, "double_blocks.%d.%s_mlp.2.weight", i, bs);
             snprintf(c, sizeof c, "transformer_blocks.%d.%s.linear_out.weight", i, s ? "ff" : "ff_context");
-            simple(d, 3 * d, a, {a, c});
+            simple(d, 3 * d, a, {a, c}, T_DIRECT, true);
         }
     }
     for (int i = 0; i < m->cfg.n_single; ++i) {
         snprintf(a, sizeof a, "single_blocks.%d.linear1.weight", i);
         snprintf(c, sizeof c, "single_transformer_blocks.%d.attn.to_qkv_mlp_proj.weight", i);
-        simple(9 * d, d, a, {a, c}, T_LINEAR1);
+        simple(9 * d, d, a, {a, c}, T_LINEAR1, true);
         snprintf(a, sizeof a, "single_blocks.%d.linear2.weight", i);
         snprintf(c, sizeof c, "single_transformer_blocks.%d.attn.to_out.weight", i);
-        simple(d, 4 * d, a, {a, c});
+        simple(d, 4 * d, a, {a, c}, T_DIRECT, true);
         snprintf(a, sizeof a, "single_blocks.%d.norm.query_norm.scale", i);
         snprintf(c, sizeof c, "single_transformer_blocks.%d.attn.norm_q.weight", i);
         simple(1, 128, a, {a, c});
@@ -162,6 +171,15 @@ uint16_t* buf_by_label(flux2mi_dit* m, const std::string& label) {
     for (Buf& b : m->bufs)
         if (b.label == label) return b.ptr;
     return nullptr;
+}
+flux2mi_dit::W weight_by_label(flux2mi_dit* m, const std::string& label) {
+    flux2mi_dit::W w;
+    for (Buf& b : m->bufs)
+        if (b.label == label) {
+            w.w = b.fp8 ? reinterpret_cast<const uint16_t*>(b.q) : b.ptr;
+            w.scale = b.scale;
+        }
+    return w;
 }
 
 size_t dtype_size(int dtype) { return dtype == FLUX2MI_F32 ? 4 : 2; }
@@ -187,14 +205,22 @@ extern "C" int flux2mi_dit_create(flux2mi_ctx* ctx, const flux2mi_dit_config* cf
                    cfg->n_single >= 0 && cfg->joint_dim > 0 && cfg->joint_dim % 64 == 0,
                FLUX2MI_ERR_INVALID_ARG, "dit_create: invalid config (dim %d heads %d joint %d)", cfg->dim, cfg->heads,
                cfg->joint_dim);
+    F2_REQUIRE(cfg->weight_format == 0 || cfg->weight_format == 1, FLUX2MI_ERR_UNSUPPORTED,
+               "dit_create: weight_format %d (0 = bf16, 1 = fp8 e4m3)", cfg->weight_format);
+    F2_REQUIRE(cfg->weight_format == 0 || cfg->dim % 256 == 0, FLUX2MI_ERR_UNSUPPORTED,
+               "dit_create: fp8 needs dim %% 256 == 0 (dim %d)", cfg->dim);
     F2_CHECK_HIP(hipSetDevice(ctx->device));
     flux2mi_dit* m = new flux2mi_dit();
     m->ctx = ctx;
     m->cfg = *cfg;
     build_registry(m);
     for (Buf& b : m->bufs) {
-        const size_t bytes = (size_t)b.rows * b.cols * 2;
-        hipError_t e = hipMalloc((void**)&b.ptr, bytes);
+        const size_t bytes = b.fp8 ? (size_t)b.rows * b.cols : (size_t)b.rows * b.cols * 2;
+        hipError_t e = b.fp8 ? hipMalloc((void**)&b.q, bytes) : hipMalloc((void**)&b.ptr, bytes);
+        if (e == hipSuccess && b.fp8) {
+            e = hipMalloc((void**)&b.scale, (size_t)b.rows * 4);
+            m->param_bytes += (int64_t)b.rows * 4;
+        }
         if (e != hipSuccess) {
             flux2mi_set_error("dit_create: hipMalloc(%zu) for %s failed: %s", bytes, b.label.c_str(),
                               hipGetErrorString(e));
@@ -211,10 +237,13 @@ extern "C" int flux2mi_dit_destroy(flux2mi_dit* m) {
     if (!m) return FLUX2MI_OK;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
-    for (Buf& b : m->bufs)
+    for (Buf& b : m->bufs) {
         if (b.ptr) (void)hipFree(b.ptr);
-    DevBuf* ws[] = {&m->stage_raw, &m->stage_bf16, &m->hs, &m->xn, &m->qkv, &m->vt, &m->comb, &m->mods, &m->rope,
-                    &m->lat_bf16};
+        if (b.q) (void)hipFree(b.q);
+        if (b.scale) (void)hipFree(b.scale);
+    }
+    DevBuf* ws[] = {&m->stage_raw, &m->stage_bf16, &m->stage_w, &m->hs, &m->xn, &m->qkv, &m->vt, &m->comb, &m->mods,
+                    &m->rope, &m->lat_bf16, &m->xq, &m->xs};
     for (DevBuf* w : ws) w->release();
     delete m;
     return FLUX2MI_OK;
@@ -255,8 +284,31 @@ extern "C" int flux2mi_dit_set_tensor(flux2mi_dit* m, const char* name, int dtyp
         F2_LAUNCH(launch_convert_to_bf16(st, m->stage_raw.ptr, dtype, m->stage_bf16.as<uint16_t>(), n), "convert_to_bf16");
         src = m->stage_bf16.as<uint16_t>();
     }
-    // 3. place with the layout transform
+    // 3. place with the layout transform.  An fp8 buffer gets the same row layout: the transform
+    // runs into a bf16 staging copy and the rows are then quantised (scale = row amax / 448).
     const size_t row_bytes = (size_t)cols * 2;
+    if (b.fp8) {
+        const uint16_t* rows_src = src;
+        if (s.transform == T_SWIGLU || s.transform == T_LINEAR1) {
+            F2_TRY(m->stage_w.reserve((size_t)n * 2));
+            uint16_t* w = m->stage_w.as<uint16_t>();
+            if (s.transform == T_SWIGLU) {
+                F2_LAUNCH(launch_swiglu_interleave_rows(st, src, w, (int)(rows / 2), (int)cols), "swiglu_interleave");
+            } else {
+                const int d = m->cfg.dim;
+                F2_CHECK_HIP(hipMemcpyAsync(w, src, (size_t)3 * d * row_bytes, hipMemcpyDeviceToDevice, st));
+                F2_LAUNCH(launch_swiglu_interleave_rows(st, src + (size_t)3 * d * cols, w + (size_t)3 * d * cols, 3 * d,
+                                                        (int)cols),
+                          "swiglu_interleave(linear1)");
+            }
+            rows_src = w;
+        } else {
+            F2_REQUIRE(s.transform == T_DIRECT, FLUX2MI_ERR_UNSUPPORTED, "dit_set_tensor(%s): transform on fp8 buffer", name);
+        }
+        F2_LAUNCH(launch_quantize_rows_fp8(st, rows_src, (int)cols, b.q + (size_t)s.row_off * cols, (int)cols,
+                                           b.scale + s.row_off, (int)rows, (int)cols),
+                  "quantize weight rows");
+    } else
     switch (s.transform) {
         case T_DIRECT:
             F2_CHECK_HIP(hipMemcpyAsync(b.ptr + (size_t)s.row_off * cols, src, (size_t)rows * row_bytes,
@@ -312,24 +364,24 @@ extern "C" int flux2mi_dit_finalize(flux2mi_dit* m) {
         for (int s = 0; s < 2; ++s) {
             const char* bs = s ? "img" : "txt";
             snprintf(a, sizeof a, "dbl%d.%s.qkv", i, bs);
-            m->dbl[i].qkv[s] = buf_by_label(m, a);
+            m->dbl[i].qkv[s] = weight_by_label(m, a);
             snprintf(a, sizeof a, "double_blocks.%d.%s_attn.proj.weight", i, bs);
-            m->dbl[i].proj[s] = buf_by_label(m, a);
+            m->dbl[i].proj[s] = weight_by_label(m, a);
             snprintf(a, sizeof a, "double_blocks.%d.%s_attn.norm.query_norm.scale", i, bs);
             m->dbl[i].qn[s] = buf_by_label(m, a);
             snprintf(a, sizeof a, "double_blocks.%d.%s_attn.norm.key_norm.scale", i, bs);
             m->dbl[i].kn[s] = buf_by_label(m, a);
             snprintf(a, sizeof a, "double_blocks.%d.%s_mlp.0.weight", i, bs);
-            m->dbl[i].mlp_in[s] = buf_by_label(m, a);
+            m->dbl[i].mlp_in[s] = weight_by_label(m, a);
             snprintf(a, sizeof a, "double_blocks.%d.%s_mlp.2.weight", i, bs);
-            m->dbl[i].mlp_out[s] = buf_by_label(m, a);
+            m->dbl[i].mlp_out[s] = weight_by_label(m, a);
         }
     m->sgl.resize(m->cfg.n_single);
     for (int i = 0; i < m->cfg.n_single; ++i) {
         snprintf(a, sizeof a, "single_blocks.%d.linear1.weight", i);
-        m->sgl[i].lin1 = buf_by_label(m, a);
+        m->sgl[i].lin1 = weight_by_label(m, a);
         snprintf(a, sizeof a, "single_blocks.%d.linear2.weight", i);
-        m->sgl[i].lin2 = buf_by_label(m, a);
+        m->sgl[i].lin2 = weight_by_label(m, a);
         snprintf(a, sizeof a, "single_blocks.%d.norm.query_norm.scale", i);
         m->sgl[i].qn = buf_by_label(m, a);
         snprintf(a, sizeof a, "single_blocks.%d.norm.key_norm.scale", i);
@@ -337,6 +389,7 @@ extern "C" int flux2mi_dit_finalize(flux2mi_dit* m) {
     }
     m->stage_raw.release();
     m->stage_bf16.release();
+    m->stage_w.release();
     m->finalized = true;
     return FLUX2MI_OK;
 }
@@ -359,6 +412,10 @@ int ensure_workspace(flux2mi_dit* m, int S, int s_img) {
     F2_TRY(m->mods.reserve((size_t)(256 + 2 * d + 6 * d + 6 * d + 3 * d + 2 * d) * 4));
     F2_TRY(m->rope.reserve(Sz * 128 * 4 * 2));
     F2_TRY(m->lat_bf16.reserve((size_t)s_img * 128 * 2));
+    if (m->cfg.weight_format == 1) {
+        F2_TRY(m->xq.reserve(Sz * 4 * d));
+        F2_TRY(m->xs.reserve(Sz * 4));
+    }
     m->ws_S = S;
     return FLUX2MI_OK;
 }
@@ -440,16 +497,43 @@ extern "C" int flux2mi_dit_forward(flux2mi_dit* m, const float* latents, int s_i
         F2_TRY(run_gemm(m, p, 2, 0, "embedders"));
     }
 
+    // fp8 mode: the block GEMMs read their A operand from xq (e4m3, same [row, ld] layout as the
+    // bf16 buffer it shadows) with one scale per token in xs.
+    const bool f8 = m->cfg.weight_format == 1;
+    uint8_t* xq = f8 ? m->xq.as<uint8_t>() : nullptr;
+    float* xs = f8 ? m->xs.as<float>() : nullptr;
+    using W = flux2mi_dit::W;
+    // rows [r0, r0+M) of the bf16 activation `a` (row stride ld) times weight w
+    auto blk = [&](const uint16_t* a, int ld, int r0, const W& w, void* C, int ldc, int M, int N, int K, int epi) {
+        GemmProblem p;
+        if (f8) {
+            p = mk(reinterpret_cast<const uint16_t*>(xq + (size_t)r0 * ld), ld, w.w, K, C, ldc, M, N, K, epi);
+            p.fp8 = 1;
+            p.a_scale = xs + r0;
+            p.w_scale = w.scale;
+        } else {
+            p = mk(a + (size_t)r0 * ld, ld, w.w, K, C, ldc, M, N, K, epi);
+        }
+        return p;
+    };
+    auto ln_mod = [&](int split, const float* sh0, const float* sc0, const float* sh1, const float* sc1) {
+        return f8 ? launch_layernorm_modulate_fp8(st, hs, xq, xs, S, d, split, sh0, sc0, sh1, sc1)
+                  : launch_layernorm_modulate(st, hs, xn, S, d, split, sh0, sc0, sh1, sc1);
+    };
+    // quantise rows of a bf16 activation into xq/xs before the GEMM that consumes it (fp8 only)
+    auto quant = [&](const uint16_t* a, int ld, int cols) {
+        return f8 ? launch_quantize_rows_fp8(st, a, ld, xq, ld, xs, S, cols) : 0;
+    };
+
     // ---- double-stream blocks (Flux2TransformerBlock.swift:80-168)
     for (int i = 0; i < m->cfg.n_double; ++i) {
         const flux2mi_dit::Dbl& w = m->dbl[i];
         // attention half: LN -> modulate(set 0) per stream
-        F2_LAUNCH(launch_layernorm_modulate(st, hs, xn, S, d, s_txt, mod_txt + 0 * d, mod_txt + 1 * d, mod_img + 0 * d,
-                                            mod_img + 1 * d), "ln_mod(attn)");
+        F2_LAUNCH(ln_mod(s_txt, mod_txt + 0 * d, mod_txt + 1 * d, mod_img + 0 * d, mod_img + 1 * d), "ln_mod(attn)");
         {
             GemmProblem p[2];
-            p[0] = mk(xn, d, w.qkv[0], d, qkv, 3 * d, s_txt, 3 * d, d, EPI_BF16);
-            p[1] = mk(xn + (size_t)s_txt * d, d, w.qkv[1], d, qkv + (size_t)s_txt * 3 * d, 3 * d, s_img, 3 * d, d, EPI_BF16);
+            p[0] = blk(xn, d, 0, w.qkv[0], qkv, 3 * d, s_txt, 3 * d, d, EPI_BF16);
+            p[1] = blk(xn, d, s_txt, w.qkv[1], qkv + (size_t)s_txt * 3 * d, 3 * d, s_img, 3 * d, d, EPI_BF16);
             F2_TRY(run_gemm(m, p, 2, 0, "dbl.qkv"));
         }
         F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, s_txt, w.qn[0], w.kn[0], w.qn[1], w.kn[1], cos_tab, sin_tab,
@@ -458,31 +542,31 @@ extern "C" int flux2mi_dit_forward(flux2mi_dit* m, const float* latents, int s_i
         const int ar = launch_attention(st, qkv, qkv + d, 3 * d, vt, s_pad, comb, d, S, H);
         prof_after(m->ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
         F2_LAUNCH(ar, "attention");
+        F2_LAUNCH(quant(comb, d, d), "quantize(attn out)");
         {
             GemmProblem p[2];
-            p[0] = mk(comb, d, w.proj[0], d, hs, d, s_txt, d, d, EPI_GATE_RESID);
+            p[0] = blk(comb, d, 0, w.proj[0], hs, d, s_txt, d, d, EPI_GATE_RESID);
             p[0].vec = mod_txt + 2 * d;
-            p[1] = mk(comb + (size_t)s_txt * d, d, w.proj[1], d, hs + (size_t)s_txt * d, d, s_img, d, d, EPI_GATE_RESID);
+            p[1] = blk(comb, d, s_txt, w.proj[1], hs + (size_t)s_txt * d, d, s_img, d, d, EPI_GATE_RESID);
             p[1].vec = mod_img + 2 * d;
             F2_TRY(run_gemm(m, p, 2, 0, "dbl.proj"));
         }
         // feed-forward half: LN -> modulate(set 1) -> Linear(d->6d) SwiGLU -> Linear(3d->d)
-        F2_LAUNCH(launch_layernorm_modulate(st, hs, xn, S, d, s_txt, mod_txt + 3 * d, mod_txt + 4 * d, mod_img + 3 * d,
-                                            mod_img + 4 * d), "ln_mod(ff)");
+        F2_LAUNCH(ln_mod(s_txt, mod_txt + 3 * d, mod_txt + 4 * d, mod_img + 3 * d, mod_img + 4 * d), "ln_mod(ff)");
         {
             GemmProblem p[2];
-            p[0] = mk(xn, d, w.mlp_in[0], d, nullptr, 0, s_txt, 6 * d, d, EPI_SWIGLU);
+            p[0] = blk(xn, d, 0, w.mlp_in[0], nullptr, 0, s_txt, 6 * d, d, EPI_SWIGLU);
             p[0].C2 = comb; p[0].ldc2 = 3 * d;
-            p[1] = mk(xn + (size_t)s_txt * d, d, w.mlp_in[1], d, nullptr, 0, s_img, 6 * d, d, EPI_SWIGLU);
+            p[1] = blk(xn, d, s_txt, w.mlp_in[1], nullptr, 0, s_img, 6 * d, d, EPI_SWIGLU);
             p[1].C2 = comb + (size_t)s_txt * 3 * d; p[1].ldc2 = 3 * d;
             F2_TRY(run_gemm(m, p, 2, 0, "dbl.mlp_in"));
         }
+        F2_LAUNCH(quant(comb, 3 * d, 3 * d), "quantize(ff hidden)");
         {
             GemmProblem p[2];
-            p[0] = mk(comb, 3 * d, w.mlp_out[0], 3 * d, hs, d, s_txt, d, 3 * d, EPI_GATE_RESID);
+            p[0] = blk(comb, 3 * d, 0, w.mlp_out[0], hs, d, s_txt, d, 3 * d, EPI_GATE_RESID);
             p[0].vec = mod_txt + 5 * d;
-            p[1] = mk(comb + (size_t)s_txt * 3 * d, 3 * d, w.mlp_out[1], 3 * d, hs + (size_t)s_txt * d, d, s_img, d, 3 * d,
-                      EPI_GATE_RESID);
+            p[1] = blk(comb, 3 * d, s_txt, w.mlp_out[1], hs + (size_t)s_txt * d, d, s_img, d, 3 * d, EPI_GATE_RESID);
             p[1].vec = mod_img + 5 * d;
             F2_TRY(run_gemm(m, p, 2, 0, "dbl.mlp_out"));
         }
@@ -492,9 +576,9 @@ extern "C" int flux2mi_dit_forward(flux2mi_dit* m, const float* latents, int s_i
     // Flux2ParallelAttention.swift:72-123)
     for (int i = 0; i < m->cfg.n_single; ++i) {
         const flux2mi_dit::Sgl& w = m->sgl[i];
-        F2_LAUNCH(launch_layernorm_modulate(st, hs, xn, S, d, 0, mod_sgl, mod_sgl + d, mod_sgl, mod_sgl + d), "ln_mod(single)");
+        F2_LAUNCH(ln_mod(0, mod_sgl, mod_sgl + d, mod_sgl, mod_sgl + d), "ln_mod(single)");
         {
-            GemmProblem p = mk(xn, d, w.lin1, d, qkv, 3 * d, S, 9 * d, d, EPI_QKV_MLP);
+            GemmProblem p = blk(xn, d, 0, w.lin1, qkv, 3 * d, S, 9 * d, d, EPI_QKV_MLP);
             p.n_split = 3 * d;
             p.C2 = comb + d;  // SwiGLU hidden goes to columns d..4d of comb
             p.ldc2 = 4 * d;
@@ -506,8 +590,9 @@ extern "C" int flux2mi_dit_forward(flux2mi_dit* m, const float* latents, int s_i
         const int ar = launch_attention(st, qkv, qkv + d, 3 * d, vt, s_pad, comb, 4 * d, S, H);
         prof_after(m->ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
         F2_LAUNCH(ar, "attention");
+        F2_LAUNCH(quant(comb, 4 * d, 4 * d), "quantize(attn | ff hidden)");
         {
-            GemmProblem p = mk(comb, 4 * d, w.lin2, 4 * d, hs, d, S, d, 4 * d, EPI_GATE_RESID);
+            GemmProblem p = blk(comb, 4 * d, 0, w.lin2, hs, d, S, d, 4 * d, EPI_GATE_RESID);
             p.vec = mod_sgl + 2 * d;
             F2_TRY(run_gemm(m, &p, 1, 0, "single.linear2"));
         }
@@ -531,6 +616,25 @@ extern "C" int flux2mi_op_gemm_bf16(flux2mi_ctx* ctx, const void* A, const void*
     const int r = launch_gemm(ctx->stream, &p, 1);
     prof_after(ctx, PROF_DIT_GEMM, 2.0 * M * (double)N * K);
     F2_LAUNCH(r, "op_gemm");
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_op_gemm_fp8(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K) {
+    F2_REQUIRE(ctx && A && W && C && M > 0 && N > 0 && K > 0 && K % 128 == 0, FLUX2MI_ERR_INVALID_ARG, "op_gemm_fp8: bad argument");
+    const size_t need = (size_t)M * K + (size_t)N * K + ((size_t)M + N) * 4 + 1024;
+    F2_TRY(ctx->scratch.reserve(need));
+    uint8_t* aq = ctx->scratch.as<uint8_t>();
+    uint8_t* wq = aq + (((size_t)M * K + 255) & ~(size_t)255);
+    float* as = reinterpret_cast<float*>(wq + (((size_t)N * K + 255) & ~(size_t)255));
+    float* ws = as + M;
+    F2_LAUNCH(launch_quantize_rows_fp8(ctx->stream, reinterpret_cast<const uint16_t*>(A), K, aq, K, as, M, K), "quantize A");
+    F2_LAUNCH(launch_quantize_rows_fp8(ctx->stream, reinterpret_cast<const uint16_t*>(W), K, wq, K, ws, N, K), "quantize W");
+    GemmProblem p = mk(reinterpret_cast<const uint16_t*>(aq), K, reinterpret_cast<const uint16_t*>(wq), K, C, N, M, N, K, EPI_F32);
+    p.fp8 = 1; p.a_scale = as; p.w_scale = ws;
+    prof_before(ctx, PROF_DIT_GEMM);
+    const int r = launch_gemm(ctx->stream, &p, 1);
+    prof_after(ctx, PROF_DIT_GEMM, 2.0 * M * (double)N * K);
+    F2_LAUNCH(r, "op_gemm_fp8");
     return FLUX2MI_OK;
 }
 

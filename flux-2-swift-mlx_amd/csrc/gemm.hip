@@ -284,6 +284,17 @@ __global__ void gemm_naive_kernel(GemmProblem p) {
 int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
     if (nprob < 1 || nprob > 2) return 1;
     bool mfma_ok = true;
+    int n_fp8 = 0;
+    for (int i = 0; i < nprob; ++i) n_fp8 += probs[i].fp8 ? 1 : 0;
+    if (n_fp8) {  // e4m3 operands: only the 256x256 kernel, no fallbacks
+        if (n_fp8 != nprob) return 1;
+        for (int i = 0; i < nprob; ++i) {
+            const GemmProblem& p = probs[i];
+            if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.K % 128 != 0 || (p.lda & 15) || (p.ldw & 15) || !p.a_scale || !p.w_scale) return 1;
+            if ((p.epi == EPI_SWIGLU || p.epi == EPI_QKV_MLP) && (p.N % 64 != 0 || p.n_split % 256 != 0)) return 1;
+        }
+        return launch_gemm256(stream, probs, nprob);
+    }
     for (int i = 0; i < nprob; ++i) {
         const GemmProblem& p = probs[i];
         if (p.M <= 0 || p.N <= 0 || p.K <= 0) return 1;
@@ -308,7 +319,9 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
         long tiles256 = 0;
         for (int i = 0; i < nprob; ++i)
             tiles256 += (long)((probs[i].M + 255) / 256) * ((probs[i].N + 255) / 256);
-        const bool big = tiles256 >= 100;
+        bool big = tiles256 >= 100;
+        for (int i = 0; i < nprob; ++i)
+            if (probs[i].epi == EPI_QKV_MLP && probs[i].n_split % 256 != 0) big = false;  // a 256-wide tile must not straddle the split
         static const int ver = [] {
             const char* e = getenv("FLUX2MI_GEMM_V");
             return e ? atoi(e) : 2;

@@ -30,12 +30,16 @@
 #include <vector>
 
 namespace {
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 
 constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
 constexpr int SLOT_BYTES = 128 * BK2 * 2;      // 16 KB
 constexpr int STAGE2_BYTES = 4 * SLOT_BYTES;   // 64 KB
 enum { KIND_A0 = 0, KIND_B0 = 1, KIND_B1 = 2, KIND_A1 = 3 };
 
+typedef __attribute__((ext_vector_type(2))) long i64x2;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -60,7 +64,13 @@ __device__ __forceinline__ void tile_coords256(int local, int ntiles, int tiles_
 // SIMD" item 9).  Data published by LDS-DMA is then only guaranteed one phase later for the
 // leading group, hence vmcnt(8) instead of vmcnt(10).
 // ABL bits (timing only): 1 no fragment reads, 2 no DMA, 4 DMA from an L2-resident source, 8 no vmcnt waits, 16 no MFMA
-template <bool STAGGER, int ABL, bool HALFBAR = false, bool DIAG = false>  // ABL: timing-only ablations (1 = no LDS reads in loop, 2 = no DMA in loop, 3 = both)
+// FP8: operands are OCP e4m3 bytes.  The byte geometry of the tile is unchanged (128-B rows, so a
+// K-tile holds 128 k instead of 64); a lane's two 16-B fragment reads are the 32-byte operand of
+// ONE block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3, unit block scales), the form that
+// runs at twice the bf16 rate — the plain _fp8_fp8 16x16x32 runs at the bf16 rate.  Which k of
+// the tile lands on which operand byte is the same permutation for A and W, which a dot product
+// does not see.  The epilogue multiplies by a_scale[row] * w_scale[col].
+template <bool STAGGER, int ABL, bool HALFBAR = false, bool DIAG = false, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch batch) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE2_BYTES];  // 128 KB, the ONLY LDS object
 
@@ -80,20 +90,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     // ---- LDS-DMA source addresses: per kind, 2 instructions per thread.
     // instruction j of wave w fills slot bytes [(j*8+w)*1024, +1024): rows (j*8+w)*8 .. +8,
     // lane -> row + (lane>>3), LDS chunk c' = lane&7 holds global chunk c' ^ ((row>>1)&7).
-    const uint16_t* src[4][2];
+    constexpr int ES = FP8 ? 1 : 2;          // bytes per element
+    constexpr int TILE_K = 128 / ES;         // k per K-tile (a tile row is always 128 B)
+    const uint8_t* src[4][2];
+    const uint8_t* gA = reinterpret_cast<const uint8_t*>(p.A);
+    const uint8_t* gW = reinterpret_cast<const uint8_t*>(p.W);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int rho = (j * 8 + wid) * 8 + (lane >> 3);             // slot row 0..127
         const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
         const int a_row0 = (rho >> 6) * 128 + (rho & 63);            // A0: wave-row's first 64 rows
         const int b_row0 = (rho >> 5) * 64 + (rho & 31);             // B0: wave-col's first 32 rows
-        src[KIND_A0][j] = p.A + (size_t)min(m0 + a_row0, p.M - 1) * p.lda + chunk * 8;
-        src[KIND_A1][j] = p.A + (size_t)min(m0 + a_row0 + 64, p.M - 1) * p.lda + chunk * 8;
-        src[KIND_B0][j] = p.W + (size_t)min(n0 + b_row0, p.N - 1) * p.ldw + chunk * 8;
-        src[KIND_B1][j] = p.W + (size_t)min(n0 + b_row0 + 32, p.N - 1) * p.ldw + chunk * 8;
+        src[KIND_A0][j] = gA + (size_t)min(m0 + a_row0, p.M - 1) * p.lda * ES + chunk * 16;
+        src[KIND_A1][j] = gA + (size_t)min(m0 + a_row0 + 64, p.M - 1) * p.lda * ES + chunk * 16;
+        src[KIND_B0][j] = gW + (size_t)min(n0 + b_row0, p.N - 1) * p.ldw * ES + chunk * 16;
+        src[KIND_B1][j] = gW + (size_t)min(n0 + b_row0 + 32, p.N - 1) * p.ldw * ES + chunk * 16;
     }
     const int lds_wave = wid * 1024;  // + j*8192 + slot*SLOT_BYTES + stage*STAGE2_BYTES
-    const int nk = p.K / BK2;
+    const int nk = p.K / TILE_K;
     const int total_elems = nk * 4;
 
 #define G2_ISSUE(kind_, u_)                                                                                   \
@@ -101,8 +115,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         const int u__ = (u_);                                                                                 \
         if (u__ < nk) {                                                                                       \
             uint8_t* dst__ = smem + (u__ & 1) * STAGE2_BYTES + (kind_) * SLOT_BYTES + lds_wave;               \
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[kind_][0] + u__ * BK2), (lptr_t)(dst__), 16, 0, 0);      \
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[kind_][1] + u__ * BK2), (lptr_t)(dst__ + 8192), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[kind_][0] + u__ * 128), (lptr_t)(dst__), 16, 0, 0);      \
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[kind_][1] + u__ * 128), (lptr_t)(dst__ + 8192), 16, 0, 0); \
         }                                                                                                     \
     }
 
@@ -135,12 +149,28 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     }
 #define G2_MFMA(mh_, nh_, bsrc_)                                                                         \
     __builtin_amdgcn_s_setprio(1);                                                                       \
-    if (!(ABL & 16))                                                                                     \
-    _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                                  \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                 \
-            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                             \
-                acc[(mh_) * 4 + i_][(nh_) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(          \
-                    a[i_][kk_], bsrc_[j_][kk_], acc[(mh_) * 4 + i_][(nh_) * 2 + j_], 0, 0, 0);           \
+    if (!(ABL & 16)) {                                                                                   \
+        if (FP8) {                                                                                       \
+            /* one block-scaled 16x16x128 per (i, j): the lane's 32 bytes are its two 16-B chunks;  */   \
+            /* scales are e8m0 127 = 1.0 (the real scales are per row/column, applied in the epilogue) */ \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                           \
+                const i32x8 a8__ = __builtin_shufflevector(__builtin_bit_cast(i32x4, a[i_][0]),          \
+                                                           __builtin_bit_cast(i32x4, a[i_][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
+                _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                       \
+                    const i32x8 b8__ = __builtin_shufflevector(__builtin_bit_cast(i32x4, bsrc_[j_][0]),  \
+                                                               __builtin_bit_cast(i32x4, bsrc_[j_][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
+                    acc[(mh_) * 4 + i_][(nh_) * 2 + j_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4( \
+                        a8__, b8__, acc[(mh_) * 4 + i_][(nh_) * 2 + j_], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
+                }                                                                                        \
+            }                                                                                            \
+        } else {                                                                                         \
+            _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                          \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
+                    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                     \
+                        acc[(mh_) * 4 + i_][(nh_) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(  \
+                            a[i_][kk_], bsrc_[j_][kk_], acc[(mh_) * 4 + i_][(nh_) * 2 + j_], 0, 0, 0);   \
+        }                                                                                                \
+    }                                                                                                    \
     __builtin_amdgcn_s_setprio(0);
     // DIAG: timing-only build (FLUX2MI_GEMM_DIAG=1): s_memtime stamps around the four segments of a
     // phase, summed per wave and written to p.C2 (a debug buffer no kernel reads); never shipped.
@@ -286,6 +316,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     const int col_base = n0 + wn * 64 + frow;
     int epi = p.epi;
     if (epi == EPI_QKV_MLP) epi = (n0 >= p.n_split) ? EPI_SWIGLU : EPI_BF16;
+    if (FP8) {  // de-quantise: per-row activation scale x per-column weight scale
+        float ws[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ws[j] = p.w_scale[min(col_base + j * 16, p.N - 1)];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float as = p.a_scale[min(row_base + i * 16 + r, p.M - 1)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j][r] *= as * ws[j];
+            }
+    }
 
     if (epi == EPI_F32) {
         float* C = reinterpret_cast<float*>(p.C);
@@ -404,6 +447,11 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
     if (nprob == 1) b.p[1] = probs[0];
     b.tile_start1 = tiles[0];
 
+    const bool fp8 = probs[0].fp8 != 0;
+    if (fp8) {
+        hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, true>), dim3(tiles[0] + tiles[1]), dim3(512), 0, stream, b);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
     static const int abl = [] {
         const char* e = getenv("FLUX2MI_GEMM_ABLATE");
         return e ? atoi(e) : 0;

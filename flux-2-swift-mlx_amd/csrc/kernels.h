@@ -26,6 +26,11 @@ struct GemmProblem {
     int n_split;
     float alpha;
     int epi;
+    // fp8 (OCP e4m3) operands: A and W are bytes (lda/ldw in elements = bytes), K % 128 == 0,
+    // acc is multiplied by a_scale[row] * w_scale[col] in the epilogue.  nullptr/0 for bf16.
+    const float* a_scale;
+    const float* w_scale;
+    int fp8;
 };
 struct GemmBatch {
     GemmProblem p[2];
@@ -48,6 +53,13 @@ static inline int attn_s_pad(int S) { return ((S + 63) / 64) * 64; }
 int launch_layernorm_modulate(hipStream_t stream, const float* x, uint16_t* y, int rows, int dim, int split,
                               const float* shift0, const float* scale0, const float* shift1,
                               const float* scale1);
+// fp8 variant: y is OCP e4m3 bytes [rows, dim] with a per-row scale (y_scale[row] = amax/448).
+int launch_layernorm_modulate_fp8(hipStream_t stream, const float* x, uint8_t* y, float* y_scale, int rows, int dim,
+                                  int split, const float* shift0, const float* scale0, const float* shift1,
+                                  const float* scale1);
+// Row-wise dynamic quantisation bf16 [rows, cols] (row stride ld) -> e4m3 [rows, cols] (stride ldq) + scale[rows].
+int launch_quantize_rows_fp8(hipStream_t stream, const uint16_t* x, int ld, uint8_t* q, int ldq, float* scale,
+                             int rows, int cols);
 // In place on qkv bf16 [S, 3*dim] (q | k | v): per-head RMSNorm (eps 1e-6, learned scale)
 // then RoPE on q and k; V is written transposed + key-permuted into vt [heads][128][s_pad].
 // Rows < split use (qscale0, kscale0) — the text stream of a double block — rows >= split

@@ -76,6 +76,107 @@ __global__ __launch_bounds__(256) void layernorm_modulate_kernel(const float* __
     }
 }
 
+// ------------------------------------------------------------------ LayerNorm + modulate -> fp8 + row scale
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void layernorm_modulate_fp8_kernel(const float* __restrict__ x,
+                                                                     uint8_t* __restrict__ y, float* __restrict__ ys,
+                                                                     int dim, int split,
+                                                                     const float* __restrict__ shift0,
+                                                                     const float* __restrict__ scale0,
+                                                                     const float* __restrict__ shift1,
+                                                                     const float* __restrict__ scale1) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const float* xr = x + (size_t)row * dim;
+    const int nvec = dim >> 2;
+    float4 v[LN_MAX_VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < nvec) {
+            v[i] = reinterpret_cast<const float4*>(xr)[c];
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+    }
+    const float mean = block_sum_256(s, red) / (float)dim;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < nvec) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            sq += a * a + b * b + cc * cc + d * d;
+        }
+    }
+    const float var = block_sum_256(sq, red) / (float)dim;
+    const float rstd = rsqrtf(var + 1e-6f);
+    const float* sh = (row < split) ? shift0 : shift1;
+    const float* sc = (row < split) ? scale0 : scale1;
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < nvec) {
+            const float4 h = reinterpret_cast<const float4*>(sh)[c];
+            const float4 g = reinterpret_cast<const float4*>(sc)[c];
+            // the bf16 path rounds these values to bf16; quantise the same bf16-rounded values
+            v[i].x = bf16_bits_to_f32(f32_to_bf16_bits((v[i].x - mean) * rstd * (1.f + g.x) + h.x));
+            v[i].y = bf16_bits_to_f32(f32_to_bf16_bits((v[i].y - mean) * rstd * (1.f + g.y) + h.y));
+            v[i].z = bf16_bits_to_f32(f32_to_bf16_bits((v[i].z - mean) * rstd * (1.f + g.z) + h.z));
+            v[i].w = bf16_bits_to_f32(f32_to_bf16_bits((v[i].w - mean) * rstd * (1.f + g.w) + h.w));
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+        }
+    }
+    amax = block_max_256(amax, red);
+    const float qs = fmaxf(amax, 1e-12f) * (1.0f / 448.0f);
+    const float inv = 1.0f / qs;
+    if (threadIdx.x == 0) ys[row] = qs;
+    uint32_t* yr = reinterpret_cast<uint32_t*>(y + (size_t)row * dim);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < nvec) yr[c] = pack_fp8x4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+    }
+}
+
+// Row-wise dynamic quantisation of a bf16 matrix (weights at load time, attention / SwiGLU outputs
+// in front of the next fp8 GEMM): one workgroup per row, two passes over the row (second from L2).
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const uint16_t* __restrict__ x, int ld,
+                                                                uint8_t* __restrict__ q, int ldq,
+                                                                float* __restrict__ scale, int cols) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)row * ld);
+    const int nvec = cols >> 3;
+    float amax = 0.f;
+    for (int c = threadIdx.x; c < nvec; c += 256) {
+        const uint4 u = xr[c];
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(lo_bf16(u.x)), fabsf(hi_bf16(u.x))), fmaxf(fabsf(lo_bf16(u.y)), fabsf(hi_bf16(u.y)))));
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(lo_bf16(u.z)), fabsf(hi_bf16(u.z))), fmaxf(fabsf(lo_bf16(u.w)), fabsf(hi_bf16(u.w)))));
+    }
+    amax = block_max_256(amax, red);
+    const float qs = fmaxf(amax, 1e-12f) * (1.0f / 448.0f);
+    const float inv = 1.0f / qs;
+    if (threadIdx.x == 0) scale[row] = qs;
+    uint2* qr = reinterpret_cast<uint2*>(q + (size_t)row * ldq);
+    for (int c = threadIdx.x; c < nvec; c += 256) {
+        const uint4 u = xr[c];
+        uint2 o;
+        o.x = pack_fp8x4(lo_bf16(u.x) * inv, hi_bf16(u.x) * inv, lo_bf16(u.y) * inv, hi_bf16(u.y) * inv);
+        o.y = pack_fp8x4(lo_bf16(u.z) * inv, hi_bf16(u.z) * inv, lo_bf16(u.w) * inv, hi_bf16(u.w) * inv);
+        qr[c] = o;
+    }
+}
+
 // ------------------------------------------------------------------ QK RMSNorm + RoPE (in place)
 // 16 lanes per (row, head, q|k) vector of 128: a lane owns 8 consecutive elements = 4 RoPE
 // pairs (16-B accesses); a wave handles 4 vectors, a workgroup 16.  Sum of squares by a
@@ -203,6 +304,22 @@ int launch_layernorm_modulate(hipStream_t stream, const float* x, uint16_t* y, i
     if (rows <= 0 || dim <= 0 || (dim & 3) || dim > LN_MAX_VEC * 1024) return 1;
     hipLaunchKernelGGL(layernorm_modulate_kernel, dim3(rows), dim3(256), 0, stream, x, y, dim, split, shift0,
                        scale0, shift1, scale1);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_layernorm_modulate_fp8(hipStream_t stream, const float* x, uint8_t* y, float* y_scale, int rows, int dim,
+                                  int split, const float* shift0, const float* scale0, const float* shift1,
+                                  const float* scale1) {
+    if (rows <= 0 || dim <= 0 || (dim & 3) || dim > LN_MAX_VEC * 1024) return 1;
+    hipLaunchKernelGGL(layernorm_modulate_fp8_kernel, dim3(rows), dim3(256), 0, stream, x, y, y_scale, dim, split,
+                       shift0, scale0, shift1, scale1);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_quantize_rows_fp8(hipStream_t stream, const uint16_t* x, int ld, uint8_t* q, int ldq, float* scale,
+                             int rows, int cols) {
+    if (rows <= 0 || cols <= 0 || (cols & 7) || (ld & 7) || (ldq & 7)) return 1;
+    hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(rows), dim3(256), 0, stream, x, ld, q, ldq, scale, cols);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -58,8 +58,11 @@ class Flux2GenerationResult:
 class Flux2Pipeline:
     """`Flux2Pipeline(model:...)` restricted to the hot path: embeddings in, image out."""
 
-    def __init__(self, model="klein-4b", vae_variant="small", device: int = 0):
+    def __init__(self, model="klein-4b", vae_variant="small", device: int = 0, quantization: str = "bf16"):
+        """`quantization` mirrors `Flux2Pipeline(model:quantization:)` (Flux2Pipeline.swift:286-308) for the
+        transformer only: "bf16" or "fp8" (e4m3 weights + activations; stands in for qint8/int4)."""
         self.ctx = Context(device)
+        self.quantization = quantization
         self.model = model
         self.vae_variant = vae_variant
         self.transformer: Optional[DiT] = None
@@ -68,7 +71,7 @@ class Flux2Pipeline:
     # loadModels(progressCallback:) — weights are handed over as tensors by key
     def load_models(self, dit_tensors=None, vae_tensors=None):
         if dit_tensors is not None:
-            self.transformer = DiT(self.ctx, self.model).load(dit_tensors).finalize()
+            self.transformer = DiT(self.ctx, self.model, weights=self.quantization).load(dit_tensors).finalize()
         if vae_tensors is not None:
             self.vae = VAE(self.ctx, self.vae_variant).load(vae_tensors).finalize()
         return self

@@ -117,6 +117,11 @@ typedef struct flux2mi_dit_config {
     int n_single;         /* numSingleLayers */
     int joint_dim;        /* jointAttentionDim */
     int guidance_embeds;  /* Dev: 1, Klein: 0 */
+    int weight_format;    /* 0: bf16 weights and activations (default).  1: fp8 — the large GEMM weights are
+                             stored as OCP e4m3 with one f32 scale per output channel and their
+                             activations are quantised per token on the fly (BASELINE.json configs[3]);
+                             replaces the reference's MLX weight-only quantisation
+                             (Flux2Pipeline.swift:573, Configuration/QuantizationConfig.swift:40-73) */
 } flux2mi_dit_config;
 
 /* presets "klein-4b" | "klein-9b" | "dev" (Configuration/Flux2Config.swift:258-329). */
@@ -236,6 +241,10 @@ int flux2mi_prof_end(flux2mi_ctx* ctx, int* n_launches, double* total_ms, double
 /* Standalone op entry points (tests / microbenchmarks; same kernels the forward uses). */
 /* C[M,N] (f32) = A[M,K] (bf16) * W[N,K]^T (bf16) */
 int flux2mi_op_gemm_bf16(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K);
+/* same product through the fp8 path: A and W (bf16) are quantised row-wise to OCP e4m3 with
+ * per-row scales (what the fp8 model does to activations / weights), then
+ * v_mfma_f32_16x16x32_fp8_fp8; K % 128 == 0. */
+int flux2mi_op_gemm_fp8(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K);
 /* joint attention: qkv bf16 [S, 3*heads*128] (q|k|v, already normalised/rotated) -> out bf16 [S, heads*128] */
 int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv, void* out, int S, int heads);
 

@@ -289,6 +289,47 @@ def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
     return F.linear(x, w.float(), None if b is None else b.float())
 
 
+# ---- fp8 emulation of the product's weight_format 1 (include/flux2mi.h) ---------------------
+# NOT a restatement of the reference: its quantised variants are MLX affine group-wise int8/int4,
+# weight-only (Configuration/QuantizationConfig.swift:40-73, Flux2Pipeline.swift:573).  The
+# MI355X path uses OCP e4m3 for weights (scale per output channel) AND activations (scale per
+# token) of the block GEMMs; this emulates exactly that so the fp8 parity test has a checker.
+_FP8_BLOCK_GEMMS = False
+E4M3_MAX = 448.0
+
+
+class fp8_block_gemms:
+    """Context manager: block GEMMs (qkv/proj/mlp/linear1/linear2) run on fake-quantised operands."""
+
+    def __enter__(self):
+        global _FP8_BLOCK_GEMMS
+        self._old, _FP8_BLOCK_GEMMS = _FP8_BLOCK_GEMMS, True
+
+    def __exit__(self, *exc):
+        global _FP8_BLOCK_GEMMS
+        _FP8_BLOCK_GEMMS = self._old
+
+
+def fake_quant_e4m3_rows(x: Tensor) -> Tensor:
+    """Per-row (last dim) dynamic quantisation to OCP e4m3: scale = amax/448, round-to-nearest-even,
+    saturating; returns the de-quantised f32 values."""
+    amax = x.float().abs().amax(dim=-1, keepdim=True)
+    scale = amax.clamp_min(1e-12) * (1.0 / E4M3_MAX)      # same f32 operation order as norm.hip
+    inv = 1.0 / scale
+    q = (x.float() * inv).clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).float()
+    return q * scale
+
+
+def block_linear(x: Tensor, w: Tensor) -> Tensor:
+    """A block GEMM.  In fp8 mode the activation is first rounded to bf16 (what the producing
+    kernel stores) and both operands are fake-quantised row-wise."""
+    if not _FP8_BLOCK_GEMMS:
+        return linear(x, w)
+    xq = fake_quant_e4m3_rows(x.to(torch.bfloat16).float())
+    wq = fake_quant_e4m3_rows(w.float())
+    return F.linear(xq, wq)
+
+
 def time_guidance_embed(P: Dict[str, Tensor], t: Tensor, g: Optional[Tensor]) -> Tensor:
     """Flux2Embeddings.swift:124-142; t/g already multiplied by 1000 by the caller
     (Flux2Transformer.swift:145-146)."""
@@ -353,9 +394,9 @@ def _unheads(x: Tensor) -> Tensor:
 
 def swiglu_ff(x: Tensor, w_in: Tensor, w_out: Tensor) -> Tensor:
     """a15 — Flux2FeedForward.swift:42-109: gate = first half, value = second half."""
-    p = linear(x, w_in)
+    p = block_linear(x, w_in)
     gate, value = p.chunk(2, dim=-1)
-    return linear(F.silu(gate) * value, w_out)
+    return block_linear(F.silu(gate) * value, w_out)
 
 
 def double_block(P: Dict[str, Tensor], i: int, img: Tensor, txt: Tensor, H: int,
@@ -367,7 +408,7 @@ def double_block(P: Dict[str, Tensor], i: int, img: Tensor, txt: Tensor, H: int,
     txt_n = apply_modulation(layer_norm_noaffine(txt), txt_mod[0][0], txt_mod[0][1])
 
     def qkv(x, name):
-        p = linear(x, P[pre + name + ".qkv.weight"])
+        p = block_linear(x, P[pre + name + ".qkv.weight"])
         q, k, v = p.chunk(3, dim=-1)              # WeightLoader.swift:99-119: q | k | v
         q, k, v = _heads(q, H), _heads(k, H), _heads(v, H)
         q = rms_norm(q, P[pre + name + ".norm.query_norm.scale"])
@@ -382,8 +423,8 @@ def double_block(P: Dict[str, Tensor], i: int, img: Tensor, txt: Tensor, H: int,
     k = torch.cat([k_t, k_i], dim=2)
     v = torch.cat([v_t, v_i], dim=2)
     o = _unheads(sdpa(q, k, v))
-    txt_attn = linear(o[:, :S_txt], P[pre + "txt_attn.proj.weight"])
-    img_attn = linear(o[:, S_txt:], P[pre + "img_attn.proj.weight"])
+    txt_attn = block_linear(o[:, :S_txt], P[pre + "txt_attn.proj.weight"])
+    img_attn = block_linear(o[:, S_txt:], P[pre + "img_attn.proj.weight"])
     img = img + img_attn * img_mod[0][2].unsqueeze(1)
     txt = txt + txt_attn * txt_mod[0][2].unsqueeze(1)
 
@@ -399,7 +440,7 @@ def single_block(P: Dict[str, Tensor], i: int, hs: Tensor, H: int, cos: Tensor, 
     pre = f"single_blocks.{i}."
     d = hs.shape[-1]
     x = apply_modulation(layer_norm_noaffine(hs), mod[0][0], mod[0][1])
-    p = linear(x, P[pre + "linear1.weight"])      # [q | k | v | gate | up]
+    p = block_linear(x, P[pre + "linear1.weight"])      # [q | k | v | gate | up]
     q, k, v = p[..., :d], p[..., d:2 * d], p[..., 2 * d:3 * d]
     mlp_hidden = (p.shape[-1] - 3 * d) // 2
     gate, up = p[..., 3 * d:3 * d + mlp_hidden], p[..., 3 * d + mlp_hidden:]
@@ -407,7 +448,7 @@ def single_block(P: Dict[str, Tensor], i: int, hs: Tensor, H: int, cos: Tensor, 
     q = apply_rope(rms_norm(q, P[pre + "norm.query_norm.scale"]), cos, sin)
     k = apply_rope(rms_norm(k, P[pre + "norm.key_norm.scale"]), cos, sin)
     attn = _unheads(sdpa(q, k, v))
-    out = linear(torch.cat([attn, F.silu(gate) * up], dim=-1), P[pre + "linear2.weight"])
+    out = block_linear(torch.cat([attn, F.silu(gate) * up], dim=-1), P[pre + "linear2.weight"])
     return hs + out * mod[0][2].unsqueeze(1)
 
 

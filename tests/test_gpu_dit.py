@@ -142,3 +142,59 @@ def test_production_width_blocks(flux2mi, ctx):
     out, ref = _forward_both(flux2mi, ctx, cfg, s_txt=512, h=256, w=256)
     assert torch.isfinite(out).all()
     assert rel_l2(out, ref) < 2e-2
+
+
+# ---- weight_format 1: e4m3 block GEMMs ----------------------------------------------------------
+def _fp8_case(ctx, cfg, s_txt, h, w, std=0.05):
+    from flux2mi import synthetic as syn
+    from flux2mi.api import DiT
+    P = syn.make_dit_weights(cfg, seed=77, std=std)
+    inp = syn.make_inputs(cfg, h, w, s_txt=s_txt)
+    lat = R.pack_patchified_to_sequence(inp["noise"])
+    img_ids, txt_ids = R.image_position_ids(h, w), R.text_position_ids(s_txt)
+    outs = {}
+    for wf in ("bf16", "fp8"):
+        dit = DiT(ctx, cfg, weights=wf).load(P).finalize()
+        outs[wf] = dit.forward(lat.cuda(), inp["txt"].cuda(), 0.6, 4.0, img_ids.cuda(), txt_ids.cuda()).cpu()
+        outs[wf + "_bytes"] = dit.param_bytes
+        dit.close()
+    args = (P, cfg, lat, inp["txt"].float(), torch.tensor([0.6]), None, img_ids, txt_ids)
+    ref32 = R.dit_forward(*args)[0]
+    with R.fp8_block_gemms():
+        ref8 = R.dit_forward(*args)[0]
+    return outs, ref32, ref8
+
+
+@pytest.mark.parametrize("s_txt,h,w", [(16, 128, 128), (19, 80, 112)])
+def test_tiny_forward_fp8(flux2mi, ctx, s_txt, h, w):
+    """fp8 model vs the oracle running the same e4m3 emulation (weights at std 0.05 so that the
+    block GEMMs matter: quantisation moves the output by q ~ 1.1e-2 rel-L2).  e4m3 rounding is
+    discontinuous, so the bf16-level differences between the HIP path and the f32 oracle flip a
+    few percent of the roundings and de-correlate part of the quantisation noise; the GEMM itself
+    is checked to 1e-3 in test_gpu_ops.  Stated tolerances here:
+      * rel-L2(HIP fp8, emulating oracle) <= 1e-2 and below q (the emulation explains the output
+        better than the unquantised oracle does);
+      * rel-L2(HIP fp8, f32 oracle) within [0.5 q, 1.5 q] (the noise level is the expected one);
+      * (fp8 - bf16) of the HIP path points the same way as the oracle's (cosine > 0.7)."""
+    from flux2mi import synthetic as syn
+    outs, ref32, ref8 = _fp8_case(ctx, syn.DIT_PRESETS["tiny"], s_txt, h, w)
+    assert torch.isfinite(outs["fp8"]).all()
+    assert rel_l2(outs["bf16"], ref32) < 2e-2
+    q = rel_l2(ref8, ref32)
+    assert q > 5e-3                                      # the case is sensitive to quantisation at all
+    e8 = rel_l2(outs["fp8"], ref8)
+    assert e8 < 1e-2 and e8 < q
+    assert 0.5 * q < rel_l2(outs["fp8"], ref32) < 1.5 * q
+    d_hip = (outs["fp8"] - outs["bf16"]).flatten()
+    d_ref = (ref8 - ref32).flatten()
+    assert torch.dot(d_hip, d_ref) / (d_hip.norm() * d_ref.norm()) > 0.7
+    assert outs["fp8_bytes"] < 0.7 * outs["bf16_bytes"]  # block weights are stored in one byte
+
+
+def test_fp8_rejects_unsupported_dim(flux2mi, ctx):
+    """dim must be a multiple of 256 for the fp8 tiles (include/flux2mi.h weight_format)."""
+    from flux2mi import Flux2Error
+    from flux2mi.api import DiT
+    cfg = dict(dim=128, heads=1, n_double=1, n_single=1, joint_dim=128, guidance=False)
+    with pytest.raises(Flux2Error):
+        DiT(ctx, cfg, weights="fp8")

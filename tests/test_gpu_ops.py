@@ -145,3 +145,33 @@ def test_gemm_large_auto_dispatch(ctx):
     w = torch.randint(-3, 4, (N, K), generator=g).to(torch.bfloat16)
     out = ctx.op_gemm_bf16(a.cuda(), w.cuda()).cpu()
     assert torch.equal(out, a.float() @ w.float().t())
+
+
+# ---- fp8 (e4m3) GEMM path: weight_format 1 ---------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 256), (300, 200, 384), (1000, 1544, 1024), (64, 4096, 3072)])
+def test_gemm_fp8_vs_emulation(ctx, M, N, K):
+    """op_gemm_fp8 quantises A and W row-wise to e4m3 and multiplies on the fp8 MFMA; the oracle's
+    fake_quant_e4m3_rows does the same arithmetic in f32.  Tolerance 1e-3 rel-L2 (f32 accumulation
+    order; quantised operands are identical up to rare rounding ties), and the result must be
+    quantisation-noise close (< 6e-2) to the unquantised product."""
+    from oracle import flux2_ref as R
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn((M, K), generator=g).to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g) * 0.05).to(torch.bfloat16)
+    a[0, :] = 0          # an all-zero row must not produce NaN/Inf
+    a[1, 5] = 300.0      # outlier: the row scale saturates nothing
+    out = ctx.op_gemm_fp8(a.cuda(), w.cuda()).cpu()
+    emu = R.fake_quant_e4m3_rows(a.float()) @ R.fake_quant_e4m3_rows(w.float()).t()
+    exact = a.float() @ w.float().t()
+    assert torch.isfinite(out).all()
+    assert torch.equal(out[0], torch.zeros(N))
+    assert rel_l2(out, emu) < 1e-3
+    assert rel_l2(out, exact) < 6e-2
+
+
+def test_gemm_fp8_rejects_bad_k(ctx):
+    from flux2mi import Flux2Error
+    a = torch.zeros((256, 192), dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros((256, 192), dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(Flux2Error):
+        ctx.op_gemm_fp8(a, w)

@@ -48,6 +48,15 @@ def main():
             ms = time_fn(lambda: ctx.op_gemm_bf16(a, w))
         ms_t = time_fn(lambda: torch.matmul(a, w.t()))
         fl = 2.0 * M * N * K
+        if "--fp8" in sys.argv:   # GEMM kernel alone (HIP events inside the library), quantisation passes excluded
+            for _ in range(3):
+                ctx.op_gemm_fp8(a, w)
+            ctx.prof_begin(1)
+            for _ in range(10):
+                ctx.op_gemm_fp8(a, w)
+            n, pms, _ = ctx.prof_end()
+            ms8 = pms / n
+            print(f"{name:16s} fp8 e4m3 kernel {ms8:7.3f} ms {fl / ms8 / 1e9:7.1f} TF", flush=True)
         line = f"{name:16s} M{M} N{N} K{K}: ours {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF | hipBLASLt {ms_t:7.3f} ms {fl / ms_t / 1e9:7.1f} TF"
         if check:
             out = ctx.op_gemm_bf16(a, w)

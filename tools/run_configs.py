@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Runs the BASELINE.json configurations that are not the bench headline, once each, and prints
 their timings (synthetic weights/inputs).  A: Klein-4B 256^2 4 steps; C: Dev 1024^2 50 steps;
-D: Klein-9B 1024^2 28 steps (bf16 weights: the fp8 weight path is not built yet);
+D: Klein-9B 1024^2 28 steps, bf16 weights; D8: the same with e4m3 block GEMMs (weight_format 1);
 E: Dev 1024^2, 50 steps at strength 0.7 (35 effective) with the RePaint hook, T2I and I2I (one
 1024^2 reference image, S = 8704)."""
 import os, sys, time, json
@@ -16,8 +16,8 @@ which = sys.argv[1:] or ["A", "D", "C", "E"]
 dev = torch.device("cuda", 0)
 
 
-def load(model, vae="standard"):
-    pipe = Flux2Pipeline(model=model, vae_variant=vae)
+def load(model, vae="standard", quantization="bf16"):
+    pipe = Flux2Pipeline(model=model, vae_variant=vae, quantization=quantization)
     cfg = syn.DIT_PRESETS[model]
     pipe.load_models(syn.make_dit_weights(cfg, device=dev), syn.make_vae_weights(syn.VAE_PRESETS[vae], device=dev))
     return pipe, cfg
@@ -44,6 +44,10 @@ for w in which:
         pipe, cfg = load("klein-9b")
         inp = syn.make_inputs(cfg, 1024, 1024, device=dev)
         run("D klein-9b (bf16 weights) 1024x1024 28 steps, 1 image per GPU", lambda: pipe.generate_text_to_image(height=1024, width=1024, steps=28, precomputed_embeddings=inp["txt"], noise=inp["noise"]))
+    elif w == "D8":
+        pipe, cfg = load("klein-9b", quantization="fp8")
+        inp = syn.make_inputs(cfg, 1024, 1024, device=dev)
+        run("D8 klein-9b (fp8 e4m3 block GEMMs) 1024x1024 28 steps, 1 image per GPU", lambda: pipe.generate_text_to_image(height=1024, width=1024, steps=28, precomputed_embeddings=inp["txt"], noise=inp["noise"]))
     elif w == "C":
         pipe, cfg = load("dev")
         inp = syn.make_inputs(cfg, 1024, 1024, device=dev)
