@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
                     const i32x8 b8__ = __builtin_shufflevector(__builtin_bit_cast(i32x4, bsrc_[j_][0]),  \
                                                                __builtin_bit_cast(i32x4, bsrc_[j_][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
                     acc[(mh_) * 4 + i_][(nh_) * 2 + j_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4( \
-                        a8__, b8__, acc[(mh_) * 4 + i_][(nh_) * 2 + j_], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
+                        b8__, a8__, acc[(mh_) * 4 + i_][(nh_) * 2 + j_], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
                 }                                                                                        \
             }                                                                                            \
         } else {                                                                                         \
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
                 _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
                     _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                     \
                         acc[(mh_) * 4 + i_][(nh_) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(  \
-                            a[i_][kk_], bsrc_[j_][kk_], acc[(mh_) * 4 + i_][(nh_) * 2 + j_], 0, 0, 0);   \
+                            bsrc_[j_][kk_], a[i_][kk_], acc[(mh_) * 4 + i_][(nh_) * 2 + j_], 0, 0, 0);   \
         }                                                                                                \
     }                                                                                                    \
     __builtin_amdgcn_s_setprio(0);
@@ -311,125 +311,173 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
 #undef G2_SYNC
 #undef G2_STAMP
 
-    // ---- epilogue.  acc[i][j][r]: row = m0 + wm*128 + i*16 + fq*4 + r, col = n0 + wn*64 + j*16 + frow
-    const int row_base = m0 + wm * 128 + fq * 4;
-    const int col_base = n0 + wn * 64 + frow;
+    // ---- epilogue.  The MFMAs take the W fragment as the A operand and the activation fragment as
+    // B, so the accumulator tile is the TRANSPOSE of the output block: lane (frow, fq) holds, for
+    // output row m0 + wm*128 + i*16 + frow, the FOUR CONSECUTIVE columns n0 + wn*64 + j*16 + fq*4 + r.
+    // Every store is then 16 B (f32) or 8 B (bf16) per lane instead of 4 / 2 B: a quarter of the
+    // memory instructions (the scalar form spent ~17k cycles per tile in the store queue).
+    const int row_base = m0 + wm * 128 + frow;
+    const int col_base = n0 + wn * 64 + fq * 4;
     int epi = p.epi;
     if (epi == EPI_QKV_MLP) epi = (n0 >= p.n_split) ? EPI_SWIGLU : EPI_BF16;
     if (FP8) {  // de-quantise: per-row activation scale x per-column weight scale
-        float ws[4];
+        float ws[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ws[j] = p.w_scale[min(col_base + j * 16, p.N - 1)];
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+            for (int r = 0; r < 4; ++r) ws[j][r] = p.w_scale[min(col_base + j * 16 + r, p.N - 1)];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float as = p.a_scale[min(row_base + i * 16 + r, p.M - 1)];
+        for (int i = 0; i < 8; ++i) {
+            const float as = p.a_scale[min(row_base + i * 16, p.M - 1)];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j][r] *= as * ws[j];
-            }
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] *= as * ws[j][r];
+        }
     }
 
     if (epi == EPI_F32) {
         float* C = reinterpret_cast<float*>(p.C);
+        const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i) {
+            const int row = row_base + i * 16;
+            if (row < p.M) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row_base + i * 16 + r;
-                if (row < p.M) {
+                for (int j = 0; j < 4; ++j) {
+                    const int col = col_base + j * 16;
+                    float* dst = C + (size_t)row * p.ldc + col;
+                    if (vec_ok && col + 3 < p.N) {
+                        *reinterpret_cast<f32x4*>(dst) = acc[i][j] * p.alpha;
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int col = col_base + j * 16;
-                        if (col < p.N) C[(size_t)row * p.ldc + col] = acc[i][j][r] * p.alpha;
+                        for (int r = 0; r < 4; ++r)
+                            if (col + r < p.N) dst[r] = acc[i][j][r] * p.alpha;
                     }
                 }
             }
+        }
     } else if (epi == EPI_BF16) {
         uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+        const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 7) == 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i) {
+            const int row = row_base + i * 16;
+            if (row < p.M) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row_base + i * 16 + r;
-                if (row < p.M) {
+                for (int j = 0; j < 4; ++j) {
+                    const int col = col_base + j * 16;
+                    uint16_t* dst = C + (size_t)row * p.ldc + col;
+                    const f32x4 v = acc[i][j] * p.alpha;
+                    if (vec_ok && col + 3 < p.N) {
+                        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int col = col_base + j * 16;
-                        if (col < p.N) C[(size_t)row * p.ldc + col] = f32_to_bf16_bits(acc[i][j][r] * p.alpha);
+                        for (int r = 0; r < 4; ++r)
+                            if (col + r < p.N) dst[r] = f32_to_bf16_bits(v[r]);
                     }
                 }
             }
+        }
     } else if (epi == EPI_GATE_RESID) {
         float* C = reinterpret_cast<float*>(p.C);
-        float g[4];
+        const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+        f32x4 g[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = col_base + j * 16;
-            g[j] = (col < p.N) ? p.vec[col] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = row_base + i * 16 + r;
-                if (row < p.M) {
+                const int col = col_base + j * 16 + r;
+                g[j][r] = (col < p.N) ? p.vec[col] : 0.f;
+            }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int col = col_base + j * 16;
-                        if (col < p.N) {
-                            float* dst = C + (size_t)row * p.ldc + col;
-                            *dst = *dst + g[j] * acc[i][j][r];
-                        }
+        for (int i = 0; i < 8; ++i) {
+            const int row = row_base + i * 16;
+            if (row < p.M) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = col_base + j * 16;
+                    float* dst = C + (size_t)row * p.ldc + col;
+                    if (vec_ok && col + 3 < p.N) {
+                        f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+                        *d4 = *d4 + g[j] * acc[i][j];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col + r < p.N) dst[r] = dst[r] + g[j][r] * acc[i][j][r];
                     }
                 }
             }
+        }
     } else if (epi == EPI_SWIGLU) {
+        // weight rows are interleaved in blocks of 32 (gate | value) inside each 64-column group =
+        // one wave's columns: gate = accumulator blocks j 0,1, value = blocks 2,3 of the same lane
         uint16_t* C = reinterpret_cast<uint16_t*>(p.C2);
         const int start = (p.epi == EPI_QKV_MLP) ? p.n_split : 0;
-        const int hbase = ((n0 + wn * 64 - start) >> 1) + frow;
+        const int hbase = ((n0 + wn * 64 - start) >> 1) + fq * 4;
         const int hidden = (p.N - start) >> 1;
+        const bool vec_ok = (p.ldc2 & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 7) == 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i) {
+            const int row = row_base + i * 16;
+            if (row < p.M) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row_base + i * 16 + r;
-                if (row < p.M) {
+                for (int j = 0; j < 2; ++j) {
+                    const int h = hbase + j * 16;
+                    uint16_t* dst = C + (size_t)row * p.ldc2 + h;
+                    float o[4];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int h = hbase + j * 16;
-                        if (h < hidden) {
-                            const float gate = acc[i][j][r], val = acc[i][j + 2][r];
-                            C[(size_t)row * p.ldc2 + h] = f32_to_bf16_bits(silu_f(gate) * val);
-                        }
+                    for (int r = 0; r < 4; ++r) o[r] = silu_f(acc[i][j][r]) * acc[i][j + 2][r];
+                    if (vec_ok && h + 3 < hidden) {
+                        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (h + r < hidden) dst[r] = f32_to_bf16_bits(o[r]);
                     }
                 }
             }
+        }
     } else {  // EPI_BIAS_BF16
         uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
-        float bsv[4];
+        const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 7) == 0 &&
+                            (p.resid == nullptr || ((p.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.resid) & 7) == 0));
+        f32x4 bsv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = col_base + j * 16;
-            bsv[j] = (p.vec != nullptr && col < p.N) ? p.vec[col] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = row_base + i * 16 + r;
-                if (row < p.M) {
+                const int col = col_base + j * 16 + r;
+                bsv[j][r] = (p.vec != nullptr && col < p.N) ? p.vec[col] : 0.f;
+            }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int col = col_base + j * 16;
-                        if (col < p.N) {
-                            float v = acc[i][j][r] * p.alpha + bsv[j];
-                            if (p.resid) v += bf16_bits_to_f32(p.resid[(size_t)row * p.ldr + col]);
-                            C[(size_t)row * p.ldc + col] = f32_to_bf16_bits(v);
+        for (int i = 0; i < 8; ++i) {
+            const int row = row_base + i * 16;
+            if (row < p.M) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = col_base + j * 16;
+                    uint16_t* dst = C + (size_t)row * p.ldc + col;
+                    f32x4 v = acc[i][j] * p.alpha + bsv[j];
+                    if (vec_ok && col + 3 < p.N) {
+                        if (p.resid) {
+                            const uint2 rv = *reinterpret_cast<const uint2*>(p.resid + (size_t)row * p.ldr + col);
+                            v[0] += bf16_bits_to_f32((uint16_t)(rv.x & 0xffff)); v[1] += bf16_bits_to_f32((uint16_t)(rv.x >> 16));
+                            v[2] += bf16_bits_to_f32((uint16_t)(rv.y & 0xffff)); v[3] += bf16_bits_to_f32((uint16_t)(rv.y >> 16));
                         }
+                        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col + r < p.N) {
+                                float x = v[r];
+                                if (p.resid) x += bf16_bits_to_f32(p.resid[(size_t)row * p.ldr + col + r]);
+                                dst[r] = f32_to_bf16_bits(x);
+                            }
                     }
                 }
             }
+        }
     }
 }
 
