@@ -22,6 +22,7 @@
 //     to LDS after them (one barrier per tile).
 #include "dev.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -103,6 +104,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
     const int nt = (S + BKV - 1) / BKV;
     ATTN_LOAD_TILE(0)
     ATTN_STORE_TILE(0)
+    // The Q fragments come from global loads issued before the loop.  Without this, hipcc's
+    // waitcnt pass carries "qf may still be in flight" around the back edge and puts
+    // s_waitcnt vmcnt(7..0) in front of the eight QK^T MFMAs of EVERY tile — which also drains the
+    // tile t+1 prefetch issued at the top of the iteration, so its latency was never hidden.
+    // Passing qf through an empty asm makes the values asm-defined: the wait lands here, once.
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
     __syncthreads();
 
     for (int kt = 0; kt < nt; ++kt) {

@@ -175,3 +175,32 @@ def test_gemm_fp8_rejects_bad_k(ctx):
     w = torch.zeros((256, 192), dtype=torch.bfloat16, device="cuda")
     with pytest.raises(Flux2Error):
         ctx.op_gemm_fp8(a, w)
+
+
+# ---- production-shaped launches of the 256x256 kernel, exact data ------------------------------------
+@pytest.mark.parametrize("M,N,K", [
+    (4608, 3072, 3072),    # 216 tiles (< 256 CUs)
+    (4608, 9216, 1024),    # 648 tiles
+    (4500, 3000, 2048),    # ragged edges
+    (4608, 3072, 64),      # a single K-tile
+    (2304, 27648, 512),    # wide N
+])
+def test_gemm_production_shapes_exact(ctx, M, N, K):
+    """Integer-valued operands: every partial sum is exact in f32, so the result must equal the
+    reference bit for bit."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16)
+    w = torch.randint(-3, 4, (N, K), generator=g).to(torch.bfloat16)
+    out = ctx.op_gemm_bf16(a.cuda(), w.cuda()).cpu()
+    assert torch.equal(out, a.float() @ w.float().t())
+
+
+def test_gemm_deterministic(ctx):
+    """Two runs on random data are bit-identical (no atomics, no timing-dependent summation order)."""
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn((4608, 3072), generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn((3072, 3072), generator=g) * 0.05).to(torch.bfloat16).cuda()
+    o1 = ctx.op_gemm_bf16(a, w).cpu()
+    o2 = ctx.op_gemm_bf16(a, w).cpu()
+    assert torch.equal(o1, o2)
+    assert rel_l2(o1, a.float().cpu() @ w.float().cpu().t()) < 2e-3
