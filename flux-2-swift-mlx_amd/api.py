@@ -347,6 +347,32 @@ class VAE:
         self.ctx._exit()
         return of, ou
 
+    @property
+    def has_encoder(self) -> bool:
+        return bool(lib().flux2mi_vae_has_encoder(self.handle))
+
+    def encode(self, image: torch.Tensor) -> torch.Tensor:
+        """`vae.encode(x, samplePosterior: false)`: image f32 [1,3,H,W] in [-1,1] -> posterior mean
+        f32 [1,32,H/8,W/8]  (async; no scaling factor, no BatchNorm — AutoencoderKL.swift:90-123)."""
+        x = _req(image, torch.float32, "image")
+        H, W = x.shape[-2], x.shape[-1]
+        z = torch.empty((1, 32, H // 8, W // 8), dtype=torch.float32, device=x.device)
+        self.ctx._enter()
+        check(lib().flux2mi_vae_encode(self.handle, _ptr(x), H, W, _ptr(z)))
+        self.ctx._exit()
+        return z
+
+    def encode_to_packed(self, image: torch.Tensor) -> torch.Tensor:
+        """encode -> patchify -> BatchNorm-normalise -> pack: f32 [1,(H/16)(W/16),128]."""
+        z = self.encode(image)
+        h16, w16 = z.shape[-2] // 2, z.shape[-1] // 2
+        out = torch.empty((1, h16 * w16, 128), dtype=torch.float32, device=z.device)
+        self.ctx._enter()
+        check(lib().flux2mi_vae_latents_to_packed(self.ctx.handle, _ptr(z), self.bn_mean_ptr, self.bn_var_ptr,
+                                                  _ptr(out), h16, w16))
+        self.ctx._exit()
+        return out
+
     def close(self):
         if self.handle and self.ctx.handle:
             lib().flux2mi_vae_destroy(self.handle)

@@ -111,6 +111,8 @@ struct ConvArgs {
     int Hin, Win, Cin, Cout;
     int ks;                 // 1 or 3 (pad = ks/2)
     int upsample;           // 1: the conv reads a nearest-2x upsampled view of x (Ho = 2*Hin)
+    int downsample;         // 1: stride 2, no top/left padding, one zero row/column at the bottom/right
+                            //    (Downsample2D, ResnetBlock.swift:189-214): Ho = Hin/2, ks must be 3
 };
 int launch_conv2d(hipStream_t stream, const ConvArgs& a);
 // GroupNorm statistics of NHWC bf16 x -> per-channel affine (a_c, b_c) f32 with
@@ -122,7 +124,11 @@ int groupnorm_partial_floats(int64_t pixels, int groups);
 int launch_groupnorm_apply(hipStream_t stream, const uint16_t* x, uint16_t* y, int64_t pixels, int C,
                            const float* ab, int silu);
 int launch_nchw_f32_to_nhwc_bf16(hipStream_t stream, const float* in, uint16_t* out, int C, int H, int W);
+// same, output channel count C_pad >= C with zeros in the padding (conv_in of the encoder: 3 -> 32)
+int launch_nchw_f32_to_nhwc_bf16_padded(hipStream_t stream, const float* in, uint16_t* out, int C, int C_pad, int H, int W);
+// NHWC bf16 [P, C] channels [c0, c0+n) -> f32 [n, P] (NCHW)
+int launch_nhwc_bf16_to_nchw_f32(hipStream_t stream, const uint16_t* in, float* out, int C, int c0, int n, int64_t P);
 int launch_softmax_rows(hipStream_t stream, const float* in, uint16_t* out, int rows, int cols);
 int launch_transpose_bf16(hipStream_t stream, const uint16_t* in, uint16_t* out, int rows, int cols);
 int launch_oihw_to_ohwi_bf16(hipStream_t stream, const uint16_t* in, uint16_t* out, int O, int I, int KH, int KW,
-                             int O_pad);
+                             int O_pad, int I_pad = 0 /* 0 = I */);

@@ -1,10 +1,16 @@
-// vae.cpp — AutoencoderKLFlux2.decode on MI355X (VAE/AutoencoderKL.swift:129-143,
+// vae.cpp — AutoencoderKLFlux2.decode (and .encode, posterior mean) on MI355X (VAE/AutoencoderKL.swift:129-143,
 // VAE/VAEDecoder.swift:91-121, VAE/ResnetBlock.swift).  NHWC bf16 activations, OHWI bf16
 // conv weights (same layouts the reference uses with MLX), f32 bias / GroupNorm params.
 //
 // Decoder graph:  z -> post_quant_conv 1x1 -> conv_in 3x3 -> mid(Resnet, Attn, Resnet)
 //   -> 4 up blocks x 3 Resnets (+ nearest-2x + conv3x3 after blocks 0-2)
 //   -> GroupNorm -> SiLU -> conv_out 3x3 -> [3,H,W] f32 and/or u8 HWC.
+// Encoder graph (VAE/VAEEncoder.swift:88-118, AutoencoderKL.swift:90-123): image [3,H,W] in [-1,1]
+//   -> conv_in 3x3 (3 -> c0; the 3 input channels are zero-padded to 32 for the MFMA K-step)
+//   -> 4 down blocks x 2 Resnets (+ stride-2 conv with bottom/right zero padding after blocks 0-2)
+//   -> mid(Resnet, Attn, Resnet) -> GroupNorm -> SiLU -> conv_out 3x3 (-> 64) -> quant_conv 1x1
+//   -> posterior MEAN = channels 0..31 (Flux2Pipeline.swift:2201 uses the mean, no scaling factor).
+// Encoder tensors are optional: a checkpoint loaded without them can decode but not encode.
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -25,14 +31,17 @@ struct Param {
     int kind;
     int64_t shape[4];
     int ndim;
-    void* ptr = nullptr;  // conv: bf16 [O_pad][KK][I]; linear: bf16 [O][I]; f32 vectors
+    void* ptr = nullptr;  // conv: bf16 [O_pad][KK][I_pad]; linear: bf16 [O][I]; f32 vectors
     bool got = false;
+    bool encoder = false;  // encode-only tensor: not required by finalize
+    int i_pad = 0;         // conv: input channels padded to this count (conv_in of the encoder)
 };
 
 struct ConvW { int w = -1, b = -1, cin = 0, cout = 0, ks = 0; };
 struct GNW { int g = -1, b = -1, c = 0; };
 struct LinW { int w = -1, b = -1; };
 struct ResnetW { GNW n1, n2; ConvW c1, c2, sc; bool has_sc = false; };
+struct AttnW { GNW gn; LinW q, k, v, o; };
 
 }  // namespace
 
@@ -45,11 +54,18 @@ struct flux2mi_vae {
 
     ConvW post_quant, conv_in, conv_out;
     ResnetW mid0, mid1;
-    GNW attn_gn, norm_out;
-    LinW to_q, to_k, to_v, to_o;
+    GNW norm_out;
+    AttnW attn;
     ResnetW up[4][3];
     ConvW upsample[3];
     int bn_mean = -1, bn_var = -1;
+    // encoder side
+    ConvW e_conv_in, e_conv_out, e_quant, e_down[3];
+    ResnetW e_res[4][2], e_mid0, e_mid1;
+    AttnW e_attn;
+    GNW e_norm_out;
+    int first_encoder_param = -1;
+    DevBuf img_in;
 
     DevBuf stage_raw, stage_bf16;
     DevBuf act[4];                      // A, B, C, D ping-pong activations
@@ -101,18 +117,23 @@ ResnetW add_resnet(flux2mi_vae* v, const std::string& pre, int cin, int cout) {
     return r;
 }
 
+AttnW add_attn(flux2mi_vae* v, const std::string& a, int c) {
+    AttnW w;
+    w.gn = add_gn(v, a + "group_norm", c);
+    w.q = add_lin(v, a + "to_q", c, c);
+    w.k = add_lin(v, a + "to_k", c, c);
+    w.v = add_lin(v, a + "to_v", c, c);
+    w.o = add_lin(v, a + "to_out.0", c, c);
+    return w;
+}
+
 void build(flux2mi_vae* v) {
     const flux2mi_vae_config& c = v->cfg;
     const int L = c.latent_channels, mid = c.channels[3];
     v->post_quant = add_conv(v, "post_quant_conv", L, L, 1);
     v->conv_in = add_conv(v, "decoder.conv_in", mid, L, 3);
     v->mid0 = add_resnet(v, "decoder.mid_block.resnets.0.", mid, mid);
-    const std::string a = "decoder.mid_block.attentions.0.";
-    v->attn_gn = add_gn(v, a + "group_norm", mid);
-    v->to_q = add_lin(v, a + "to_q", mid, mid);
-    v->to_k = add_lin(v, a + "to_k", mid, mid);
-    v->to_v = add_lin(v, a + "to_v", mid, mid);
-    v->to_o = add_lin(v, a + "to_out.0", mid, mid);
+    v->attn = add_attn(v, "decoder.mid_block.attentions.0.", mid);
     v->mid1 = add_resnet(v, "decoder.mid_block.resnets.1.", mid, mid);
     int prev = mid;
     char buf[128];
@@ -132,6 +153,32 @@ void build(flux2mi_vae* v) {
     v->conv_out = add_conv(v, "decoder.conv_out", 3, c.channels[0], 3);
     v->bn_mean = add_param(v, "bn.running_mean", PK_F32, {4 * L});
     v->bn_var = add_param(v, "bn.running_var", PK_F32, {4 * L});
+
+    // ---- encoder (diffusers keys, WeightLoader.swift:486-560)
+    v->first_encoder_param = (int)v->params.size();
+    v->e_conv_in = add_conv(v, "encoder.conv_in", c.channels[0], 3, 3);
+    v->params[v->e_conv_in.w].i_pad = 32;
+    v->e_conv_in.cin = 32;
+    prev = c.channels[0];
+    for (int i = 0; i < 4; ++i) {
+        const int co = c.channels[i];
+        for (int j = 0; j < c.layers_per_block; ++j) {
+            snprintf(buf, sizeof buf, "encoder.down_blocks.%d.resnets.%d.", i, j);
+            v->e_res[i][j] = add_resnet(v, buf, j == 0 ? prev : co, co);
+        }
+        prev = co;
+        if (i < 3) {
+            snprintf(buf, sizeof buf, "encoder.down_blocks.%d.downsamplers.0.conv", i);
+            v->e_down[i] = add_conv(v, buf, co, co, 3);
+        }
+    }
+    v->e_mid0 = add_resnet(v, "encoder.mid_block.resnets.0.", mid, mid);
+    v->e_attn = add_attn(v, "encoder.mid_block.attentions.0.", mid);
+    v->e_mid1 = add_resnet(v, "encoder.mid_block.resnets.1.", mid, mid);
+    v->e_norm_out = add_gn(v, "encoder.conv_norm_out", mid);
+    v->e_conv_out = add_conv(v, "encoder.conv_out", 2 * L, mid, 3);
+    v->e_quant = add_conv(v, "quant_conv", 2 * L, 2 * L, 1);
+    for (size_t i = (size_t)v->first_encoder_param; i < v->params.size(); ++i) v->params[i].encoder = true;
 }
 
 size_t dsize(int dtype) { return dtype == FLUX2MI_F32 ? 4 : 2; }
@@ -166,7 +213,7 @@ extern "C" int flux2mi_vae_create(flux2mi_ctx* ctx, const flux2mi_vae_config* cf
     build(v);
     for (Param& p : v->params) {
         size_t bytes = 0;
-        if (p.kind == PK_CONV_W) bytes = (size_t)pad32((int)p.shape[0]) * p.shape[1] * p.shape[2] * p.shape[3] * 2;
+        if (p.kind == PK_CONV_W) bytes = (size_t)pad32((int)p.shape[0]) * (p.i_pad ? p.i_pad : p.shape[1]) * p.shape[2] * p.shape[3] * 2;
         else if (p.kind == PK_LINEAR_W) bytes = (size_t)p.shape[0] * p.shape[1] * 2;
         else bytes = (size_t)p.shape[0] * 4;
         hipError_t e = hipMalloc(&p.ptr, bytes);
@@ -187,7 +234,7 @@ extern "C" int flux2mi_vae_destroy(flux2mi_vae* v) {
     for (Param& p : v->params)
         if (p.ptr) (void)hipFree(p.ptr);
     DevBuf* bufs[] = {&v->stage_raw, &v->stage_bf16, &v->act[0], &v->act[1], &v->act[2], &v->act[3], &v->aq, &v->ak,
-                      &v->av, &v->avt, &v->scores, &v->probs, &v->gn_partial, &v->gn_ab, &v->zin};
+                      &v->av, &v->avt, &v->scores, &v->probs, &v->gn_partial, &v->gn_ab, &v->zin, &v->img_in};
     for (DevBuf* b : bufs) b->release();
     delete v;
     return FLUX2MI_OK;
@@ -196,9 +243,7 @@ extern "C" int flux2mi_vae_destroy(flux2mi_vae* v) {
 extern "C" int flux2mi_vae_set_tensor(flux2mi_vae* v, const char* name, int dtype, const int64_t* shape, int ndim,
                                       const void* data) {
     F2_REQUIRE(v && name && shape && data, FLUX2MI_ERR_INVALID_ARG, "vae_set_tensor: NULL argument");
-    // encoder-side and bookkeeping tensors of the checkpoint are not part of the decode path
-    if (!strncmp(name, "encoder.", 8) || !strncmp(name, "quant_conv.", 11) || strstr(name, "num_batches_tracked"))
-        return FLUX2MI_OK;
+    if (strstr(name, "num_batches_tracked")) return FLUX2MI_OK;  // bookkeeping tensor of the checkpoint
     auto it = v->index.find(name);
     if (it == v->index.end()) {
         flux2mi_set_error("vae_set_tensor: unknown key '%s'", name);
@@ -227,7 +272,7 @@ extern "C" int flux2mi_vae_set_tensor(flux2mi_vae* v, const char* name, int dtyp
             // OIHW (file) -> OHWI, O zero-padded to a multiple of 32 (WeightLoader.swift:495-497)
             F2_LAUNCH(launch_oihw_to_ohwi_bf16(st, v->stage_bf16.as<uint16_t>(), reinterpret_cast<uint16_t*>(p.ptr),
                                                (int)p.shape[0], (int)p.shape[1], (int)p.shape[2], (int)p.shape[3],
-                                               pad32((int)p.shape[0])), "oihw_to_ohwi");
+                                               pad32((int)p.shape[0]), p.i_pad), "oihw_to_ohwi");
         }
     }
     F2_CHECK_HIP(hipStreamSynchronize(st));
@@ -239,7 +284,7 @@ extern "C" int flux2mi_vae_set_tensor(flux2mi_vae* v, const char* name, int dtyp
 extern "C" int flux2mi_vae_finalize(flux2mi_vae* v) {
     F2_REQUIRE(v, FLUX2MI_ERR_INVALID_ARG, "vae_finalize: NULL");
     for (const Param& p : v->params)
-        if (!p.got) {
+        if (!p.got && !p.encoder) {
             flux2mi_set_error("vae_finalize: tensor '%s' missing", p.name.c_str());
             return FLUX2MI_ERR_NOT_LOADED;
         }
@@ -265,13 +310,16 @@ struct Dec {
     const uint16_t* W(int i) const { return reinterpret_cast<const uint16_t*>(v->params[i].ptr); }
     const float* F(int i) const { return reinterpret_cast<const float*>(v->params[i].ptr); }
 
-    int conv(const ConvW& c, const uint16_t* x, int Hin, int Win, int upsample, const uint16_t* resid, uint16_t* y,
+    // resample: 0 none, 1 nearest-2x upsample folded into the gather, -1 stride-2 downsample
+    int conv(const ConvW& c, const uint16_t* x, int Hin, int Win, int resample, const uint16_t* resid, uint16_t* y,
              float* y_f32 = nullptr, uint8_t* y_u8 = nullptr) {
         ConvArgs a;
         memset(&a, 0, sizeof a);
         a.x = x; a.w = W(c.w); a.bias = F(c.b); a.resid = resid; a.y = y; a.y_f32_nchw = y_f32; a.y_u8_hwc = y_u8;
-        a.Hin = Hin; a.Win = Win; a.Cin = c.cin; a.Cout = c.cout; a.ks = c.ks; a.upsample = upsample;
-        const double ho = upsample ? 2.0 * Hin : Hin, wo = upsample ? 2.0 * Win : Win;
+        a.Hin = Hin; a.Win = Win; a.Cin = c.cin; a.Cout = c.cout; a.ks = c.ks;
+        a.upsample = resample > 0; a.downsample = resample < 0;
+        const double ho = resample > 0 ? 2.0 * Hin : resample < 0 ? 0.5 * Hin : Hin;
+        const double wo = resample > 0 ? 2.0 * Win : resample < 0 ? 0.5 * Win : Win;
         prof_before(v->ctx, PROF_VAE_CONV);
         const int r = launch_conv2d(st, a);
         prof_after(v->ctx, PROF_VAE_CONV, 2.0 * ho * wo * c.cout * c.cin * c.ks * c.ks);
@@ -309,17 +357,17 @@ struct Dec {
         return FLUX2MI_OK;
     }
     // single-head attention over P = H*W tokens (ResnetBlock.swift:257-313); A in place
-    int attention(uint16_t* A, uint16_t* B, int H, int Wd) {
-        const int C = v->attn_gn.c;
+    int attention(const AttnW& w, uint16_t* A, uint16_t* B, int H, int Wd) {
+        const int C = w.gn.c;
         const int P = H * Wd;
         const size_t pc = (size_t)P * C * 2;
         F2_TRY(v->aq.reserve(pc)); F2_TRY(v->ak.reserve(pc)); F2_TRY(v->av.reserve(pc)); F2_TRY(v->avt.reserve(pc));
         F2_TRY(v->scores.reserve((size_t)P * P * 4));
         F2_TRY(v->probs.reserve((size_t)P * P * 2));
-        F2_TRY(gn(v->attn_gn, A, B, P, 0));
-        F2_TRY(lin(v->to_q, B, v->aq.as<uint16_t>(), P, C, nullptr));
-        F2_TRY(lin(v->to_k, B, v->ak.as<uint16_t>(), P, C, nullptr));
-        F2_TRY(lin(v->to_v, B, v->av.as<uint16_t>(), P, C, nullptr));
+        F2_TRY(gn(w.gn, A, B, P, 0));
+        F2_TRY(lin(w.q, B, v->aq.as<uint16_t>(), P, C, nullptr));
+        F2_TRY(lin(w.k, B, v->ak.as<uint16_t>(), P, C, nullptr));
+        F2_TRY(lin(w.v, B, v->av.as<uint16_t>(), P, C, nullptr));
         GemmProblem s;
         memset(&s, 0, sizeof s);
         s.A = v->aq.as<uint16_t>(); s.lda = C; s.W = v->ak.as<uint16_t>(); s.ldw = C; s.C = v->scores.ptr; s.ldc = P;
@@ -332,7 +380,7 @@ struct Dec {
         o.A = v->probs.as<uint16_t>(); o.lda = P; o.W = v->avt.as<uint16_t>(); o.ldw = P; o.C = v->aq.ptr; o.ldc = C;
         o.M = P; o.N = C; o.K = P; o.epi = EPI_BF16; o.alpha = 1.0f;
         F2_LAUNCH(launch_gemm(st, &o, 1), "vae.pv");
-        F2_TRY(lin(v->to_o, v->aq.as<uint16_t>(), A, P, C, A));
+        F2_TRY(lin(w.o, v->aq.as<uint16_t>(), A, P, C, A));
         return FLUX2MI_OK;
     }
 };
@@ -364,7 +412,7 @@ extern "C" int flux2mi_vae_decode(flux2mi_vae* v, const float* z, int h, int w, 
     F2_TRY(d.conv(v->post_quant, v->zin.as<uint16_t>(), h, w, 0, nullptr, B));
     F2_TRY(d.conv(v->conv_in, B, h, w, 0, nullptr, A));
     F2_TRY(d.resnet(v->mid0, A, B, C, D, h, w));
-    F2_TRY(d.attention(A, B, h, w));
+    F2_TRY(d.attention(v->attn, A, B, h, w));
     F2_TRY(d.resnet(v->mid1, A, B, C, D, h, w));
     int H = h, W = w;
     for (int i = 0; i < 4; ++i) {
@@ -380,5 +428,65 @@ extern "C" int flux2mi_vae_decode(flux2mi_vae* v, const float* z, int h, int w, 
     }
     F2_TRY(d.gn(v->norm_out, A, B, (int64_t)H * W, 1));
     F2_TRY(d.conv(v->conv_out, B, H, W, 0, nullptr, nullptr, out_f32, out_u8));
+    return FLUX2MI_OK;
+}
+
+// ------------------------------------------------------------------ encode
+extern "C" int flux2mi_vae_has_encoder(const flux2mi_vae* v) {
+    if (!v || v->first_encoder_param < 0) return 0;
+    for (size_t i = (size_t)v->first_encoder_param; i < v->params.size(); ++i)
+        if (!v->params[i].got) return 0;
+    return 1;
+}
+
+extern "C" int flux2mi_vae_encode(flux2mi_vae* v, const float* image, int H, int W, float* z_mean) {
+    F2_REQUIRE(v && image && z_mean, FLUX2MI_ERR_INVALID_ARG, "vae_encode: NULL argument");
+    F2_REQUIRE(H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0, FLUX2MI_ERR_SHAPE,
+               "vae_encode: image %dx%d must be a multiple of 16 (8x VAE stride, 2x2 patchify)", H, W);
+    F2_REQUIRE(v->finalized, FLUX2MI_ERR_NOT_LOADED, "vae_encode: weights not finalized");
+    if (!flux2mi_vae_has_encoder(v)) {
+        for (size_t i = (size_t)v->first_encoder_param; i < v->params.size(); ++i)
+            if (!v->params[i].got) {
+                flux2mi_set_error("vae_encode: encoder tensor '%s' was not loaded", v->params[i].name.c_str());
+                break;
+            }
+        return FLUX2MI_ERR_NOT_LOADED;
+    }
+    F2_CHECK_HIP(hipSetDevice(v->ctx->device));
+    const flux2mi_vae_config& c = v->cfg;
+    size_t max_elems = 0;
+    for (int i = 0; i < 4; ++i) {
+        const size_t hw = ((size_t)H >> i) * ((size_t)W >> i);
+        const size_t ch = (size_t)c.channels[i];
+        if (hw * ch > max_elems) max_elems = hw * ch;
+    }
+    for (int i = 0; i < 4; ++i) F2_TRY(v->act[i].reserve(max_elems * 2));
+    F2_TRY(v->img_in.reserve((size_t)H * W * 32 * 2));
+    Dec d{v, v->ctx->stream};
+    uint16_t* A = v->act[0].as<uint16_t>();
+    uint16_t* B = v->act[1].as<uint16_t>();
+    uint16_t* C = v->act[2].as<uint16_t>();
+    uint16_t* D = v->act[3].as<uint16_t>();
+
+    F2_LAUNCH(launch_nchw_f32_to_nhwc_bf16_padded(d.st, image, v->img_in.as<uint16_t>(), 3, 32, H, W), "image->nhwc");
+    F2_TRY(d.conv(v->e_conv_in, v->img_in.as<uint16_t>(), H, W, 0, nullptr, A));
+    int h = H, w = W;
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < c.layers_per_block; ++j) F2_TRY(d.resnet(v->e_res[i][j], A, B, C, D, h, w));
+        if (i < 3) {
+            F2_TRY(d.conv(v->e_down[i], A, h, w, -1, nullptr, B));
+            std::swap(A, B);
+            h /= 2;
+            w /= 2;
+        }
+    }
+    F2_TRY(d.resnet(v->e_mid0, A, B, C, D, h, w));
+    F2_TRY(d.attention(v->e_attn, A, B, h, w));
+    F2_TRY(d.resnet(v->e_mid1, A, B, C, D, h, w));
+    F2_TRY(d.gn(v->e_norm_out, A, B, (int64_t)h * w, 1));
+    F2_TRY(d.conv(v->e_conv_out, B, h, w, 0, nullptr, C));           // [h, w, 64]
+    F2_TRY(d.conv(v->e_quant, C, h, w, 0, nullptr, B));              // quant_conv 1x1
+    F2_LAUNCH(launch_nhwc_bf16_to_nchw_f32(d.st, B, z_mean, 2 * c.latent_channels, 0, c.latent_channels, (int64_t)h * w),
+              "mean->nchw");
     return FLUX2MI_OK;
 }

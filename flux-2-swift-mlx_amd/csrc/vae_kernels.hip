@@ -32,6 +32,10 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a, int Ho, int Wo,
     const int cblocks = a.Cin / CBK;
     const int nsteps = taps * cblocks;
     const int up = a.upsample;
+    // input-view extent and the output -> input coordinate map: iy = oy*stride + ky - pad
+    const int stride = a.downsample ? 2 : 1;
+    const int pad_tl = a.downsample ? 0 : pad;
+    const int Hv = a.Hin << up, Wv = a.Win << up;
 
     // ---- A staging: 2 chunks/thread: row = idx>>2 (pixel), chunk = idx&3 (8 channels)
     int a_y[2], a_x[2], a_lds[2], a_chunk[2];
@@ -69,8 +73,8 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a, int Ho, int Wo,
         const int tap_ = (s_) / cblocks, cb_ = (s_) - tap_ * cblocks;                                          \
         const int ky_ = tap_ / a.ks, kx_ = tap_ - ky_ * a.ks;                                                  \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                     \
-            const int iy_ = a_y[i_] + ky_ - pad, ix_ = a_x[i_] + kx_ - pad;                                    \
-            const bool ok_ = a_ok[i_] && iy_ >= 0 && iy_ < Ho && ix_ >= 0 && ix_ < Wo;                         \
+            const int iy_ = a_y[i_] * stride + ky_ - pad_tl, ix_ = a_x[i_] * stride + kx_ - pad_tl;            \
+            const bool ok_ = a_ok[i_] && iy_ >= 0 && iy_ < Hv && ix_ >= 0 && ix_ < Wv;                         \
             u32x4 v_ = {0u, 0u, 0u, 0u};                                                                 \
             if (ok_) {                                                                                         \
                 const size_t off_ = ((size_t)(iy_ >> up) * a.Win + (ix_ >> up)) * a.Cin + cb_ * CBK + a_chunk[i_] * 8; \
@@ -296,11 +300,31 @@ __global__ void transpose_bf16_kernel(const uint16_t* __restrict__ in, uint16_t*
 
 // OIHW -> O(HW)I with O zero-padded to O_pad rows (WeightLoader.swift:495-497 does OIHW->OHWI)
 __global__ void oihw_to_ohwi_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int O, int I, int KK,
-                                    int O_pad) {
-    const int total = O_pad * KK * I;
+                                    int O_pad, int I_pad) {
+    const int total = O_pad * KK * I_pad;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int ci = i % I, tap = (i / I) % KK, o = i / (I * KK);
-        out[i] = (o < O) ? in[((size_t)o * I + ci) * KK + tap] : (uint16_t)0;
+        const int ci = i % I_pad, tap = (i / I_pad) % KK, o = i / (I_pad * KK);
+        out[i] = (o < O && ci < I) ? in[((size_t)o * I + ci) * KK + tap] : (uint16_t)0;
+    }
+}
+
+__global__ void nchw_to_nhwc_padded_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int C, int C_pad,
+                                           int64_t P) {
+    const int64_t total = P * C_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C_pad);
+        const int64_t p = i / C_pad;
+        out[i] = c < C ? f32_to_bf16_bits(in[(size_t)c * P + p]) : (uint16_t)0;
+    }
+}
+
+__global__ void nhwc_to_nchw_f32_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, int C, int c0, int n,
+                                        int64_t P) {
+    const int64_t total = P * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i % P;
+        const int c = (int)(i / P);
+        out[i] = bf16_bits_to_f32(in[(size_t)p * C + c0 + c]);
     }
 }
 
@@ -310,7 +334,9 @@ __global__ void oihw_to_ohwi_kernel(const uint16_t* __restrict__ in, uint16_t* _
 
 int launch_conv2d(hipStream_t stream, const ConvArgs& a) {
     if ((a.ks != 1 && a.ks != 3) || a.Cin % CBK != 0 || a.Cout <= 0 || a.Hin <= 0 || a.Win <= 0) return 1;
-    const int Ho = a.upsample ? 2 * a.Hin : a.Hin, Wo = a.upsample ? 2 * a.Win : a.Win;
+    if (a.downsample && (a.ks != 3 || a.upsample || (a.Hin & 1) || (a.Win & 1))) return 1;
+    const int Ho = a.upsample ? 2 * a.Hin : a.downsample ? a.Hin / 2 : a.Hin;
+    const int Wo = a.upsample ? 2 * a.Win : a.downsample ? a.Win / 2 : a.Win;
     const int P = Ho * Wo;
     const int tiles_m = (P + CBM - 1) / CBM;
     const int cout_pad = ((a.Cout + 31) / 32) * 32;
@@ -379,11 +405,27 @@ int launch_transpose_bf16(hipStream_t stream, const uint16_t* in, uint16_t* out,
     VK_DONE();
 }
 int launch_oihw_to_ohwi_bf16(hipStream_t stream, const uint16_t* in, uint16_t* out, int O, int I, int KH, int KW,
-                             int O_pad) {
-    const int total = O_pad * KH * KW * I;
-    if (total <= 0) return 1;
-    int blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(oihw_to_ohwi_kernel, dim3(blocks), dim3(256), 0, stream, in, out, O, I, KH * KW, O_pad);
+                             int O_pad, int I_pad) {
+    if (I_pad <= 0) I_pad = I;
+    if (O <= 0 || I <= 0 || O_pad < O || I_pad < I) return 1;
+    const int total = O_pad * KH * KW * I_pad;
+    const int blocks = (total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256;
+    hipLaunchKernelGGL(oihw_to_ohwi_kernel, dim3(blocks), dim3(256), 0, stream, in, out, O, I, KH * KW, O_pad, I_pad);
+    VK_DONE();
+}
+
+int launch_nchw_f32_to_nhwc_bf16_padded(hipStream_t stream, const float* in, uint16_t* out, int C, int C_pad, int H, int W) {
+    if (C <= 0 || C_pad < C || H <= 0 || W <= 0) return 1;
+    const int64_t total = (int64_t)H * W * C_pad;
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(nchw_to_nhwc_padded_kernel, dim3(blocks), dim3(256), 0, stream, in, out, C, C_pad, (int64_t)H * W);
+    VK_DONE();
+}
+
+int launch_nhwc_bf16_to_nchw_f32(hipStream_t stream, const uint16_t* in, float* out, int C, int c0, int n, int64_t P) {
+    if (C <= 0 || n <= 0 || c0 < 0 || c0 + n > C || P <= 0) return 1;
+    const int64_t total = P * n;
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(blocks), dim3(256), 0, stream, in, out, C, c0, n, P);
     VK_DONE();
 }

@@ -221,6 +221,25 @@ class Flux2Pipeline:
         m = torch.nn.functional.adaptive_avg_pool2d(m, (target_height // 16, target_width // 16))
         return (torch.round(m * 255.0) / 255.0).reshape(1, -1, 1)
 
+    def encode_image_to_packed_sequence(self, image, target_height: Optional[int] = None,
+                                        target_width: Optional[int] = None) -> torch.Tensor:
+        """`encodeImageToPackedSequence(_:targetHeight:targetWidth:samplePosterior: false)`
+        (+ChainHelpers.swift:75-103).  `image`: u8 [H,W,3] (numpy or tensor) or f32 [1,3,H,W] already in
+        [-1,1].  The reference resizes with CoreGraphics first; here the image must already have the
+        target size (resampling is host-side pre-processing outside the hot path)."""
+        if self.vae is None:
+            raise Flux2Error(L.ERR_NOT_LOADED, "VAE not loaded")
+        dev = self.ctx.device
+        x = torch.as_tensor(image)
+        if x.dtype == torch.uint8:
+            x = (x.to(dev).float() / 127.5 - 1.0).permute(2, 0, 1).unsqueeze(0).contiguous()   # Flux2Pipeline.swift:2408-2418
+        else:
+            x = x.to(dev, torch.float32).reshape(1, 3, x.shape[-2], x.shape[-1]).contiguous()
+        H, W = x.shape[-2], x.shape[-1]
+        if (target_height not in (None, H)) or (target_width not in (None, W)):
+            raise Flux2Error(L.ERR_SHAPE, f"image is {H}x{W}, target {target_height}x{target_width}: resize it first")
+        return self.vae.encode_to_packed(x)
+
     def clearAll(self):
         if self.transformer:
             self.transformer.close()

@@ -75,9 +75,9 @@ def dit_param_shapes(cfg: dict) -> List[Tuple[str, Tuple[int, ...], str]]:
     return out
 
 
-def vae_decoder_param_shapes(vcfg: dict) -> List[Tuple[str, Tuple[int, ...], str]]:
-    """(name, shape, kind) for the decoder side of AutoencoderKLFlux2; kind in
-    {conv, bias, gn_w, gn_b, linear, bn_mean, bn_var}."""
+def vae_decoder_param_shapes(vcfg: dict, encoder: bool = False) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """(name, shape, kind) for the decoder side of AutoencoderKLFlux2 (+ the encoder side when
+    `encoder`); kind in {conv, bias, gn_w, gn_b, linear, bn_mean, bn_var}."""
     ch = list(vcfg["channels"])
     L = vcfg["latent"]
     out: List[Tuple[str, Tuple[int, ...], str]] = []
@@ -120,6 +120,28 @@ def vae_decoder_param_shapes(vcfg: dict) -> List[Tuple[str, Tuple[int, ...], str
     conv("decoder.conv_out", 3, ch[0], 3)
     out.append(("bn.running_mean", (4 * L,), "bn_mean"))
     out.append(("bn.running_var", (4 * L,), "bn_var"))
+    if not encoder:
+        return out
+    # encoder side, appended AFTER the decoder list so that decoder values for a given seed do not
+    # depend on it (VAE/VAEEncoder.swift:26-85; diffusers keys, WeightLoader.swift:486-560)
+    conv("encoder.conv_in", ch[0], 3, 3)
+    prev = ch[0]
+    for i, co in enumerate(ch):
+        for j in range(vcfg["layers_per_block"]):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}.", prev if j == 0 else co, co)
+        prev = co
+        if i < len(ch) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", co, co, 3)
+    resnet("encoder.mid_block.resnets.0.", mid, mid)
+    a = "encoder.mid_block.attentions.0."
+    gn(a + "group_norm", mid)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        out.append((a + n + ".weight", (mid, mid), "linear"))
+        out.append((a + n + ".bias", (mid,), "bias"))
+    resnet("encoder.mid_block.resnets.1.", mid, mid)
+    gn("encoder.conv_norm_out", mid)
+    conv("encoder.conv_out", 2 * L, mid, 3)
+    conv("quant_conv", 2 * L, 2 * L, 1)
     return out
 
 
@@ -144,12 +166,12 @@ def make_dit_weights(cfg: dict, seed: int = 1234, device="cpu", std: float = 0.0
     return P
 
 
-def make_vae_weights(vcfg: dict, seed: int = 4321, device="cpu") -> Dict[str, torch.Tensor]:
+def make_vae_weights(vcfg: dict, seed: int = 4321, device="cpu", encoder: bool = True) -> Dict[str, torch.Tensor]:
     """conv ~ N(0, sqrt(2/fan_in)), linear ~ N(0, sqrt(1/in)), biases N(0, 0.05),
     GroupNorm weight 1+0.1N / bias 0.1N, BN mean N(0,0.5), var U(0.5,1.5)."""
     g = _gen(device, seed)
     P: Dict[str, torch.Tensor] = {}
-    for name, shape, kind in vae_decoder_param_shapes(vcfg):
+    for name, shape, kind in vae_decoder_param_shapes(vcfg, encoder=encoder):
         if kind == "bn_var":
             x = 0.5 + torch.rand(shape, generator=g, device=device, dtype=torch.float32)
         else:

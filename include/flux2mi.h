@@ -175,6 +175,15 @@ const float* flux2mi_vae_bn_var(const flux2mi_vae* vae);  /* device f32 [128] */
  *   out_u8   u8 [8h,8w,3] device or NULL: clip((x+1)*127.5,0,255), truncating cast */
 int flux2mi_vae_decode(flux2mi_vae* vae, const float* z, int h, int w, float* out_f32, uint8_t* out_u8);
 
+/* AutoencoderKLFlux2.encode(x, samplePosterior: false) (VAE/AutoencoderKL.swift:90-123,
+ * VAE/VAEEncoder.swift:88-118): image f32 [3,H,W] in [-1,1] (device; H, W multiples of 16) ->
+ * posterior mean f32 [32,H/8,W/8].  No scaling factor and no BatchNorm here: chain
+ * flux2mi_vae_latents_to_packed() for `encodeImageToPackedSequence`
+ * (Pipeline/Flux2Pipeline+ChainHelpers.swift:75-103).  The encoder tensors ("encoder.*",
+ * "quant_conv.*") are optional at load time; encode fails with FLUX2MI_ERR_NOT_LOADED without them. */
+int flux2mi_vae_encode(flux2mi_vae* vae, const float* image, int H, int W, float* z_mean);
+int flux2mi_vae_has_encoder(const flux2mi_vae* vae);
+
 /* ---- pipeline: Flux2Pipeline.generateWithResult hot section -------------- */
 /* Flux2StepContext (Pipeline/Flux2Pipeline.swift:42-57) */
 typedef struct flux2mi_step_context {

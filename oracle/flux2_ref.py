@@ -559,6 +559,46 @@ def vae_decode(P: Dict[str, Tensor], vcfg: dict, z: Tensor, taps: Optional[dict]
     return conv2d(x, P, "decoder.conv_out", 1)
 
 
+def downsample2x(x: Tensor, P: Dict[str, Tensor], pre: str) -> Tensor:
+    """ResnetBlock.swift:189-214: zero-pad bottom/right by one, conv3x3 stride 2, no other padding."""
+    x = F.pad(x, (0, 1, 0, 1))
+    return F.conv2d(x, P[pre + "conv.weight"].float(), P[pre + "conv.bias"].float(), stride=2)
+
+
+def vae_encode(P: Dict[str, Tensor], vcfg: dict, x: Tensor) -> Tensor:
+    """a23 — AutoencoderKL.swift:90-123 with samplePosterior = false + VAEEncoder.swift:88-118.
+    x [B,3,H,W] in [-1,1] -> posterior mean [B,32,H/8,W/8]; quant_conv applied; no scaling factor."""
+    groups = vcfg["groups"]
+    n = len(vcfg["channels"])
+    h = conv2d(x.float(), P, "encoder.conv_in", 1)
+    for i in range(n):
+        for j in range(vcfg["layers_per_block"]):
+            h = resnet_block(h, P, f"encoder.down_blocks.{i}.resnets.{j}.", groups)
+        if i < n - 1:
+            h = downsample2x(h, P, f"encoder.down_blocks.{i}.downsamplers.0.")
+    h = resnet_block(h, P, "encoder.mid_block.resnets.0.", groups)
+    h = vae_attention(h, P, "encoder.mid_block.attentions.0.", groups)
+    h = resnet_block(h, P, "encoder.mid_block.resnets.1.", groups)
+    h = F.silu(group_norm(h, P["encoder.conv_norm_out.weight"], P["encoder.conv_norm_out.bias"], groups))
+    h = conv2d(h, P, "encoder.conv_out", 1)
+    h = conv2d(h, P, "quant_conv", 0)
+    return h[:, :vcfg["latent"]]
+
+
+def preprocess_image_for_vae(image_u8_hwc: Tensor) -> Tensor:
+    """Flux2Pipeline.swift:2408-2418: u8 [H,W,3] -> f32 [1,3,H,W] = x / 127.5 - 1 (resize not restated)."""
+    return (image_u8_hwc.float() / 127.5 - 1.0).permute(2, 0, 1).unsqueeze(0)
+
+
+def encode_image_to_packed_sequence(P: Dict[str, Tensor], vcfg: dict, image: Tensor) -> Tensor:
+    """Flux2Pipeline+ChainHelpers.swift:75-103: encode (mean) -> patchify -> BN-normalise -> pack.
+    image f32 [1,3,H,W] -> [1, (H/16)(W/16), 128]."""
+    z = vae_encode(P, vcfg, image)
+    pt = pack_latents_to_patchified(z)
+    pt = normalize_latents_bn(pt, P["bn.running_mean"].float(), P["bn.running_var"].float())
+    return pack_patchified_to_sequence(pt)
+
+
 def postprocess_vae_output(x: Tensor) -> Tensor:
     """a24 — Flux2Pipeline.swift:2425-2468: clip((x+1)*127.5, 0, 255) -> TRUNCATING
     u8 cast -> [H,W,3]."""

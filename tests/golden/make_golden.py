@@ -16,6 +16,7 @@ from flux2mi import synthetic as syn  # noqa: E402
 from oracle import flux2_ref as R  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
+PROD_DIT_SLICE = dict(dim=3072, heads=24, n_double=1, n_single=1, joint_dim=7680, guidance=False)
 
 
 def main():
@@ -66,6 +67,26 @@ def main():
     dec = R.vae_decode(VP, vcfg, z, taps=vt)
     np.savez_compressed(os.path.join(OUT, "tiny_vae.npz"), decoded=dec[0].numpy().astype(np.float16),
                         image=R.postprocess_vae_output(dec).numpy(), mid=vt["mid"][0].numpy().astype(np.float16))
+    # ---- production-WIDTH slices: Klein-4B widths (d 3072, 24 heads, J 7680) with one
+    # double + one single block, and the standard VAE decoder widths [128,256,512,512] on an 8x8
+    # latent.  Weights are regenerated from the seed by the tests (synthetic.py), only I/O is stored.
+    pcfg = dict(PROD_DIT_SLICE)
+    PP = syn.make_dit_weights(pcfg, seed=2024)
+    pin = syn.make_inputs(pcfg, 128, 128, s_txt=32, noise_seed=5, txt_seed=6)
+    plat = R.pack_patchified_to_sequence(pin["noise"])
+    ptaps = {}
+    pout = R.dit_forward(PP, pcfg, plat, pin["txt"].float(), torch.tensor([0.4]), None,
+                         R.image_position_ids(128, 128), R.text_position_ids(32), taps=ptaps)
+    np.savez_compressed(os.path.join(OUT, "prod_dit_slice.npz"), forward_out=pout[0].numpy().astype(np.float32),
+                        double0_img=ptaps["double0.img"][0].numpy().astype(np.float16),
+                        single0=ptaps["single0"][0].numpy().astype(np.float16))
+    del PP
+    svcfg = syn.VAE_PRESETS["standard"]
+    SVP = syn.make_vae_weights(svcfg, seed=77)
+    z = torch.randn((1, 32, 8, 8), generator=torch.Generator().manual_seed(12))
+    sdec = R.vae_decode(SVP, svcfg, z)
+    np.savez_compressed(os.path.join(OUT, "prod_vae.npz"), decoded=sdec[0].numpy().astype(np.float16),
+                        image=R.postprocess_vae_output(sdec).numpy())
     print("golden fixtures written to", OUT)
 
 

@@ -66,3 +66,36 @@ def test_vae_vs_golden(flux2mi, ctx):
     assert _rel(of[0].cpu().numpy(), g["decoded"].astype(np.float32)) < 3e-2
     assert np.abs(ou.cpu().numpy().astype(int) - g["image"].astype(int)).mean() < 2.0
     vae.close()
+
+
+PROD_DIT_SLICE = dict(dim=3072, heads=24, n_double=1, n_single=1, joint_dim=7680, guidance=False)
+
+
+def test_production_width_dit_slice_vs_golden(flux2mi, ctx):
+    """Klein-4B widths (d 3072, 24 heads, J 7680; one double + one single block): the kernels at
+    their production K/N extents against the committed oracle output.  rel-L2 <= 2e-2."""
+    from flux2mi import api, synthetic as syn
+    from flux2mi.api import DiT
+    g = np.load("tests/golden/prod_dit_slice.npz")
+    dit = DiT(ctx, PROD_DIT_SLICE).load(syn.make_dit_weights(PROD_DIT_SLICE, seed=2024)).finalize()
+    inp = syn.make_inputs(PROD_DIT_SLICE, 128, 128, s_txt=32, noise_seed=5, txt_seed=6)
+    lat = ctx.pack_patchified_to_sequence(inp["noise"].cuda())
+    for weights, tol in (("bf16", 2e-2),):
+        out = dit.forward(lat[0], inp["txt"].cuda(), 0.4, 0.0, torch.from_numpy(api.image_position_ids(128, 128)).cuda(),
+                          torch.from_numpy(api.text_position_ids(32)).cuda())
+        assert _rel(out.cpu().numpy(), g["forward_out"]) < tol
+    dit.close()
+
+
+def test_production_width_vae_vs_golden(flux2mi, ctx):
+    """Standard VAE decoder widths [128,256,512,512] on an 8x8 latent -> 64x64 image."""
+    from flux2mi import synthetic as syn
+    from flux2mi.api import VAE
+    g = np.load("tests/golden/prod_vae.npz")
+    vcfg = syn.VAE_PRESETS["standard"]
+    vae = VAE(ctx, vcfg).load(syn.make_vae_weights(vcfg, seed=77)).finalize()
+    z = torch.randn((1, 32, 8, 8), generator=torch.Generator().manual_seed(12))
+    of, ou = vae.decode(z.cuda())
+    assert _rel(of[0].cpu().numpy(), g["decoded"].astype(np.float32)) < 3e-2
+    assert np.abs(ou.cpu().numpy().astype(int) - g["image"].astype(int)).mean() < 2.0
+    vae.close()

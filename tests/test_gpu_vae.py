@@ -59,3 +59,58 @@ def test_vae_small_decoder_channels(flux2mi, ctx):
 def test_vae_standard_decoder_channels(flux2mi, ctx):
     from flux2mi import synthetic as syn
     _check(*_decode_both(flux2mi, ctx, syn.VAE_PRESETS["standard"], 16, 16))
+
+
+# ---- encoder (VAE encoder + encodeImageToPackedSequence) ---------------------
+def _image(h, w, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    # smooth-ish image in [-1, 1]
+    x = torch.randn((1, 3, h // 8, w // 8), generator=g)
+    x = torch.nn.functional.interpolate(x, size=(h, w), mode="bilinear", align_corners=False)
+    return (x / x.abs().max()).contiguous()
+
+
+@pytest.mark.parametrize("variant,h,w", [("tiny", 64, 64), ("tiny", 96, 160), ("small", 64, 64)])
+def test_encode_vs_oracle(flux2mi, ctx, variant, h, w):
+    """Posterior mean of AutoencoderKLFlux2.encode: rel-L2 <= 3e-2 vs the f32 oracle (bf16 NHWC
+    activations, stride-2 convs with bottom/right padding, 3->32 channel padding of conv_in)."""
+    from flux2mi import synthetic as syn
+    from flux2mi.api import VAE
+    vcfg = syn.VAE_PRESETS[variant]
+    P = syn.make_vae_weights(vcfg, seed=21)
+    vae = VAE(ctx, vcfg).load(P).finalize()
+    assert vae.has_encoder
+    img = _image(h, w)
+    z = vae.encode(img.cuda()).cpu()
+    ref = R.vae_encode(P, vcfg, img)
+    assert z.shape == ref.shape == (1, 32, h // 8, w // 8)
+    assert rel_l2(z, ref) < 3e-2
+    packed = vae.encode_to_packed(img.cuda()).cpu()
+    assert rel_l2(packed, R.encode_image_to_packed_sequence(P, vcfg, img)) < 3e-2
+    vae.close()
+
+
+def test_encode_without_encoder_weights_fails_loudly(flux2mi, ctx):
+    from flux2mi import Flux2Error, synthetic as syn
+    from flux2mi.api import VAE
+    vcfg = syn.VAE_PRESETS["tiny"]
+    vae = VAE(ctx, vcfg).load(syn.make_vae_weights(vcfg, encoder=False)).finalize()   # decode-only checkpoint
+    assert not vae.has_encoder
+    with pytest.raises(Flux2Error):
+        vae.encode(torch.zeros((1, 3, 64, 64), device="cuda"))
+    of, _ = vae.decode(torch.zeros((1, 32, 8, 8), device="cuda"))
+    assert torch.isfinite(of).all()
+    vae.close()
+
+
+def test_encode_decode_roundtrip_shapes_via_pipeline(flux2mi, ctx):
+    """encode_image_to_packed_sequence feeds the RePaint chain: u8 image in, [1,S,128] out."""
+    from flux2mi import synthetic as syn
+    from flux2mi.pipeline import Flux2Pipeline
+    cfg, vcfg = syn.DIT_PRESETS["tiny"], syn.VAE_PRESETS["tiny"]
+    pipe = Flux2Pipeline(model=cfg, vae_variant=vcfg).load_models(syn.make_dit_weights(cfg), syn.make_vae_weights(vcfg))
+    img = (torch.rand((128, 128, 3), generator=torch.Generator().manual_seed(1)) * 255).to(torch.uint8)
+    packed = pipe.encode_image_to_packed_sequence(img, 128, 128)
+    assert packed.shape == (1, 64, 128) and torch.isfinite(packed).all()
+    ref = R.encode_image_to_packed_sequence(syn.make_vae_weights(vcfg), vcfg, R.preprocess_image_for_vae(img))
+    assert rel_l2(packed, ref) < 3e-2
