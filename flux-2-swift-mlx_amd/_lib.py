@@ -57,7 +57,7 @@ class GenerateParams(C.Structure):
         ("on_step", STEP_HOOK), ("on_step_user", C.c_void_p),
         ("on_progress", PROGRESS_CB), ("on_progress_user", C.c_void_p),
         ("on_checkpoint", CHECKPOINT_CB), ("on_checkpoint_user", C.c_void_p),
-        ("skip_decode", C.c_int),
+        ("skip_decode", C.c_int), ("use_kv_cache", C.c_int),
         ("out_image", C.c_void_p), ("out_latents", C.c_void_p),
         ("out_height", C.c_int), ("out_width", C.c_int), ("effective_steps", C.c_int),
         ("ms_denoise", C.c_float), ("ms_decode", C.c_float),
@@ -97,6 +97,10 @@ PROTOTYPES = {
     "flux2mi_dit_finalize": (_I, [_P]),
     "flux2mi_dit_param_bytes": (_I64, [_P]),
     "flux2mi_dit_forward": (_I, [_P, _P, _I, _P, _I, _F, _F, _P, _P, _P, _I]),
+    "flux2mi_kv_cache_create": (_I, [_P, _I, _I, C.POINTER(_P)]),
+    "flux2mi_kv_cache_destroy": (_I, [_P]),
+    "flux2mi_dit_forward_kv_extract": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _F, _F, _P, _P, _P, _P]),
+    "flux2mi_dit_forward_kv_cached": (_I, [_P, _P, _P, _I, _P, _I, _F, _F, _P, _P, _P]),
     "flux2mi_vae_preset": (_I, [C.c_char_p, C.POINTER(VaeConfig)]),
     "flux2mi_vae_create": (_I, [_P, C.POINTER(VaeConfig), C.POINTER(_P)]),
     "flux2mi_vae_destroy": (_I, [_P]),

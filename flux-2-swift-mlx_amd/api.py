@@ -286,9 +286,58 @@ class DiT:
         self.ctx._exit()
         return out
 
+    def forward_kv_extract(self, cache: "KVCache", latents, ref_latents, txt_emb, timestep: float, guidance: float,
+                           img_ids, txt_ids, ref_ids) -> torch.Tensor:
+        """`forwardKVExtract` (Flux2Transformer.swift:346-446): fills `cache`, returns f32 [S_out,128]."""
+        lat = _req(latents.reshape(-1, 128), torch.float32, "latents")
+        ref = _req(ref_latents.reshape(-1, 128), torch.float32, "ref_latents")
+        txt = _req(txt_emb.reshape(-1, txt_emb.shape[-1]), torch.bfloat16, "txt_emb")
+        ii, ti, ri = (_req(x, torch.int32, n) for x, n in ((img_ids, "img_ids"), (txt_ids, "txt_ids"), (ref_ids, "ref_ids")))
+        out = torch.empty((lat.shape[0], 128), dtype=torch.float32, device=lat.device)
+        self.ctx._enter()
+        check(lib().flux2mi_dit_forward_kv_extract(self.handle, cache.handle, _ptr(lat), lat.shape[0], _ptr(ref), ref.shape[0],
+                                                   _ptr(txt), txt.shape[0], timestep, guidance, _ptr(ii), _ptr(ti), _ptr(ri),
+                                                   _ptr(out)))
+        self.ctx._exit()
+        return out
+
+    def forward_kv_cached(self, cache: "KVCache", latents, txt_emb, timestep: float, guidance: float, img_ids,
+                          txt_ids) -> torch.Tensor:
+        """`forwardKVCached` (Flux2Transformer.swift:459-546)."""
+        lat = _req(latents.reshape(-1, 128), torch.float32, "latents")
+        txt = _req(txt_emb.reshape(-1, txt_emb.shape[-1]), torch.bfloat16, "txt_emb")
+        ii, ti = _req(img_ids, torch.int32, "img_ids"), _req(txt_ids, torch.int32, "txt_ids")
+        out = torch.empty((lat.shape[0], 128), dtype=torch.float32, device=lat.device)
+        self.ctx._enter()
+        check(lib().flux2mi_dit_forward_kv_cached(self.handle, cache.handle, _ptr(lat), lat.shape[0], _ptr(txt), txt.shape[0],
+                                                  timestep, guidance, _ptr(ii), _ptr(ti), _ptr(out)))
+        self.ctx._exit()
+        return out
+
     def close(self):
         if self.handle and self.ctx.handle:
             lib().flux2mi_dit_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class KVCache:
+    """`TransformerKVCache`: reference-token K/V of every block (flux2mi_kv_cache)."""
+
+    def __init__(self, dit: DiT, s_txt: int, s_ref: int):
+        self.dit = dit
+        h = C.c_void_p()
+        check(lib().flux2mi_kv_cache_create(dit.handle, s_txt, s_ref, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle and self.dit.handle and self.dit.ctx.handle:
+            lib().flux2mi_kv_cache_destroy(self.handle)
         self.handle = None
 
     def __del__(self):

@@ -34,8 +34,9 @@ constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ q,
                                                           const uint16_t* __restrict__ k, int ldqk,
                                                           const uint16_t* __restrict__ vt, int s_pad,
-                                                          uint16_t* __restrict__ out, int ldo, int S,
+                                                          uint16_t* __restrict__ out, int ldo, int Sq, int S,
                                                           float scale_log2e) {
+    // Sq query rows (q / out already point at the first of them), S keys (k / vt from key 0)
     __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE_BYTES];
 
     const int head = blockIdx.y;
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = l31][d = 16ks + 8hi + j]
     const int qrow = q0 + wid * 32 + l31;
-    const uint16_t* qp = q + (size_t)min(qrow, S - 1) * ldqk + head * HD + hi * 8;
+    const uint16_t* qp = q + (size_t)min(qrow, Sq - 1) * ldqk + head * HD + hi * 8;
     bf16x8 qf[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
     // ---- normalise and store.  o[db][r]: d = db*32 + (r&3) + 8*(r>>2) + 4*hi, query = l31
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
-    if (qrow < S) {
+    if (qrow < Sq) {
         uint16_t* op = out + (size_t)qrow * ldo + head * HD + hi * 4;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
@@ -225,11 +226,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 }  // namespace
 
 int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
-                     int s_pad, uint16_t* out, int ldo, int S, int heads) {
-    if (S <= 0 || heads <= 0 || (ldqk & 7) || (ldo & 3) || s_pad < attn_s_pad(S) || (s_pad & 7)) return 1;
+                     int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads) {
+    if (Sq <= 0 || S <= 0 || heads <= 0 || (ldqk & 7) || (ldo & 3) || s_pad < attn_s_pad(S) || (s_pad & 7)) return 1;
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
-    dim3 grid((S + BQ - 1) / BQ, heads);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, stream, q, k, ldqk, vt, s_pad, out, ldo, S,
+    dim3 grid((Sq + BQ - 1) / BQ, heads);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S,
                        scale_log2e);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

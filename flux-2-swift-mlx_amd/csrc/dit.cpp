@@ -440,19 +440,43 @@ int run_gemm(flux2mi_dit* m, const GemmProblem* p, int n, int extra_cls, const c
 
 }  // namespace
 
-extern "C" int flux2mi_dit_forward(flux2mi_dit* m, const float* latents, int s_img, const void* txt_emb, int s_txt,
-                                   float timestep, float guidance, const int32_t* img_ids, const int32_t* txt_ids,
-                                   float* out, int s_out) {
-    F2_REQUIRE(m && latents && txt_emb && img_ids && txt_ids && out, FLUX2MI_ERR_INVALID_ARG, "dit_forward: NULL argument");
-    F2_REQUIRE(m->finalized, FLUX2MI_ERR_NOT_LOADED, "dit_forward: weights not finalized");
-    F2_REQUIRE(s_img > 0 && s_txt > 0 && s_out > 0 && s_out <= s_img, FLUX2MI_ERR_SHAPE,
-               "dit_forward: s_img %d s_txt %d s_out %d", s_img, s_txt, s_out);
+// Reference-token K/V of every layer, written by the extraction pass and read by the cached passes
+// (Transformer/TransformerKVCache.swift).  Per layer: K post-RoPE [s_ref, d] bf16 and V^T
+// [heads*128, s_ref] bf16 in key order.  Layers: double blocks first, then single blocks.
+struct flux2mi_kv_cache {
+    flux2mi_dit* dit = nullptr;
+    int s_txt = 0, s_ref = 0;
+    bool filled = false;
+    uint16_t* data = nullptr;
+    size_t layer_elems = 0;   // 2 * s_ref * d
+    uint16_t* k(int layer) const { return data + (size_t)layer * layer_elems; }
+    uint16_t* v(int layer) const { return data + (size_t)layer * layer_elems + layer_elems / 2; }
+};
+
+namespace {
+
+enum FwdMode { FWD_PLAIN = 0, FWD_KV_EXTRACT = 1, FWD_KV_CACHED = 2 };
+
+// Joint row layout of one forward:
+//   plain       [ txt | image tokens (output first, appended references after) ]
+//   kv extract  [ txt | ref | out ]   reference queries see keys [txt | ref] only (Flux2Attention.swift:296-306)
+//   kv cached   [ txt | gap | out ]   the gap keeps the rows of the extraction pass: its K rows / V^T
+//                                     columns are filled from the cache, nothing else touches it
+// so position ids, RoPE rows and key indices are the same in both KV passes.
+int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const float* latents, int s_lat,
+                     const float* ref_latents, int s_ref, const void* txt_emb, int s_txt, float timestep,
+                     float guidance, const int32_t* img_ids, const int32_t* txt_ids, const int32_t* ref_ids, float* out,
+                     int s_out) {
     F2_CHECK_HIP(hipSetDevice(m->ctx->device));
     hipStream_t st = m->ctx->stream;
     const int d = m->cfg.dim, H = m->cfg.heads, J = m->cfg.joint_dim;
-    const int S = s_txt + s_img;
+    const int gap = mode == FWD_PLAIN ? 0 : s_ref;            // rows between the text and the live image rows
+    const int S = s_txt + gap + s_lat;                         // rows of the layout (= keys of the attention)
+    const int img0 = mode == FWD_KV_CACHED ? s_txt + gap : s_txt;   // first live image-stream row
+    const int n_img = S - img0;                                // live image-stream rows
+    const int out0 = mode == FWD_PLAIN ? s_txt : s_txt + gap;  // first output row
     const int s_pad = attn_s_pad(S);
-    F2_TRY(ensure_workspace(m, S, s_img));
+    F2_TRY(ensure_workspace(m, S, S - s_txt));
 
     float* hs = m->hs.as<float>();
     uint16_t* xn = m->xn.as<uint16_t>();
@@ -485,16 +509,33 @@ extern "C" int flux2mi_dit_forward(flux2mi_dit* m, const float* latents, int s_i
     F2_LAUNCH(launch_gemv(st, m->mod_txt, temb, mod_txt, 6 * d, d, 1, 0), "mod_txt");
     F2_LAUNCH(launch_gemv(st, m->mod_single, temb, mod_sgl, 3 * d, d, 1, 0), "mod_single");
     F2_LAUNCH(launch_gemv(st, m->final_mod, temb, mod_fin, 2 * d, d, 1, 0), "final_mod");
-    // ---- RoPE tables from the ids of this call (Flux2Transformer.swift:153-154)
-    F2_LAUNCH(launch_rope_tables(st, txt_ids, s_txt, img_ids, s_img, cos_tab, sin_tab), "rope_tables");
+    // ---- RoPE tables from the ids of this call (Flux2Transformer.swift:153-154, :370-371)
+    if (mode == FWD_PLAIN) {
+        F2_LAUNCH(launch_rope_tables(st, txt_ids, s_txt, img_ids, s_lat, cos_tab, sin_tab), "rope_tables");
+    } else {
+        // [txt | ref] rows (the gap rows of a cached pass get their ids too when given; unused otherwise)
+        if (mode == FWD_KV_EXTRACT) {
+            F2_LAUNCH(launch_rope_tables(st, txt_ids, s_txt, ref_ids, s_ref, cos_tab, sin_tab), "rope_tables(txt,ref)");
+        } else {
+            F2_LAUNCH(launch_rope_tables(st, txt_ids, s_txt, img_ids, 0, cos_tab, sin_tab), "rope_tables(txt)");
+        }
+        F2_LAUNCH(launch_rope_tables(st, txt_ids, 0, img_ids, s_lat, cos_tab + (size_t)out0 * 128, sin_tab + (size_t)out0 * 128),
+                  "rope_tables(out)");
+    }
 
-    // ---- input projections into the joint residual stream [txt ; img] (:137-138)
-    F2_LAUNCH(launch_f32_to_bf16(st, latents, m->lat_bf16.as<uint16_t>(), (int64_t)s_img * 128), "latents->bf16");
+    // ---- input projections into the joint residual stream (:137-138, :357-362)
+    F2_LAUNCH(launch_f32_to_bf16(st, latents, m->lat_bf16.as<uint16_t>(), (int64_t)s_lat * 128), "latents->bf16");
     {
         GemmProblem p[2];
         p[0] = mk(reinterpret_cast<const uint16_t*>(txt_emb), J, m->txt_in, J, hs, d, s_txt, d, J, EPI_F32);
-        p[1] = mk(m->lat_bf16.as<uint16_t>(), 128, m->img_in, 128, hs + (size_t)s_txt * d, d, s_img, d, 128, EPI_F32);
+        p[1] = mk(m->lat_bf16.as<uint16_t>(), 128, m->img_in, 128, hs + (size_t)out0 * d, d, s_lat, d, 128, EPI_F32);
         F2_TRY(run_gemm(m, p, 2, 0, "embedders"));
+    }
+    if (mode == FWD_KV_EXTRACT) {
+        uint16_t* rb = m->lat_bf16.as<uint16_t>() + (size_t)s_lat * 128;
+        F2_LAUNCH(launch_f32_to_bf16(st, ref_latents, rb, (int64_t)s_ref * 128), "ref latents->bf16");
+        GemmProblem p = mk(rb, 128, m->img_in, 128, hs + (size_t)s_txt * d, d, s_ref, d, 128, EPI_F32);
+        F2_TRY(run_gemm(m, &p, 1, 0, "embedder(ref)"));
     }
 
     // fp8 mode: the block GEMMs read their A operand from xq (e4m3, same [row, ld] layout as the
@@ -516,49 +557,84 @@ extern "C" int flux2mi_dit_forward(flux2mi_dit* m, const float* latents, int s_i
         }
         return p;
     };
-    auto ln_mod = [&](int split, const float* sh0, const float* sc0, const float* sh1, const float* sc1) {
-        return f8 ? launch_layernorm_modulate_fp8(st, hs, xq, xs, S, d, split, sh0, sc0, sh1, sc1)
-                  : launch_layernorm_modulate(st, hs, xn, S, d, split, sh0, sc0, sh1, sc1);
+    // LayerNorm + modulate of the text rows with (sh0, sc0) and of the live image rows with (sh1, sc1)
+    auto ln_mod = [&](const float* sh0, const float* sc0, const float* sh1, const float* sc1) {
+        if (img0 == s_txt) {
+            return f8 ? launch_layernorm_modulate_fp8(st, hs, xq, xs, S, d, s_txt, sh0, sc0, sh1, sc1)
+                      : launch_layernorm_modulate(st, hs, xn, S, d, s_txt, sh0, sc0, sh1, sc1);
+        }
+        const size_t o = (size_t)img0 * d;
+        const int r = f8 ? launch_layernorm_modulate_fp8(st, hs, xq, xs, s_txt, d, s_txt, sh0, sc0, sh0, sc0)
+                         : launch_layernorm_modulate(st, hs, xn, s_txt, d, s_txt, sh0, sc0, sh0, sc0);
+        if (r) return r;
+        return f8 ? launch_layernorm_modulate_fp8(st, hs + o, xq + o, xs + img0, n_img, d, 0, sh1, sc1, sh1, sc1)
+                  : launch_layernorm_modulate(st, hs + o, xn + o, n_img, d, 0, sh1, sc1, sh1, sc1);
     };
     // quantise rows of a bf16 activation into xq/xs before the GEMM that consumes it (fp8 only)
     auto quant = [&](const uint16_t* a, int ld, int cols) {
         return f8 ? launch_quantize_rows_fp8(st, a, ld, xq, ld, xs, S, cols) : 0;
+    };
+    // joint attention per query range; keys = all S rows except for the reference queries of the
+    // extraction pass, which see [txt | ref] only.  Also moves the reference K / V^T to / from the cache.
+    auto attend = [&](int layer, uint16_t* o_buf, int ldo) -> int {
+        if (mode == FWD_KV_EXTRACT) {
+            F2_CHECK_HIP(hipMemcpy2DAsync(cache->k(layer), (size_t)d * 2, qkv + (size_t)s_txt * 3 * d + d, (size_t)3 * d * 2,
+                                          (size_t)d * 2, (size_t)s_ref, hipMemcpyDeviceToDevice, st));
+            F2_LAUNCH(launch_vt_keys_copy(st, vt, s_pad, cache->v(layer), H, s_txt, s_ref, 1), "kv_cache(V^T out)");
+        } else if (mode == FWD_KV_CACHED) {
+            F2_CHECK_HIP(hipMemcpy2DAsync(qkv + (size_t)s_txt * 3 * d + d, (size_t)3 * d * 2, cache->k(layer), (size_t)d * 2,
+                                          (size_t)d * 2, (size_t)s_ref, hipMemcpyDeviceToDevice, st));
+            F2_LAUNCH(launch_vt_keys_copy(st, vt, s_pad, cache->v(layer), H, s_txt, s_ref, 0), "kv_cache(V^T in)");
+        }
+        struct Range { int q0, nq, nk; } rg[3];
+        int nr = 0;
+        if (mode == FWD_PLAIN) rg[nr++] = {0, S, S};
+        else {
+            rg[nr++] = {0, s_txt, S};
+            if (mode == FWD_KV_EXTRACT) rg[nr++] = {s_txt, s_ref, s_txt + s_ref};
+            rg[nr++] = {out0, s_lat, S};
+        }
+        for (int i = 0; i < nr; ++i) {
+            prof_before(m->ctx, PROF_ATTENTION);
+            const int ar = launch_attention(st, qkv + (size_t)rg[i].q0 * 3 * d, qkv + d, 3 * d, vt, s_pad,
+                                            o_buf + (size_t)rg[i].q0 * ldo, ldo, rg[i].nq, rg[i].nk, H);
+            prof_after(m->ctx, PROF_ATTENTION, 4.0 * (double)rg[i].nq * rg[i].nk * d);
+            F2_LAUNCH(ar, "attention");
+        }
+        return FLUX2MI_OK;
     };
 
     // ---- double-stream blocks (Flux2TransformerBlock.swift:80-168)
     for (int i = 0; i < m->cfg.n_double; ++i) {
         const flux2mi_dit::Dbl& w = m->dbl[i];
         // attention half: LN -> modulate(set 0) per stream
-        F2_LAUNCH(ln_mod(s_txt, mod_txt + 0 * d, mod_txt + 1 * d, mod_img + 0 * d, mod_img + 1 * d), "ln_mod(attn)");
+        F2_LAUNCH(ln_mod(mod_txt + 0 * d, mod_txt + 1 * d, mod_img + 0 * d, mod_img + 1 * d), "ln_mod(attn)");
         {
             GemmProblem p[2];
             p[0] = blk(xn, d, 0, w.qkv[0], qkv, 3 * d, s_txt, 3 * d, d, EPI_BF16);
-            p[1] = blk(xn, d, s_txt, w.qkv[1], qkv + (size_t)s_txt * 3 * d, 3 * d, s_img, 3 * d, d, EPI_BF16);
+            p[1] = blk(xn, d, img0, w.qkv[1], qkv + (size_t)img0 * 3 * d, 3 * d, n_img, 3 * d, d, EPI_BF16);
             F2_TRY(run_gemm(m, p, 2, 0, "dbl.qkv"));
         }
         F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, s_txt, w.qn[0], w.kn[0], w.qn[1], w.kn[1], cos_tab, sin_tab,
                                          vt, s_pad), "qk_norm_rope");
-        prof_before(m->ctx, PROF_ATTENTION);
-        const int ar = launch_attention(st, qkv, qkv + d, 3 * d, vt, s_pad, comb, d, S, H);
-        prof_after(m->ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
-        F2_LAUNCH(ar, "attention");
+        F2_TRY(attend(i, comb, d));
         F2_LAUNCH(quant(comb, d, d), "quantize(attn out)");
         {
             GemmProblem p[2];
             p[0] = blk(comb, d, 0, w.proj[0], hs, d, s_txt, d, d, EPI_GATE_RESID);
             p[0].vec = mod_txt + 2 * d;
-            p[1] = blk(comb, d, s_txt, w.proj[1], hs + (size_t)s_txt * d, d, s_img, d, d, EPI_GATE_RESID);
+            p[1] = blk(comb, d, img0, w.proj[1], hs + (size_t)img0 * d, d, n_img, d, d, EPI_GATE_RESID);
             p[1].vec = mod_img + 2 * d;
             F2_TRY(run_gemm(m, p, 2, 0, "dbl.proj"));
         }
         // feed-forward half: LN -> modulate(set 1) -> Linear(d->6d) SwiGLU -> Linear(3d->d)
-        F2_LAUNCH(ln_mod(s_txt, mod_txt + 3 * d, mod_txt + 4 * d, mod_img + 3 * d, mod_img + 4 * d), "ln_mod(ff)");
+        F2_LAUNCH(ln_mod(mod_txt + 3 * d, mod_txt + 4 * d, mod_img + 3 * d, mod_img + 4 * d), "ln_mod(ff)");
         {
             GemmProblem p[2];
             p[0] = blk(xn, d, 0, w.mlp_in[0], nullptr, 0, s_txt, 6 * d, d, EPI_SWIGLU);
             p[0].C2 = comb; p[0].ldc2 = 3 * d;
-            p[1] = blk(xn, d, s_txt, w.mlp_in[1], nullptr, 0, s_img, 6 * d, d, EPI_SWIGLU);
-            p[1].C2 = comb + (size_t)s_txt * 3 * d; p[1].ldc2 = 3 * d;
+            p[1] = blk(xn, d, img0, w.mlp_in[1], nullptr, 0, n_img, 6 * d, d, EPI_SWIGLU);
+            p[1].C2 = comb + (size_t)img0 * 3 * d; p[1].ldc2 = 3 * d;
             F2_TRY(run_gemm(m, p, 2, 0, "dbl.mlp_in"));
         }
         F2_LAUNCH(quant(comb, 3 * d, 3 * d), "quantize(ff hidden)");
@@ -566,46 +642,125 @@ extern "C" int flux2mi_dit_forward(flux2mi_dit* m, const float* latents, int s_i
             GemmProblem p[2];
             p[0] = blk(comb, 3 * d, 0, w.mlp_out[0], hs, d, s_txt, d, 3 * d, EPI_GATE_RESID);
             p[0].vec = mod_txt + 5 * d;
-            p[1] = blk(comb, 3 * d, s_txt, w.mlp_out[1], hs + (size_t)s_txt * d, d, s_img, d, 3 * d, EPI_GATE_RESID);
+            p[1] = blk(comb, 3 * d, img0, w.mlp_out[1], hs + (size_t)img0 * d, d, n_img, d, 3 * d, EPI_GATE_RESID);
             p[1].vec = mod_img + 5 * d;
             F2_TRY(run_gemm(m, p, 2, 0, "dbl.mlp_out"));
         }
     }
 
     // ---- single-stream blocks on the concatenated stream (Flux2SingleBlock.swift:59-98,
-    // Flux2ParallelAttention.swift:72-123)
+    // Flux2ParallelAttention.swift:72-123); with a gap the two live row ranges are two problems
+    // on the same weights
+    const int n_rng = img0 == s_txt ? 1 : 2;
+    const int rng0[2] = {0, img0}, rngn[2] = {img0 == s_txt ? S : s_txt, n_img};
     for (int i = 0; i < m->cfg.n_single; ++i) {
         const flux2mi_dit::Sgl& w = m->sgl[i];
-        F2_LAUNCH(ln_mod(0, mod_sgl, mod_sgl + d, mod_sgl, mod_sgl + d), "ln_mod(single)");
+        F2_LAUNCH(ln_mod(mod_sgl, mod_sgl + d, mod_sgl, mod_sgl + d), "ln_mod(single)");
         {
-            GemmProblem p = blk(xn, d, 0, w.lin1, qkv, 3 * d, S, 9 * d, d, EPI_QKV_MLP);
-            p.n_split = 3 * d;
-            p.C2 = comb + d;  // SwiGLU hidden goes to columns d..4d of comb
-            p.ldc2 = 4 * d;
-            F2_TRY(run_gemm(m, &p, 1, PROF_LINEAR1, "single.linear1"));
+            GemmProblem p[2];
+            for (int r = 0; r < n_rng; ++r) {
+                p[r] = blk(xn, d, rng0[r], w.lin1, qkv + (size_t)rng0[r] * 3 * d, 3 * d, rngn[r], 9 * d, d, EPI_QKV_MLP);
+                p[r].n_split = 3 * d;
+                p[r].C2 = comb + (size_t)rng0[r] * 4 * d + d;  // SwiGLU hidden goes to columns d..4d of comb
+                p[r].ldc2 = 4 * d;
+            }
+            F2_TRY(run_gemm(m, p, n_rng, PROF_LINEAR1, "single.linear1"));
         }
         F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, 0, w.qn, w.kn, w.qn, w.kn, cos_tab, sin_tab, vt, s_pad),
                   "qk_norm_rope");
-        prof_before(m->ctx, PROF_ATTENTION);
-        const int ar = launch_attention(st, qkv, qkv + d, 3 * d, vt, s_pad, comb, 4 * d, S, H);
-        prof_after(m->ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
-        F2_LAUNCH(ar, "attention");
+        F2_TRY(attend(m->cfg.n_double + i, comb, 4 * d));
         F2_LAUNCH(quant(comb, 4 * d, 4 * d), "quantize(attn | ff hidden)");
         {
-            GemmProblem p = blk(comb, 4 * d, 0, w.lin2, hs, d, S, d, 4 * d, EPI_GATE_RESID);
-            p.vec = mod_sgl + 2 * d;
-            F2_TRY(run_gemm(m, &p, 1, 0, "single.linear2"));
+            GemmProblem p[2];
+            for (int r = 0; r < n_rng; ++r) {
+                p[r] = blk(comb, 4 * d, rng0[r], w.lin2, hs + (size_t)rng0[r] * d, d, rngn[r], d, 4 * d, EPI_GATE_RESID);
+                p[r].vec = mod_sgl + 2 * d;
+            }
+            F2_TRY(run_gemm(m, p, n_rng, 0, "single.linear2"));
         }
     }
 
-    // ---- output: drop text tokens, AdaLayerNormContinuous, proj_out (:316-324)
-    F2_LAUNCH(launch_layernorm_modulate(st, hs + (size_t)s_txt * d, xn, s_out, d, 0, mod_fin, mod_fin + d, mod_fin, mod_fin + d),
+    // ---- output: drop text (and reference) tokens, AdaLayerNormContinuous, proj_out (:316-324, :444-452)
+    F2_LAUNCH(launch_layernorm_modulate(st, hs + (size_t)out0 * d, xn, s_out, d, 0, mod_fin, mod_fin + d, mod_fin, mod_fin + d),
               "ln_mod(final)");
     {
         GemmProblem p = mk(xn, d, m->final_lin, d, out, 128, s_out, 128, d, EPI_F32);
         F2_TRY(run_gemm(m, &p, 1, 0, "proj_out"));
     }
+    if (mode == FWD_KV_EXTRACT) cache->filled = true;
     return FLUX2MI_OK;
+}
+
+}  // namespace
+
+extern "C" int flux2mi_dit_forward(flux2mi_dit* m, const float* latents, int s_img, const void* txt_emb, int s_txt,
+                                   float timestep, float guidance, const int32_t* img_ids, const int32_t* txt_ids,
+                                   float* out, int s_out) {
+    F2_REQUIRE(m && latents && txt_emb && img_ids && txt_ids && out, FLUX2MI_ERR_INVALID_ARG, "dit_forward: NULL argument");
+    F2_REQUIRE(m->finalized, FLUX2MI_ERR_NOT_LOADED, "dit_forward: weights not finalized");
+    F2_REQUIRE(s_img > 0 && s_txt > 0 && s_out > 0 && s_out <= s_img, FLUX2MI_ERR_SHAPE,
+               "dit_forward: s_img %d s_txt %d s_out %d", s_img, s_txt, s_out);
+    return dit_forward_impl(m, FWD_PLAIN, nullptr, latents, s_img, nullptr, 0, txt_emb, s_txt, timestep, guidance, img_ids,
+                            txt_ids, nullptr, out, s_out);
+}
+
+// ------------------------------------------------------------------ KV-cached reference conditioning
+extern "C" int flux2mi_kv_cache_create(flux2mi_dit* m, int s_txt, int s_ref, flux2mi_kv_cache** out) {
+    F2_REQUIRE(m && out && s_txt > 0 && s_ref > 0, FLUX2MI_ERR_INVALID_ARG, "kv_cache_create: bad argument");
+    F2_CHECK_HIP(hipSetDevice(m->ctx->device));
+    flux2mi_kv_cache* c = new flux2mi_kv_cache();
+    c->dit = m;
+    c->s_txt = s_txt;
+    c->s_ref = s_ref;
+    c->layer_elems = (size_t)2 * s_ref * m->cfg.dim;
+    const size_t bytes = c->layer_elems * (size_t)(m->cfg.n_double + m->cfg.n_single) * 2;
+    hipError_t e = hipMalloc((void**)&c->data, bytes);
+    if (e != hipSuccess) {
+        flux2mi_set_error("kv_cache_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        delete c;
+        return FLUX2MI_ERR_OOM;
+    }
+    *out = c;
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_kv_cache_destroy(flux2mi_kv_cache* c) {
+    if (!c) return FLUX2MI_OK;
+    (void)hipSetDevice(c->dit->ctx->device);
+    (void)hipStreamSynchronize(c->dit->ctx->stream);
+    if (c->data) (void)hipFree(c->data);
+    delete c;
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_dit_forward_kv_extract(flux2mi_dit* m, flux2mi_kv_cache* cache, const float* latents, int s_out,
+                                              const float* ref_latents, int s_ref, const void* txt_emb, int s_txt,
+                                              float timestep, float guidance, const int32_t* img_ids,
+                                              const int32_t* txt_ids, const int32_t* ref_ids, float* out) {
+    F2_REQUIRE(m && cache && latents && ref_latents && txt_emb && img_ids && txt_ids && ref_ids && out, FLUX2MI_ERR_INVALID_ARG,
+               "dit_forward_kv_extract: NULL argument");
+    F2_REQUIRE(m->finalized, FLUX2MI_ERR_NOT_LOADED, "dit_forward_kv_extract: weights not finalized");
+    F2_REQUIRE(cache->dit == m && cache->s_txt == s_txt && cache->s_ref == s_ref && s_out > 0, FLUX2MI_ERR_SHAPE,
+               "dit_forward_kv_extract: cache was created for s_txt %d s_ref %d, call has %d / %d", cache->s_txt,
+               cache->s_ref, s_txt, s_ref);
+    // the bf16 copy of the latents also holds the reference latents in this pass
+    F2_TRY(m->lat_bf16.reserve((size_t)(s_out + s_ref) * 128 * 2));
+    return dit_forward_impl(m, FWD_KV_EXTRACT, cache, latents, s_out, ref_latents, s_ref, txt_emb, s_txt, timestep, guidance,
+                            img_ids, txt_ids, ref_ids, out, s_out);
+}
+
+extern "C" int flux2mi_dit_forward_kv_cached(flux2mi_dit* m, flux2mi_kv_cache* cache, const float* latents, int s_out,
+                                             const void* txt_emb, int s_txt, float timestep, float guidance,
+                                             const int32_t* img_ids, const int32_t* txt_ids, float* out) {
+    F2_REQUIRE(m && cache && latents && txt_emb && img_ids && txt_ids && out, FLUX2MI_ERR_INVALID_ARG,
+               "dit_forward_kv_cached: NULL argument");
+    F2_REQUIRE(m->finalized, FLUX2MI_ERR_NOT_LOADED, "dit_forward_kv_cached: weights not finalized");
+    // the reference aborts here (fatalError, Flux2Transformer.swift:488); this returns a status
+    F2_REQUIRE(cache->filled, FLUX2MI_ERR_NOT_LOADED, "dit_forward_kv_cached: the cache has not been filled by an extraction pass");
+    F2_REQUIRE(cache->dit == m && cache->s_txt == s_txt && s_out > 0, FLUX2MI_ERR_SHAPE,
+               "dit_forward_kv_cached: cache was created for s_txt %d, call has %d", cache->s_txt, s_txt);
+    return dit_forward_impl(m, FWD_KV_CACHED, cache, latents, s_out, nullptr, cache->s_ref, txt_emb, s_txt, timestep, guidance,
+                            img_ids, txt_ids, nullptr, out, s_out);
 }
 
 // ------------------------------------------------------------------ standalone ops (tests, microbenchmarks)
@@ -650,7 +805,7 @@ extern "C" int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv_in, void* 
               "v_transpose");
     const uint16_t* q = reinterpret_cast<const uint16_t*>(qkv_in);
     prof_before(ctx, PROF_ATTENTION);
-    const int r = launch_attention(ctx->stream, q, q + d, 3 * d, vt, s_pad, reinterpret_cast<uint16_t*>(out), d, S, heads);
+    const int r = launch_attention(ctx->stream, q, q + d, 3 * d, vt, s_pad, reinterpret_cast<uint16_t*>(out), d, S, S, heads);
     prof_after(ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
     F2_LAUNCH(r, "op_attention");
     return FLUX2MI_OK;

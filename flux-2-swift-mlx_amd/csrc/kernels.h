@@ -43,8 +43,10 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob);
 // Joint (text+image) non-causal attention, head_dim 128, bf16 in/out, f32 softmax.
 //   q, k: bf16, row s at (q + s*ldqk + head*128); vt: bf16 [heads][128][s_pad] with the
 //   key-permuted layout produced by launch_qk_norm_rope_vt; out row s at out + s*ldo + head*128.
+// Sq query rows starting at q / out, S keys starting at k / column 0 of vt (Sq == S: plain self-attention;
+// the KV-cache paths launch it per query range, and with S = the key prefix a range may see).
 int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
-                     int s_pad, uint16_t* out, int ldo, int S, int heads);
+                     int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads);
 static inline int attn_s_pad(int S) { return ((S + 63) / 64) * 64; }
 
 // ---------------------------------------------------------------- norms / rope (norm.hip)
@@ -73,6 +75,11 @@ int launch_v_transpose_only(hipStream_t stream, const uint16_t* qkv, int ldqkv, 
                             int s_pad);
 // cos/sin f32 [S,128] from position ids i32 [S,4] (Flux2RoPE.swift:129-169); rows [0,s_txt)
 // come from txt_ids, the rest from img_ids.
+// Copy the V^T columns of keys [key0, key0 + nkeys) between the attention operand vt
+// ([heads*128][s_pad], keys permuted inside groups of 16) and a compact key-ordered cache
+// [heads*128][nkeys]; to_cache = 1: vt -> cache, 0: cache -> vt.  (TransformerKVCache.swift)
+int launch_vt_keys_copy(hipStream_t stream, uint16_t* vt, int s_pad, uint16_t* cache, int heads, int key0, int nkeys,
+                        int to_cache);
 int launch_rope_tables(hipStream_t stream, const int32_t* txt_ids, int s_txt, const int32_t* img_ids, int s_img,
                        float* cos_tab, float* sin_tab);
 

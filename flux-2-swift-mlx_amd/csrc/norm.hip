@@ -276,6 +276,21 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __rest
     }
 }
 
+// Reference-token V^T columns <-> compact cache (see kernels.h).  Thread = one (row, key).
+__global__ __launch_bounds__(256) void vt_keys_copy_kernel(uint16_t* __restrict__ vt, int s_pad, uint16_t* __restrict__ cache,
+                                                           long rows, int key0, int nkeys, int to_cache) {
+    const long total = rows * nkeys;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % nkeys);
+        const long row = i / nkeys;
+        const int key = key0 + kk;
+        const int o = key & 15;                                  // key offset 8a + 4h + b is stored at 8h + 4a + b
+        const int col = (key & ~15) | (((o >> 2) & 1) << 3) | ((o >> 3) << 2) | (o & 3);
+        if (to_cache) cache[i] = vt[row * s_pad + col];
+        else vt[row * s_pad + col] = cache[i];
+    }
+}
+
 // ------------------------------------------------------------------ RoPE tables
 // cos/sin [S,128]: axis a (0..3) covers columns 32a..32a+31; pair j (0..15) of an axis uses
 // omega = theta^(-2j/32), theta = 2000, value repeated for columns 2j, 2j+1.
@@ -341,6 +356,16 @@ int launch_v_transpose_only(hipStream_t stream, const uint16_t* qkv, int ldqkv, 
     if (S <= 0 || heads <= 0 || (ldqkv & 7) || s_pad < attn_s_pad(S)) return 1;
     hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, heads), dim3(256), 0, stream, qkv, ldqkv, S, heads,
                        vt, s_pad);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_vt_keys_copy(hipStream_t stream, uint16_t* vt, int s_pad, uint16_t* cache, int heads, int key0, int nkeys,
+                        int to_cache) {
+    if (heads <= 0 || key0 < 0 || nkeys <= 0 || key0 + nkeys > s_pad) return 1;
+    const long total = (long)heads * 128 * nkeys;
+    const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(vt_keys_copy_kernel, dim3(blocks), dim3(256), 0, stream, vt, s_pad, cache, (long)heads * 128, key0,
+                       nkeys, to_cache);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -118,7 +118,17 @@ extern "C" int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae*
     F2_CHECK_HIP(hipEventCreate(&ev0));
     F2_CHECK_HIP(hipEventCreate(&ev1));
     F2_CHECK_HIP(hipEventCreate(&ev2));
-    auto cleanup = [&]() { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(ev2); };
+    flux2mi_kv_cache* kv = nullptr;
+    if (p->use_kv_cache) {
+        F2_REQUIRE(s_ref > 0, FLUX2MI_ERR_INVALID_ARG, "generate: use_kv_cache needs reference latents");
+        F2_REQUIRE(!use_cfg, FLUX2MI_ERR_UNSUPPORTED, "generate: use_kv_cache with classical CFG (the reference's KV path has none)");
+        F2_TRY(flux2mi_kv_cache_create(dit, p->s_txt, s_ref, &kv));
+    }
+    auto cleanup = [&]() {
+        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(ev2);
+        if (kv) (void)flux2mi_kv_cache_destroy(kv);
+        kv = nullptr;
+    };
 #define GEN_TRY(expr) do { int _s = (expr); if (_s != FLUX2MI_OK) { cleanup(); return _s; } } while (0)
 
     std::vector<uint8_t> ckpt_host;
@@ -126,12 +136,24 @@ extern "C" int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae*
     // ---- "6. Denoising Loop" (:1933-2052)
     for (int k = 0; k < n_steps; ++k) {
         const float sigma = sigmas[k], sigma_next = sigmas[k + 1];
-        if (s_ref)  // per-step concat [out ; ref] (:1703)
+        if (s_ref && !kv)  // per-step concat [out ; ref] (:1703)
             if (hipMemcpyAsync(g.lat_in.ptr, packed, (size_t)n_lat * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
                 cleanup();
                 flux2mi_set_error("generate: concat copy failed");
                 return FLUX2MI_ERR_HIP;
             }
+        if (kv) {
+            // KV-cached reference conditioning (Flux2Pipeline.swift:1555-1682): step 0 runs
+            // [txt | ref | out] and stores the reference K/V of every layer, later steps run
+            // [txt | out] against the stored K/V
+            if (k == 0)
+                GEN_TRY(flux2mi_dit_forward_kv_extract(dit, kv, packed, S_img, p->ref_latents, s_ref, p->txt_emb, p->s_txt, sigma,
+                                                       p->guidance, g.ids_img.as<int32_t>(), g.ids_txt.as<int32_t>(),
+                                                       g.ids_img.as<int32_t>() + (size_t)S_img * 4, v));
+            else
+                GEN_TRY(flux2mi_dit_forward_kv_cached(dit, kv, packed, S_img, p->txt_emb, p->s_txt, sigma, p->guidance,
+                                                      g.ids_img.as<int32_t>(), g.ids_txt.as<int32_t>(), v));
+        } else
         GEN_TRY(flux2mi_dit_forward(dit, lat_in, S_all, p->txt_emb, p->s_txt, sigma, p->guidance,
                                     g.ids_img.as<int32_t>(), g.ids_txt.as<int32_t>(), v, S_img));
         if (use_cfg) {  // classical CFG: second forward + v_u + g (v_c - v_u) (:1955-1973)

@@ -62,6 +62,10 @@ class Flux2Pipeline:
         """`quantization` mirrors `Flux2Pipeline(model:quantization:)` (Flux2Pipeline.swift:286-308) for the
         transformer only: "bf16" or "fp8" (e4m3 weights + activations; stands in for qint8/int4)."""
         self.ctx = Context(device)
+        # `model.supportsKVCache` (ModelRegistry: klein-9b-kv shares klein-9b's architecture)
+        self.supports_kv_cache = isinstance(model, str) and model.endswith("-kv")
+        if self.supports_kv_cache:
+            model = model[:-3]
         self.quantization = quantization
         self.model = model
         self.vae_variant = vae_variant
@@ -109,7 +113,9 @@ class Flux2Pipeline:
                              strength: float = 1.0, on_progress=None, on_checkpoint=None,
                              on_step: Optional[Flux2StepHook] = None, reference_latents=None, reference_ids=None,
                              custom_sigmas: Optional[Sequence[float]] = None, skip_decode: bool = False,
-                             return_latents: bool = False) -> Flux2GenerationResult:
+                             return_latents: bool = False, kv_cache: Optional[bool] = None) -> Flux2GenerationResult:
+        """`kv_cache`: reference tokens through the KV-cached path (the klein-9b-kv variant,
+        Flux2Pipeline.swift:1555-1682); default = the pipeline's `supports_kv_cache`."""
         if self.transformer is None:
             raise Flux2Error(L.ERR_NOT_LOADED, "Transformer")
         if self.vae is None and not skip_decode:
@@ -155,6 +161,8 @@ class Flux2Pipeline:
             p.custom_sigmas, p.n_custom_sigmas = cs, len(custom_sigmas)
         p.checkpoint_interval = checkpoint_interval or 0
         p.skip_decode = int(skip_decode)
+        use_kv = self.supports_kv_cache if kv_cache is None else bool(kv_cache)
+        p.use_kv_cache = int(use_kv and reference_latents is not None)
 
         stream = self.ctx.stream
         hook_error: List[BaseException] = []

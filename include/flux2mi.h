@@ -149,6 +149,25 @@ int flux2mi_dit_forward(flux2mi_dit* dit, const float* latents, int s_img, const
                         float timestep, float guidance, const int32_t* img_ids, const int32_t* txt_ids,
                         float* out, int s_out);
 
+/* ---- KV-cached reference conditioning (Transformer/TransformerKVCache.swift,
+ * Flux2Transformer.swift:330-546; model variant klein-9b-kv) -------------------------------------- */
+typedef struct flux2mi_kv_cache flux2mi_kv_cache;
+/* Storage for the post-RoPE keys and the values of s_ref reference tokens in every block. */
+int flux2mi_kv_cache_create(flux2mi_dit* dit, int s_txt, int s_ref, flux2mi_kv_cache** out);
+int flux2mi_kv_cache_destroy(flux2mi_kv_cache* cache);
+/* forwardKVExtract (:346-446): sequence [txt | ref | out]; reference queries attend to [txt | ref]
+ * only (Flux2Attention.swift:296-306, :407-425), everything else to all keys; fills `cache`.
+ * latents f32 [s_out,128], ref_latents f32 [s_ref,128], ids i32 [.,4]; out f32 [s_out,128].  Async. */
+int flux2mi_dit_forward_kv_extract(flux2mi_dit* dit, flux2mi_kv_cache* cache, const float* latents, int s_out,
+                                   const float* ref_latents, int s_ref, const void* txt_emb, int s_txt, float timestep,
+                                   float guidance, const int32_t* img_ids, const int32_t* txt_ids, const int32_t* ref_ids,
+                                   float* out);
+/* forwardKVCached (:459-546): sequence [txt | out], keys/values [txt | cached ref | out], no mask.
+ * An unfilled cache is an error status (the reference calls fatalError, :488). */
+int flux2mi_dit_forward_kv_cached(flux2mi_dit* dit, flux2mi_kv_cache* cache, const float* latents, int s_out,
+                                  const void* txt_emb, int s_txt, float timestep, float guidance, const int32_t* img_ids,
+                                  const int32_t* txt_ids, float* out);
+
 /* ---- VAE decoder (AutoencoderKLFlux2.decode) ---------------------------- */
 typedef struct flux2mi_vae_config {
     int channels[4];       /* decoder block_out_channels, e.g. 128,256,512,512 (small: 96,192,384,384) */
@@ -229,6 +248,9 @@ typedef struct flux2mi_generate_params {
     flux2mi_progress_cb on_progress; void* on_progress_user;
     flux2mi_checkpoint_cb on_checkpoint; void* on_checkpoint_user;
     int skip_decode;               /* 1: stop after the denoise loop */
+    int use_kv_cache;              /* 1 (needs ref_latents): KV-cached reference conditioning, the klein-9b-kv
+                                      path (Flux2Pipeline.swift:1555-1682): step 0 = flux2mi_dit_forward_kv_extract,
+                                      steps 1+ = flux2mi_dit_forward_kv_cached */
     /* outputs */
     uint8_t* out_image;            /* host u8 [H,W,3] or NULL */
     float* out_latents;            /* device f32 [S_img,128] or NULL: final packed latents */

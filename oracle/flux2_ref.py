@@ -497,6 +497,98 @@ def dit_forward(P: Dict[str, Tensor], cfg: dict, lat: Tensor, txt_emb: Tensor, t
 # the arithmetic is identical).
 # ---------------------------------------------------------------------------
 
+# ---- KV-cached reference conditioning (klein-9b-kv) --------------------------------------------
+def _kv_mask(s_txt: int, s_ref: int, s_out: int) -> Tensor:
+    """Flux2Attention.swift:407-425: additive mask over [txt | ref | out]; reference queries do not
+    see output keys, everything else is allowed."""
+    S = s_txt + s_ref + s_out
+    m = torch.zeros((S, S))
+    m[s_txt:s_txt + s_ref, s_txt + s_ref:] = float("-inf")
+    return m
+
+
+def dit_forward_kv(P: Dict[str, Tensor], cfg: dict, lat: Tensor, txt_emb: Tensor, t: Tensor, g: Optional[Tensor],
+                   img_ids: Tensor, txt_ids: Tensor, ref_lat: Optional[Tensor] = None, ref_ids: Optional[Tensor] = None,
+                   cache: Optional[list] = None) -> Tuple[Tensor, list]:
+    """Flux2Transformer.swift:346-446 (ref_lat given: extraction, returns the cache) and :459-546
+    (cache given: cached pass).  cache[layer] = (K post-RoPE, V) of the reference tokens, [1,H,S_ref,128];
+    layers = double blocks then single blocks."""
+    extract = ref_lat is not None
+    assert extract != (cache is not None)
+    H, d = cfg["heads"], cfg["dim"]
+    S_txt, S_out = txt_emb.shape[1], lat.shape[1]
+    img = linear(lat.float(), P["img_in.weight"])
+    txt = linear(txt_emb.float(), P["txt_in.weight"])
+    if extract:
+        S_ref = ref_lat.shape[1]
+        img = torch.cat([linear(ref_lat.float(), P["img_in.weight"]), img], dim=1)     # [ref | out]
+        ids = torch.cat([txt_ids, ref_ids, img_ids], dim=0)
+        mask = _kv_mask(S_txt, S_ref, S_out)
+        new_cache = []
+    else:
+        S_ref = cache[0][0].shape[2]
+        ids = torch.cat([txt_ids, img_ids], dim=0)
+        mask = None
+    temb = time_guidance_embed(P, t * 1000.0, None if g is None else g * 1000.0)
+    cos, sin = rope_tables(ids)
+    img_mod = modulation(temb, P["double_stream_modulation_img.lin.weight"], 2)
+    txt_mod = modulation(temb, P["double_stream_modulation_txt.lin.weight"], 2)
+    sgl_mod = modulation(temb, P["single_stream_modulation.lin.weight"], 1)
+
+    def attend(q, k, v, layer):
+        # q,k,v [1,H,S,128] over [txt | (ref) | out]
+        if extract:
+            new_cache.append((k[:, :, S_txt:S_txt + S_ref].clone(), v[:, :, S_txt:S_txt + S_ref].clone()))
+            return sdpa(q, k, v, mask)
+        ck, cv = cache[layer]
+        k = torch.cat([k[:, :, :S_txt], ck, k[:, :, S_txt:]], dim=2)
+        v = torch.cat([v[:, :, :S_txt], cv, v[:, :, S_txt:]], dim=2)
+        return sdpa(q, k, v)
+
+    for i in range(cfg["n_double"]):
+        pre = f"double_blocks.{i}."
+        img_n = apply_modulation(layer_norm_noaffine(img), img_mod[0][0], img_mod[0][1])
+        txt_n = apply_modulation(layer_norm_noaffine(txt), txt_mod[0][0], txt_mod[0][1])
+
+        def qkv(x, name, c, s_):
+            p = block_linear(x, P[pre + name + ".qkv.weight"])
+            q, k, v = p.chunk(3, dim=-1)
+            q, k, v = _heads(q, H), _heads(k, H), _heads(v, H)
+            q = apply_rope(rms_norm(q, P[pre + name + ".norm.query_norm.scale"]), c, s_)
+            k = apply_rope(rms_norm(k, P[pre + name + ".norm.key_norm.scale"]), c, s_)
+            return q, k, v
+
+        q_i, k_i, v_i = qkv(img_n, "img_attn", cos[S_txt:], sin[S_txt:])
+        q_t, k_t, v_t = qkv(txt_n, "txt_attn", cos[:S_txt], sin[:S_txt])
+        o = _unheads(attend(torch.cat([q_t, q_i], 2), torch.cat([k_t, k_i], 2), torch.cat([v_t, v_i], 2), i))
+        txt = txt + block_linear(o[:, :S_txt], P[pre + "txt_attn.proj.weight"]) * txt_mod[0][2].unsqueeze(1)
+        img = img + block_linear(o[:, S_txt:], P[pre + "img_attn.proj.weight"]) * img_mod[0][2].unsqueeze(1)
+        img_n2 = apply_modulation(layer_norm_noaffine(img), img_mod[1][0], img_mod[1][1])
+        txt_n2 = apply_modulation(layer_norm_noaffine(txt), txt_mod[1][0], txt_mod[1][1])
+        img = img + swiglu_ff(img_n2, P[pre + "img_mlp.0.weight"], P[pre + "img_mlp.2.weight"]) * img_mod[1][2].unsqueeze(1)
+        txt = txt + swiglu_ff(txt_n2, P[pre + "txt_mlp.0.weight"], P[pre + "txt_mlp.2.weight"]) * txt_mod[1][2].unsqueeze(1)
+
+    hs = torch.cat([txt, img], dim=1)
+    for i in range(cfg["n_single"]):
+        pre = f"single_blocks.{i}."
+        x = apply_modulation(layer_norm_noaffine(hs), sgl_mod[0][0], sgl_mod[0][1])
+        p = block_linear(x, P[pre + "linear1.weight"])
+        q, k, v = p[..., :d], p[..., d:2 * d], p[..., 2 * d:3 * d]
+        hid = (p.shape[-1] - 3 * d) // 2
+        gate, up = p[..., 3 * d:3 * d + hid], p[..., 3 * d + hid:]
+        q, k, v = _heads(q, H), _heads(k, H), _heads(v, H)
+        q = apply_rope(rms_norm(q, P[pre + "norm.query_norm.scale"]), cos, sin)
+        k = apply_rope(rms_norm(k, P[pre + "norm.key_norm.scale"]), cos, sin)
+        attn = _unheads(attend(q, k, v, cfg["n_double"] + i))
+        hs = hs + block_linear(torch.cat([attn, F.silu(gate) * up], dim=-1), P[pre + "linear2.weight"]) * sgl_mod[0][2].unsqueeze(1)
+
+    out_hs = hs[:, hs.shape[1] - S_out:]
+    pm = linear(F.silu(temb), P["final_layer.adaLN_modulation.1.weight"])
+    shift, scale = pm.chunk(2, dim=-1)      # BFL order [shift | scale], as in dit_forward
+    y = apply_modulation(layer_norm_noaffine(out_hs), shift, scale)
+    return linear(y, P["final_layer.linear.weight"]), (new_cache if extract else cache)
+
+
 def group_norm(x: Tensor, w: Tensor, b: Tensor, groups: int = 32, eps: float = 1e-6) -> Tensor:
     """ResnetBlock.swift:9-55 (f32 statistics over (H,W,C/G))."""
     return F.group_norm(x, groups, w.float(), b.float(), eps)

@@ -198,3 +198,74 @@ def test_fp8_rejects_unsupported_dim(flux2mi, ctx):
     cfg = dict(dim=128, heads=1, n_double=1, n_single=1, joint_dim=128, guidance=False)
     with pytest.raises(Flux2Error):
         DiT(ctx, cfg, weights="fp8")
+
+
+# ---- KV-cached reference conditioning (klein-9b-kv path) ------------------------
+def _kv_case(ctx, cfg, s_txt, h, w, ref_hw, weights="bf16", std=0.05):
+    from flux2mi import synthetic as syn
+    from flux2mi.api import DiT, KVCache
+    P = syn.make_dit_weights(cfg, seed=5, std=std)
+    inp = syn.make_inputs(cfg, h, w, s_txt=s_txt)
+    lat = R.pack_patchified_to_sequence(inp["noise"])
+    g = torch.Generator().manual_seed(1)
+    s_ref = ref_hw[0] * ref_hw[1]
+    ref = torch.randn((1, s_ref, 128), generator=g)
+    lat2 = lat + 0.3 * torch.randn(lat.shape, generator=g)
+    ref_ids = R.reference_position_ids([ref_hw[0]], [ref_hw[1]])
+    img_ids, txt_ids = R.image_position_ids(h, w), R.text_position_ids(s_txt)
+    gt = torch.tensor([4.0]) if cfg["guidance"] else None
+    # oracle: extraction at t0, cached pass at t1 on moved latents
+    o0, cache = R.dit_forward_kv(P, cfg, lat, inp["txt"].float(), torch.tensor([0.8]), gt, img_ids, txt_ids, ref_lat=ref, ref_ids=ref_ids)
+    o1, _ = R.dit_forward_kv(P, cfg, lat2, inp["txt"].float(), torch.tensor([0.55]), gt, img_ids, txt_ids, cache=cache)
+    dit = DiT(ctx, cfg, weights=weights).load(P).finalize()
+    kv = KVCache(dit, s_txt, s_ref)
+    d = lambda x: x.cuda()
+    h0 = dit.forward_kv_extract(kv, d(lat), d(ref), d(inp["txt"]), 0.8, 4.0, d(img_ids), d(txt_ids), d(ref_ids)).cpu()
+    h1 = dit.forward_kv_cached(kv, d(lat2), d(inp["txt"]), 0.55, 4.0, d(img_ids), d(txt_ids)).cpu()
+    h0_again = dit.forward_kv_cached(kv, d(lat), d(inp["txt"]), 0.8, 4.0, d(img_ids), d(txt_ids)).cpu()
+    kv.close()
+    dit.close()
+    return (o0[0], o1[0]), (h0, h1, h0_again)
+
+
+@pytest.mark.parametrize("preset,s_txt,h,w,ref_hw", [
+    ("tiny", 16, 64, 64, (4, 6)),      # s_ref 24: the V^T key groups straddle the ref/out boundary
+    ("tiny", 19, 80, 112, (6, 10)),    # nothing aligned: s_txt 19, s_ref 60, s_out 35
+    ("tiny-g", 16, 64, 64, (4, 4)),    # guidance embedding
+    ("tiny", 32, 128, 128, (8, 8)),    # aligned, more than one attention q-block per range
+])
+def test_kv_extract_and_cached_vs_oracle(flux2mi, ctx, preset, s_txt, h, w, ref_hw):
+    """forwardKVExtract / forwardKVCached vs the oracle's masked / concatenated-KV restatement
+    (rel-L2 <= 2e-2), and the structural identity that a cached pass on the extraction pass's own
+    inputs reproduces its output (same keys, same values: <= 2e-3, bf16 rounding of split launches)."""
+    from flux2mi import synthetic as syn
+    (o0, o1), (h0, h1, h0_again) = _kv_case(ctx, syn.DIT_PRESETS[preset], s_txt, h, w, ref_hw)
+    assert torch.isfinite(h0).all() and torch.isfinite(h1).all()
+    assert rel_l2(h0, o0) < 2e-2
+    assert rel_l2(h1, o1) < 2e-2
+    assert rel_l2(h0_again, h0) < 2e-3
+
+
+def test_kv_cached_before_extract_is_an_error(flux2mi, ctx):
+    """The reference calls fatalError on a missing cache entry (Flux2Transformer.swift:488); here: a status."""
+    from flux2mi import Flux2Error, synthetic as syn
+    from flux2mi.api import DiT, KVCache
+    cfg = syn.DIT_PRESETS["tiny"]
+    dit = DiT(ctx, cfg).load(syn.make_dit_weights(cfg)).finalize()
+    kv = KVCache(dit, 16, 16)
+    lat = torch.zeros((16, 128), device="cuda")
+    txt = torch.zeros((16, cfg["joint_dim"]), dtype=torch.bfloat16, device="cuda")
+    ids = torch.zeros((16, 4), dtype=torch.int32, device="cuda")
+    with pytest.raises(Flux2Error):
+        dit.forward_kv_cached(kv, lat, txt, 0.5, 4.0, ids, ids)
+    kv.close()
+    dit.close()
+
+
+def test_kv_fp8_runs_and_matches_emulation(flux2mi, ctx):
+    """The KV paths share the fp8 block GEMMs: cached pass vs the emulating oracle."""
+    from flux2mi import synthetic as syn
+    cfg = syn.DIT_PRESETS["tiny"]
+    with R.fp8_block_gemms():
+        (o0, o1), (h0, h1, _) = _kv_case(ctx, cfg, 16, 64, 64, (4, 4), weights="fp8")
+    assert rel_l2(h0, o0) < 2e-2 and rel_l2(h1, o1) < 2e-2

@@ -18,7 +18,7 @@ dev = torch.device("cuda", 0)
 
 def load(model, vae="standard", quantization="bf16"):
     pipe = Flux2Pipeline(model=model, vae_variant=vae, quantization=quantization)
-    cfg = syn.DIT_PRESETS[model]
+    cfg = syn.DIT_PRESETS[model[:-3] if model.endswith("-kv") else model]
     pipe.load_models(syn.make_dit_weights(cfg, device=dev), syn.make_vae_weights(syn.VAE_PRESETS[vae], device=dev))
     return pipe, cfg
 
@@ -48,6 +48,18 @@ for w in which:
         pipe, cfg = load("klein-9b", quantization="fp8")
         inp = syn.make_inputs(cfg, 1024, 1024, device=dev)
         run("D8 klein-9b (fp8 e4m3 block GEMMs) 1024x1024 28 steps, 1 image per GPU", lambda: pipe.generate_text_to_image(height=1024, width=1024, steps=28, precomputed_embeddings=inp["txt"], noise=inp["noise"]))
+    elif w == "K":
+        # klein-9b-kv: one 1024^2 reference image (S_ref 4096), 4 steps like the distilled model; the
+        # same I2I generation without and with the KV-cached path
+        pipe, cfg = load("klein-9b-kv")
+        inp = syn.make_inputs(cfg, 1024, 1024, device=dev)
+        g = torch.Generator(device=dev); g.manual_seed(99)
+        ref = torch.randn((1, 4096, 128), generator=g, device=dev)
+        ref_ids = torch.from_numpy(api.reference_position_ids([64], [64])).to(dev)
+        for kvc in (False, True):
+            run(f"K klein-9b{'-kv (KV-cached reference tokens)' if kvc else ' plain I2I'} 1024x1024 + one 1024^2 reference, 4 steps",
+                lambda: pipe.generate_with_result("imageToImage", height=1024, width=1024, steps=4, precomputed_embeddings=inp["txt"],
+                                                  noise=inp["noise"], reference_latents=ref, reference_ids=ref_ids, kv_cache=kvc))
     elif w == "C":
         pipe, cfg = load("dev")
         inp = syn.make_inputs(cfg, 1024, 1024, device=dev)
