@@ -70,7 +70,9 @@ __device__ __forceinline__ void tile_coords256(int local, int ntiles, int tiles_
 // runs at twice the bf16 rate — the plain _fp8_fp8 16x16x32 runs at the bf16 rate.  Which k of
 // the tile lands on which operand byte is the same permutation for A and W, which a dot product
 // does not see.  The epilogue multiplies by a_scale[row] * w_scale[col].
-template <bool STAGGER, int ABL, bool HALFBAR = false, bool DIAG = false, bool FP8 = false>
+// VAR (schedule experiments, FLUX2MI_GEMM_VAR): bit 0 = wait for the fragment reads AFTER the phase's first
+// barrier; bit 1 = one counted vmcnt per K-tile (before the first barrier of phase 3) instead of one per phase.
+template <bool STAGGER, int ABL, bool HALFBAR = false, bool DIAG = false, bool FP8 = false, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch batch) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE2_BYTES];  // 128 KB, the ONLY LDS object
 
@@ -199,19 +201,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     asm volatile("" ::: "memory");
 #define G2_READS_DONE()                                          \
     if (STAGGER) {                                               \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        if (!(VAR & 1)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         G2_STAMP(dg_r)                                           \
         G2_SYNC()                                                \
+        if (VAR & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
         G2_STAMP(dg_w1)                                          \
     }
 #define G2_PHASE_END()                                                          \
-    if (ABL & 8) {}                                                             \
+    if ((ABL & 8) || (VAR & 2)) {}                                              \
     else if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            \
     else if (STAGGER) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          \
     else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                      \
     G2_STAMP(dg_m)                                                              \
     G2_SYNC()                                                                   \
     G2_STAMP(dg_w2)
+#define G2_TILE_WAIT()                                                          \
+    if (VAR & 2) {                                                              \
+        if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             \
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                   \
+    }
 
     const int wm_u = __builtin_amdgcn_readfirstlane(wid) >> 2;  // provably wave-uniform
 #define G2_ISSUE_L(k_, u_) if (ABL == 4) G2_ISSUE(k_, ((u_) < nk ? ((u_) & 1) : nk)) else if (!(ABL & 2)) G2_ISSUE(k_, u_)
@@ -255,6 +263,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     G2_ISSUE(KIND_A0, 1) G2_ISSUE(KIND_B0, 1) G2_ISSUE(KIND_B1, 1)
     {
         const bool drain = nk < 3;
+        G2_TILE_WAIT()
         G2_PHASE_END()
     }
     if (STAGGER && wm_u == 1) { G2_SYNC() }
@@ -292,6 +301,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         // phase 3: issue B1(kt+2); b0 still in registers -> (m1, n0)
         G2_ISSUE_L(KIND_B1, kt + 2)
         G2_STAMP_NW(dg_dma)
+        G2_TILE_WAIT()
         G2_READS_DONE()
         G2_MFMA(1, 0, b0)
         G2_PHASE_END()
@@ -307,6 +317,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
 #undef G2_READ_B
 #undef G2_MFMA
 #undef G2_PHASE_END
+#undef G2_TILE_WAIT
 #undef G2_READS_DONE
 #undef G2_SYNC
 #undef G2_STAMP
@@ -497,7 +508,7 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
 
     const bool fp8 = probs[0].fp8 != 0;
     if (fp8) {
-        hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, true>), dim3(tiles[0] + tiles[1]), dim3(512), 0, stream, b);
+        hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, true, 3>), dim3(tiles[0] + tiles[1]), dim3(512), 0, stream, b);
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
     static const int abl = [] {
@@ -509,6 +520,23 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
         return e ? atoi(e) : 1;
     }();
     const dim3 grid(tiles[0] + tiles[1]), block(512);
+    // schedule variant (see VAR on the kernel): default 3 = one counted vmcnt per K-tile (measured +7 %
+    // over a wait in every phase: linear1 0.649 -> 0.605 ms, 8192^3 1224 -> 1326 TF on one box) and
+    // the fragment-read wait behind the phase's first barrier (+0..1 %)
+    static const int var = [] {
+        const char* e = getenv("FLUX2MI_GEMM_VAR");
+        return e ? atoi(e) : 3;
+    }();
+    if (var == 2 && abl == 0 && stagger == 0) {   // lockstep waves, one wait per K-tile (A/B only)
+        hipLaunchKernelGGL((gemm_bf16_256x256_kernel<false, 0, false, false, false, 2>), grid, block, 0, stream, b);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
+    if (var >= 1 && var <= 3 && abl == 0 && stagger == 1) {
+        if (var == 1) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 1>), grid, block, 0, stream, b);
+        else if (var == 2) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 2>), grid, block, 0, stream, b);
+        else hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 3>), grid, block, 0, stream, b);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
     static const int diag = [] {
         const char* e = getenv("FLUX2MI_GEMM_DIAG");
         return e ? atoi(e) : 0;
