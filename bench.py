@@ -127,9 +127,16 @@ def main():
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     # TFLOP/s dense MFMA, MI355X_MICROARCH.md chip table: bf16 2500, fp8 5000
     peak = 5000.0 if args.weights == "fp8" else 2500.0
+    # HBM-side traffic of that kernel from the committed PMC passes (rocprofv3 cannot run inside this
+    # process); null when the summary is not there or another model / size / format is benchmarked
+    traffic = None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c_linear1_traffic.json")
+    if args.model == "klein-4b" and (H, W) == (1024, 1024) and args.weights == "bf16" and os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f)["traffic_bytes_per_launch"]
     roofline = {"bound": "mfma", "kernel": "gemm_bf16_256x256_kernel (single_blocks.linear1: [S,d] x [9d,d]^T, fused qkv store + SwiGLU)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None,
+                "frac": round(achieved / peak, 4), "traffic": traffic,
                 "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
                 "flops_per_launch": flops_per_launch}
 
