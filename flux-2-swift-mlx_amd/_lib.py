@@ -95,6 +95,9 @@ PROTOTYPES = {
     "flux2mi_dit_destroy": (_I, [_P]),
     "flux2mi_dit_set_tensor": (_I, [_P, C.c_char_p, _I, C.POINTER(_I64), _I, _P]),
     "flux2mi_dit_finalize": (_I, [_P]),
+    "flux2mi_dit_load_safetensors": (_I, [_P, C.c_char_p, _PI, _PI]),
+    "flux2mi_dit_set_tensor_q8": (_I, [_P, C.c_char_p, _P, _P, _I64, _I64]),
+    "flux2mi_dit_merge_lora": (_I, [_P, C.c_char_p, _I, _P, _P, _I, _F]),
     "flux2mi_dit_param_bytes": (_I64, [_P]),
     "flux2mi_dit_forward": (_I, [_P, _P, _I, _P, _I, _F, _F, _P, _P, _P, _I]),
     "flux2mi_kv_cache_create": (_I, [_P, _I, _I, C.POINTER(_P)]),
@@ -106,6 +109,7 @@ PROTOTYPES = {
     "flux2mi_vae_destroy": (_I, [_P]),
     "flux2mi_vae_set_tensor": (_I, [_P, C.c_char_p, _I, C.POINTER(_I64), _I, _P]),
     "flux2mi_vae_finalize": (_I, [_P]),
+    "flux2mi_vae_load_safetensors": (_I, [_P, C.c_char_p, _PI, _PI]),
     "flux2mi_vae_bn_mean": (_P, [_P]),
     "flux2mi_vae_bn_var": (_P, [_P]),
     "flux2mi_vae_decode": (_I, [_P, _P, _I, _I, _P, _P]),

@@ -267,6 +267,31 @@ class DiT:
         check(lib().flux2mi_dit_finalize(self.handle))
         return self
 
+    def load_safetensors(self, path: str):
+        """Native reader (csrc/loader.cpp): BFL or diffusers keys, bf16/f16/f32, quanto qint8 pairs.
+        Returns (tensors ingested, tensors skipped)."""
+        n, k = C.c_int(0), C.c_int(0)
+        self.ctx._enter()
+        check(lib().flux2mi_dit_load_safetensors(self.handle, str(path).encode(), C.byref(n), C.byref(k)))
+        self.ctx._exit()
+        return n.value, k.value
+
+    def set_tensor_q8(self, name: str, data: torch.Tensor, scale: torch.Tensor):
+        """One quanto qint8 tensor: int8 [out,in] x f32 scale [out] (WeightLoader.swift:347-363)."""
+        d = data.contiguous()
+        sc = scale.reshape(-1).to(torch.float32).contiguous()
+        assert d.dtype == torch.int8 and d.dim() == 2 and sc.numel() == d.shape[0]
+        check(lib().flux2mi_dit_set_tensor_q8(self.handle, name.encode(), d.data_ptr(), sc.data_ptr(), d.shape[0], d.shape[1]))
+        return self
+
+    def merge_lora(self, name: str, lora_a: torch.Tensor, lora_b: torch.Tensor, scale: float):
+        """W[name] += scale * (B A); A [rank,in], B [out,rank] (WeightLoader.mergeLoRAWeights)."""
+        a, b = lora_a.contiguous(), lora_b.to(lora_a.dtype).contiguous()
+        dt = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}[a.dtype]
+        assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[1]
+        check(lib().flux2mi_dit_merge_lora(self.handle, name.encode(), dt, a.data_ptr(), b.data_ptr(), a.shape[0], float(scale)))
+        return self
+
     @property
     def param_bytes(self) -> int:
         return int(lib().flux2mi_dit_param_bytes(self.handle))
@@ -395,6 +420,13 @@ class VAE:
         check(lib().flux2mi_vae_decode(self.handle, _ptr(z), h, w, _ptr(of), _ptr(ou)))
         self.ctx._exit()
         return of, ou
+
+    def load_safetensors(self, path: str):
+        n, k = C.c_int(0), C.c_int(0)
+        self.ctx._enter()
+        check(lib().flux2mi_vae_load_safetensors(self.handle, str(path).encode(), C.byref(n), C.byref(k)))
+        self.ctx._exit()
+        return n.value, k.value
 
     @property
     def has_encoder(self) -> bool:

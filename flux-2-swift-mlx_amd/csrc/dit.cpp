@@ -67,7 +67,7 @@ struct flux2mi_dit {
     std::vector<Sgl> sgl;
 
     // staging for ingestion
-    DevBuf stage_raw, stage_bf16, stage_w;
+    DevBuf stage_raw, stage_bf16, stage_w, stage_d, stage_q8;
     // forward workspace
     DevBuf hs, xn, qkv, vt, comb, mods, rope, lat_bf16, xq, xs;
     int ws_S = 0;
@@ -182,6 +182,64 @@ flux2mi_dit::W weight_by_label(flux2mi_dit* m, const std::string& label) {
     return w;
 }
 
+// Put `rows` x `cols` bf16 rows (checkpoint order) of slot `s` where the kernels want them.  `dst` is
+// the base of a bf16 image of the slot's buffer (the weight buffer itself, or a scratch image of it for
+// the LoRA merge); nullptr = the buffer is fp8: the transform runs into a bf16 staging copy and the
+// rows are quantised (scale = row amax / 448).
+int place_rows(flux2mi_dit* m, const Slot& s, const uint16_t* src, uint16_t* dst) {
+    hipStream_t st = m->ctx->stream;
+    Buf& b = m->bufs[s.buf];
+    const int64_t rows = s.rows, cols = s.cols;
+    const size_t row_bytes = (size_t)cols * 2;
+    if (dst == nullptr) {
+        const uint16_t* rows_src = src;
+        if (s.transform == T_SWIGLU || s.transform == T_LINEAR1) {
+            F2_TRY(m->stage_w.reserve((size_t)rows * cols * 2));
+            uint16_t* w = m->stage_w.as<uint16_t>();
+            if (s.transform == T_SWIGLU) {
+                F2_LAUNCH(launch_swiglu_interleave_rows(st, src, w, (int)(rows / 2), (int)cols), "swiglu_interleave");
+            } else {
+                const int d = m->cfg.dim;
+                F2_CHECK_HIP(hipMemcpyAsync(w, src, (size_t)3 * d * row_bytes, hipMemcpyDeviceToDevice, st));
+                F2_LAUNCH(launch_swiglu_interleave_rows(st, src + (size_t)3 * d * cols, w + (size_t)3 * d * cols, 3 * d,
+                                                        (int)cols),
+                          "swiglu_interleave(linear1)");
+            }
+            rows_src = w;
+        } else {
+            F2_REQUIRE(s.transform == T_DIRECT, FLUX2MI_ERR_UNSUPPORTED, "transform on an fp8 buffer");
+        }
+        F2_LAUNCH(launch_quantize_rows_fp8(st, rows_src, (int)cols, b.q + (size_t)s.row_off * cols, (int)cols,
+                                           b.scale + s.row_off, (int)rows, (int)cols),
+                  "quantize weight rows");
+        return FLUX2MI_OK;
+    }
+    switch (s.transform) {
+        case T_DIRECT:
+            F2_CHECK_HIP(hipMemcpyAsync(dst + (size_t)s.row_off * cols, src, (size_t)rows * row_bytes,
+                                        hipMemcpyDeviceToDevice, st));
+            break;
+        case T_SWAP_HALVES: {
+            const size_t half = (size_t)(rows / 2) * cols;
+            F2_CHECK_HIP(hipMemcpyAsync(dst, src + half, half * 2, hipMemcpyDeviceToDevice, st));
+            F2_CHECK_HIP(hipMemcpyAsync(dst + half, src, half * 2, hipMemcpyDeviceToDevice, st));
+            break;
+        }
+        case T_SWIGLU:
+            F2_LAUNCH(launch_swiglu_interleave_rows(st, src, dst, (int)(rows / 2), (int)cols), "swiglu_interleave");
+            break;
+        case T_LINEAR1: {
+            const int d = m->cfg.dim;
+            F2_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)3 * d * row_bytes, hipMemcpyDeviceToDevice, st));
+            F2_LAUNCH(launch_swiglu_interleave_rows(st, src + (size_t)3 * d * cols, dst + (size_t)3 * d * cols, 3 * d,
+                                                    (int)cols),
+                      "swiglu_interleave(linear1)");
+            break;
+        }
+    }
+    return FLUX2MI_OK;
+}
+
 size_t dtype_size(int dtype) { return dtype == FLUX2MI_F32 ? 4 : 2; }
 
 }  // namespace
@@ -242,7 +300,7 @@ extern "C" int flux2mi_dit_destroy(flux2mi_dit* m) {
         if (b.q) (void)hipFree(b.q);
         if (b.scale) (void)hipFree(b.scale);
     }
-    DevBuf* ws[] = {&m->stage_raw, &m->stage_bf16, &m->stage_w, &m->hs, &m->xn, &m->qkv, &m->vt, &m->comb, &m->mods,
+    DevBuf* ws[] = {&m->stage_raw, &m->stage_bf16, &m->stage_w, &m->stage_d, &m->stage_q8, &m->hs, &m->xn, &m->qkv, &m->vt, &m->comb, &m->mods,
                     &m->rope, &m->lat_bf16, &m->xq, &m->xs};
     for (DevBuf* w : ws) w->release();
     delete m;
@@ -284,57 +342,83 @@ extern "C" int flux2mi_dit_set_tensor(flux2mi_dit* m, const char* name, int dtyp
         F2_LAUNCH(launch_convert_to_bf16(st, m->stage_raw.ptr, dtype, m->stage_bf16.as<uint16_t>(), n), "convert_to_bf16");
         src = m->stage_bf16.as<uint16_t>();
     }
-    // 3. place with the layout transform.  An fp8 buffer gets the same row layout: the transform
-    // runs into a bf16 staging copy and the rows are then quantised (scale = row amax / 448).
-    const size_t row_bytes = (size_t)cols * 2;
-    if (b.fp8) {
-        const uint16_t* rows_src = src;
-        if (s.transform == T_SWIGLU || s.transform == T_LINEAR1) {
-            F2_TRY(m->stage_w.reserve((size_t)n * 2));
-            uint16_t* w = m->stage_w.as<uint16_t>();
-            if (s.transform == T_SWIGLU) {
-                F2_LAUNCH(launch_swiglu_interleave_rows(st, src, w, (int)(rows / 2), (int)cols), "swiglu_interleave");
-            } else {
-                const int d = m->cfg.dim;
-                F2_CHECK_HIP(hipMemcpyAsync(w, src, (size_t)3 * d * row_bytes, hipMemcpyDeviceToDevice, st));
-                F2_LAUNCH(launch_swiglu_interleave_rows(st, src + (size_t)3 * d * cols, w + (size_t)3 * d * cols, 3 * d,
-                                                        (int)cols),
-                          "swiglu_interleave(linear1)");
-            }
-            rows_src = w;
-        } else {
-            F2_REQUIRE(s.transform == T_DIRECT, FLUX2MI_ERR_UNSUPPORTED, "dit_set_tensor(%s): transform on fp8 buffer", name);
-        }
-        F2_LAUNCH(launch_quantize_rows_fp8(st, rows_src, (int)cols, b.q + (size_t)s.row_off * cols, (int)cols,
-                                           b.scale + s.row_off, (int)rows, (int)cols),
-                  "quantize weight rows");
-    } else
-    switch (s.transform) {
-        case T_DIRECT:
-            F2_CHECK_HIP(hipMemcpyAsync(b.ptr + (size_t)s.row_off * cols, src, (size_t)rows * row_bytes,
-                                        hipMemcpyDeviceToDevice, st));
-            break;
-        case T_SWAP_HALVES: {
-            const size_t half = (size_t)(rows / 2) * cols;
-            F2_CHECK_HIP(hipMemcpyAsync(b.ptr, src + half, half * 2, hipMemcpyDeviceToDevice, st));
-            F2_CHECK_HIP(hipMemcpyAsync(b.ptr + half, src, half * 2, hipMemcpyDeviceToDevice, st));
-            break;
-        }
-        case T_SWIGLU:
-            F2_LAUNCH(launch_swiglu_interleave_rows(st, src, b.ptr, (int)(rows / 2), (int)cols), "swiglu_interleave");
-            break;
-        case T_LINEAR1: {
-            const int d = m->cfg.dim;
-            F2_CHECK_HIP(hipMemcpyAsync(b.ptr, src, (size_t)3 * d * row_bytes, hipMemcpyDeviceToDevice, st));
-            F2_LAUNCH(launch_swiglu_interleave_rows(st, src + (size_t)3 * d * cols, b.ptr + (size_t)3 * d * cols, 3 * d,
-                                                    (int)cols),
-                      "swiglu_interleave(linear1)");
-            break;
-        }
-    }
+    // 3. place with the layout transform
+    F2_TRY(place_rows(m, s, src, b.fp8 ? nullptr : b.ptr));
     F2_CHECK_HIP(hipStreamSynchronize(st));  // the caller may free `data` on return
     b.got_rows += (int)rows;
     m->finalized = false;
+    return FLUX2MI_OK;
+}
+
+namespace {
+GemmProblem mk(const uint16_t* A, int lda, const uint16_t* W, int ldw, void* C, int ldc, int M, int N, int K, int epi);
+}
+
+// quanto qint8 tensor pair (`<key>._data` int8 [out,in], `<key>._scale` f32 [out] or [out,1]):
+// de-quantised on the device (data * scale, WeightLoader.swift:347-363) and ingested like any tensor.
+// The reference keeps the product in f16; here it is rounded to the bf16 weight storage.
+extern "C" int flux2mi_dit_set_tensor_q8(flux2mi_dit* m, const char* name, const int8_t* data, const float* scale,
+                                         int64_t rows, int64_t cols) {
+    F2_REQUIRE(m && name && data && scale && rows > 0 && cols > 0, FLUX2MI_ERR_INVALID_ARG, "dit_set_tensor_q8: bad argument");
+    F2_CHECK_HIP(hipSetDevice(m->ctx->device));
+    hipStream_t st = m->ctx->stream;
+    const size_t n = (size_t)rows * cols;
+    F2_TRY(m->stage_q8.reserve(n + (size_t)rows * 4 + n * 2 + 512));
+    int8_t* dq = m->stage_q8.as<int8_t>();
+    float* ds = reinterpret_cast<float*>(dq + ((n + 255) & ~(size_t)255));
+    uint16_t* out = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(ds) + (((size_t)rows * 4 + 255) & ~(size_t)255));
+    F2_CHECK_HIP(hipMemcpyAsync(dq, data, n, hipMemcpyDefault, st));
+    F2_CHECK_HIP(hipMemcpyAsync(ds, scale, (size_t)rows * 4, hipMemcpyDefault, st));
+    F2_LAUNCH(launch_dequant_i8_rows(st, dq, ds, out, (int)rows, (int)cols), "dequant_i8");
+    const int64_t shape[2] = {rows, cols};
+    return flux2mi_dit_set_tensor(m, name, FLUX2MI_BF16, shape, 2, out);
+}
+
+// LoRA merge into the resident weight: W += scale * (B A), A [rank, in], B [out, rank]
+// (WeightLoader.mergeLoRAWeights, Loading/WeightLoader.swift:736-856, non-quantised branch: the
+// delta is formed in the weight dtype and added in it).  `name` is any checkpoint key of the target
+// weight (BFL or diffusers); the delta goes through the same layout transform as the weight did.
+extern "C" int flux2mi_dit_merge_lora(flux2mi_dit* m, const char* name, int dtype, const void* A, const void* B, int rank,
+                                      float scale) {
+    F2_REQUIRE(m && name && A && B && rank > 0, FLUX2MI_ERR_INVALID_ARG, "dit_merge_lora: bad argument");
+    F2_REQUIRE(dtype == FLUX2MI_F32 || dtype == FLUX2MI_BF16 || dtype == FLUX2MI_F16, FLUX2MI_ERR_INVALID_ARG,
+               "dit_merge_lora(%s): unsupported dtype %d", name, dtype);
+    auto it = m->slots.find(name);
+    if (it == m->slots.end()) {
+        flux2mi_set_error("dit_merge_lora: unknown key '%s'", name);
+        return FLUX2MI_ERR_INVALID_ARG;
+    }
+    const Slot& s = it->second;
+    Buf& b = m->bufs[s.buf];
+    F2_REQUIRE(!b.fp8, FLUX2MI_ERR_UNSUPPORTED,
+               "dit_merge_lora(%s): fp8 weights (merge into the bf16 checkpoint before loading with weight_format 1)", name);
+    F2_REQUIRE(b.got_rows >= b.rows, FLUX2MI_ERR_NOT_LOADED, "dit_merge_lora(%s): base weight not loaded", name);
+    F2_CHECK_HIP(hipSetDevice(m->ctx->device));
+    hipStream_t st = m->ctx->stream;
+    const int64_t rows = s.rows, cols = s.cols;
+    // A, B -> bf16 on the device; A^T so that delta = B (A^T)^T is the library's C = X W^T form
+    const size_t na = (size_t)rank * cols, nb = (size_t)rows * rank;
+    F2_TRY(m->stage_raw.reserve((na > nb ? na : nb) * dtype_size(dtype)));
+    F2_TRY(m->stage_bf16.reserve((2 * na + nb) * 2 + 1024));
+    uint16_t* a16 = m->stage_bf16.as<uint16_t>();
+    uint16_t* at16 = a16 + ((na + 127) & ~(size_t)127);
+    uint16_t* b16 = at16 + ((na + 127) & ~(size_t)127);
+    F2_CHECK_HIP(hipMemcpyAsync(m->stage_raw.ptr, A, na * dtype_size(dtype), hipMemcpyDefault, st));
+    F2_LAUNCH(launch_convert_to_bf16(st, m->stage_raw.ptr, dtype, a16, (int64_t)na), "lora A->bf16");
+    F2_LAUNCH(launch_transpose_bf16(st, a16, at16, rank, (int)cols), "lora A^T");
+    F2_CHECK_HIP(hipMemcpyAsync(m->stage_raw.ptr, B, nb * dtype_size(dtype), hipMemcpyDefault, st));
+    F2_LAUNCH(launch_convert_to_bf16(st, m->stage_raw.ptr, dtype, b16, (int64_t)nb), "lora B->bf16");
+    // delta (bf16, checkpoint row order) = scale * B A
+    F2_TRY(m->stage_w.reserve((size_t)rows * cols * 2));
+    GemmProblem p = mk(b16, rank, at16, rank, m->stage_w.ptr, (int)cols, (int)rows, (int)cols, rank, EPI_BF16);
+    p.alpha = scale;
+    F2_LAUNCH(launch_gemm(st, &p, 1), "lora delta");
+    // the delta in the layout of the weight buffer, then W += delta over the rows the slot covers
+    F2_TRY(m->stage_d.reserve((size_t)b.rows * b.cols * 2));
+    F2_TRY(place_rows(m, s, m->stage_w.as<uint16_t>(), m->stage_d.as<uint16_t>()));
+    const size_t off = (s.transform == T_DIRECT) ? (size_t)s.row_off * cols : 0;
+    F2_LAUNCH(launch_bf16_add_inplace(st, b.ptr + off, m->stage_d.as<uint16_t>() + off, rows * cols), "lora merge");
+    F2_CHECK_HIP(hipStreamSynchronize(st));
     return FLUX2MI_OK;
 }
 
@@ -390,6 +474,7 @@ extern "C" int flux2mi_dit_finalize(flux2mi_dit* m) {
     m->stage_raw.release();
     m->stage_bf16.release();
     m->stage_w.release();
+    m->stage_q8.release();
     m->finalized = true;
     return FLUX2MI_OK;
 }

@@ -84,6 +84,19 @@ __global__ void swiglu_interleave_kernel(const uint16_t* __restrict__ in, uint16
     for (int c = threadIdx.x; c < K / 8; c += blockDim.x) d[c] = s[c];
 }
 
+__global__ void bf16_add_kernel(uint16_t* __restrict__ w, const uint16_t* __restrict__ dl, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        w[i] = f32_to_bf16_bits(bf16_bits_to_f32(w[i]) + bf16_bits_to_f32(dl[i]));
+}
+__global__ void dequant_i8_rows_kernel(const int8_t* __restrict__ data, const float* __restrict__ scale,
+                                       uint16_t* __restrict__ out, int rows, int cols) {
+    const int64_t n = (int64_t)rows * cols;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = f32_to_bf16_bits((float)data[i] * scale[i / cols]);
+}
+
 // ---- sampler arithmetic (f32, 16 B/lane)
 __global__ void axpy_kernel(float* __restrict__ x, const float* __restrict__ v, float a, int64_t n4, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -193,6 +206,17 @@ int launch_convert_to_f32(hipStream_t stream, const void* in, int dtype, float* 
 int launch_swiglu_interleave_rows(hipStream_t stream, const uint16_t* in, uint16_t* out, int hidden, int K) {
     if (hidden <= 0 || (hidden & 31) || (K & 7)) return 1;
     hipLaunchKernelGGL(swiglu_interleave_kernel, dim3(2 * hidden), dim3(256), 0, stream, in, out, hidden, K);
+    EW_DONE();
+}
+int launch_bf16_add_inplace(hipStream_t stream, uint16_t* w, const uint16_t* delta, int64_t n) {
+    if (n <= 0) return 1;
+    hipLaunchKernelGGL(bf16_add_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, stream, w, delta, n);
+    EW_DONE();
+}
+int launch_dequant_i8_rows(hipStream_t stream, const int8_t* data, const float* scale, uint16_t* out, int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 1;
+    hipLaunchKernelGGL(dequant_i8_rows_kernel, dim3(ew_grid((int64_t)rows * cols)), dim3(EW_BLOCK), 0, stream, data, scale, out,
+                       rows, cols);
     EW_DONE();
 }
 int launch_axpy(hipStream_t stream, float* x, const float* v, float a, int64_t n) {

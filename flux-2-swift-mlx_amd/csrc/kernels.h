@@ -95,6 +95,10 @@ int launch_convert_to_bf16(hipStream_t stream, const void* in, int dtype, uint16
 int launch_convert_to_f32(hipStream_t stream, const void* in, int dtype, float* out, int64_t n);
 // out rows permuted: out[r,:] = in[perm(r),:], SwiGLU interleave of a [2h,K] matrix (see gemm.hip)
 int launch_swiglu_interleave_rows(hipStream_t stream, const uint16_t* in, uint16_t* out, int hidden, int K);
+// w[i] = bf16(f32(w[i]) + f32(delta[i]))  (LoRA merge, WeightLoader.swift:823-838)
+int launch_bf16_add_inplace(hipStream_t stream, uint16_t* w, const uint16_t* delta, int64_t n);
+// quanto qint8: out_bf16[r, c] = bf16(f32(data[r, c]) * scale[r])  (WeightLoader.swift:347-363)
+int launch_dequant_i8_rows(hipStream_t stream, const int8_t* data, const float* scale, uint16_t* out, int rows, int cols);
 int launch_axpy(hipStream_t stream, float* x, const float* v, float a, int64_t n);                 // x += a*v
 int launch_lerp(hipStream_t stream, float* out, const float* a, const float* b, float t, int64_t n); // (1-t)a + t b
 int launch_cfg_combine(hipStream_t stream, float* vc, const float* vu, float g, int64_t n);

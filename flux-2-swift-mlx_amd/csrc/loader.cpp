@@ -1,0 +1,244 @@
+// loader.cpp — safetensors ingestion for the DiT and the VAE (replaces the file side of
+// Loading/WeightLoader.swift:24-78 `loadWeights(from:)` + the key handling of :306-345).
+//
+// Format: 8-byte little-endian header length N, N bytes of JSON
+//   { "<key>": {"dtype": "BF16"|"F16"|"F32"|"I8", "shape": [...], "data_offsets": [begin, end]}, ...,
+//     "__metadata__": {...} }
+// followed by the tensor bytes.  The file is mmap'ed and every tensor the model's registry knows is
+// handed to flux2mi_{dit,vae}_set_tensor straight from the mapping (the H2D copy is the only copy).
+// Keys: an optional "transformer." / "vae." prefix is dropped (WeightLoader.swift:322-325); quanto
+// int8 pairs "<key>._data" + "<key>._scale" are de-quantised on the device; "*.input_scale" /
+// "*.output_scale" are skipped (:336-338); other unknown keys are counted and skipped.
+#include <errno.h>
+#include <fcntl.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "../../include/flux2mi.h"
+
+namespace {
+
+struct TensorInfo {
+    std::string dtype;
+    std::vector<int64_t> shape;
+    uint64_t begin = 0, end = 0;
+};
+
+// Minimal JSON reader for the safetensors header (objects, arrays, strings, integers).
+struct Json {
+    const char* p;
+    const char* e;
+    bool ok = true;
+    void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
+    bool eat(char c) { ws(); if (p < e && *p == c) { ++p; return true; } return false; }
+    std::string str() {
+        std::string s;
+        ws();
+        if (p >= e || *p != '"') { ok = false; return s; }
+        ++p;
+        while (p < e && *p != '"') {
+            if (*p == '\\' && p + 1 < e) {
+                ++p;
+                switch (*p) {
+                    case 'n': s += '\n'; break;
+                    case 't': s += '\t'; break;
+                    case 'u': s += '?'; p += 4; break;   // keys of interest are ASCII
+                    default: s += *p;
+                }
+                ++p;
+            } else {
+                s += *p++;
+            }
+        }
+        if (p >= e) { ok = false; return s; }
+        ++p;
+        return s;
+    }
+    int64_t integer() {
+        ws();
+        bool neg = false;
+        if (p < e && *p == '-') { neg = true; ++p; }
+        if (p >= e || *p < '0' || *p > '9') { ok = false; return 0; }
+        int64_t v = 0;
+        while (p < e && *p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0');
+        return neg ? -v : v;
+    }
+    void skip_value() {   // any JSON value
+        ws();
+        if (p >= e) { ok = false; return; }
+        if (*p == '"') { (void)str(); return; }
+        if (*p == '{' || *p == '[') {
+            const char open = *p, close = (*p == '{') ? '}' : ']';
+            int depth = 0;
+            while (p < e) {
+                if (*p == '"') { (void)str(); continue; }
+                if (*p == open) ++depth;
+                else if (*p == close && --depth == 0) { ++p; return; }
+                ++p;
+            }
+            ok = false;
+            return;
+        }
+        while (p < e && *p != ',' && *p != '}' && *p != ']') ++p;
+    }
+};
+
+struct MappedFile {
+    int fd = -1;
+    uint8_t* base = nullptr;
+    size_t size = 0;
+    ~MappedFile() {
+        if (base) munmap(base, size);
+        if (fd >= 0) close(fd);
+    }
+};
+
+int parse_safetensors(const char* path, MappedFile& f, std::map<std::string, TensorInfo>& out, const uint8_t** data) {
+    f.fd = open(path, O_RDONLY);
+    if (f.fd < 0) {
+        flux2mi_set_error("load_safetensors: cannot open '%s': %s", path, strerror(errno));
+        return FLUX2MI_ERR_INVALID_ARG;
+    }
+    struct stat st;
+    if (fstat(f.fd, &st) != 0 || st.st_size < 8) {
+        flux2mi_set_error("load_safetensors: '%s' is not a safetensors file (size)", path);
+        return FLUX2MI_ERR_INVALID_ARG;
+    }
+    f.size = (size_t)st.st_size;
+    void* m = mmap(nullptr, f.size, PROT_READ, MAP_PRIVATE, f.fd, 0);
+    if (m == MAP_FAILED) {
+        flux2mi_set_error("load_safetensors: mmap('%s') failed: %s", path, strerror(errno));
+        return FLUX2MI_ERR_OOM;
+    }
+    f.base = static_cast<uint8_t*>(m);
+    uint64_t hlen = 0;
+    memcpy(&hlen, f.base, 8);
+    if (hlen == 0 || hlen > f.size - 8) {
+        flux2mi_set_error("load_safetensors: '%s': bad header length %llu", path, (unsigned long long)hlen);
+        return FLUX2MI_ERR_INVALID_ARG;
+    }
+    Json j{reinterpret_cast<const char*>(f.base + 8), reinterpret_cast<const char*>(f.base + 8 + hlen)};
+    if (!j.eat('{')) j.ok = false;
+    while (j.ok) {
+        if (j.eat('}')) break;
+        std::string key = j.str();
+        if (!j.ok || !j.eat(':')) { j.ok = false; break; }
+        if (key == "__metadata__") {
+            j.skip_value();
+        } else {
+            TensorInfo t;
+            if (!j.eat('{')) { j.ok = false; break; }
+            while (j.ok) {
+                if (j.eat('}')) break;
+                std::string field = j.str();
+                if (!j.eat(':')) { j.ok = false; break; }
+                if (field == "dtype") t.dtype = j.str();
+                else if (field == "shape") {
+                    if (!j.eat('[')) { j.ok = false; break; }
+                    while (j.ok && !j.eat(']')) { t.shape.push_back(j.integer()); (void)j.eat(','); }
+                } else if (field == "data_offsets") {
+                    if (!j.eat('[')) { j.ok = false; break; }
+                    t.begin = (uint64_t)j.integer(); (void)j.eat(',');
+                    t.end = (uint64_t)j.integer();
+                    if (!j.eat(']')) j.ok = false;
+                } else j.skip_value();
+                (void)j.eat(',');
+            }
+            if (t.end < t.begin || 8 + hlen + t.end > f.size) {
+                flux2mi_set_error("load_safetensors: '%s': tensor '%s' lies outside the file", path, key.c_str());
+                return FLUX2MI_ERR_INVALID_ARG;
+            }
+            out[key] = t;
+        }
+        (void)j.eat(',');
+    }
+    if (!j.ok) {
+        flux2mi_set_error("load_safetensors: '%s': malformed header", path);
+        return FLUX2MI_ERR_INVALID_ARG;
+    }
+    *data = f.base + 8 + hlen;
+    return FLUX2MI_OK;
+}
+
+int st_dtype(const std::string& s) {
+    if (s == "F32") return FLUX2MI_F32;
+    if (s == "BF16") return FLUX2MI_BF16;
+    if (s == "F16") return FLUX2MI_F16;
+    return -1;
+}
+
+bool ends_with(const std::string& s, const char* suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+template <class SetFn, class Q8Fn>
+int load_all(const char* path, const char* const* prefixes, SetFn set_tensor, Q8Fn set_q8, int* n_loaded, int* n_skipped) {
+    MappedFile f;
+    std::map<std::string, TensorInfo> ts;
+    const uint8_t* data = nullptr;
+    F2_TRY(parse_safetensors(path, f, ts, &data));
+    int loaded = 0, skipped = 0;
+    for (const auto& kv : ts) {
+        std::string key = kv.first;
+        for (const char* const* pf = prefixes; *pf; ++pf)
+            if (key.compare(0, strlen(*pf), *pf) == 0) { key = key.substr(strlen(*pf)); break; }
+        const TensorInfo& t = kv.second;
+        if (ends_with(key, ".input_scale") || ends_with(key, ".output_scale") || ends_with(key, "._scale")) continue;
+        if (ends_with(key, "._data")) {   // quanto qint8: needs its "._scale" partner
+            const std::string base = key.substr(0, key.size() - 6);
+            auto sc = ts.find(kv.first.substr(0, kv.first.size() - 6) + "._scale");
+            if (t.dtype != "I8" || t.shape.size() != 2 || sc == ts.end() || sc->second.dtype != "F32" ||
+                (int64_t)((sc->second.end - sc->second.begin) / 4) != t.shape[0]) {
+                flux2mi_set_error("load_safetensors: '%s': quantised tensor '%s' without a matching f32 per-row ._scale",
+                                  path, kv.first.c_str());
+                return FLUX2MI_ERR_SHAPE;
+            }
+            const int r = set_q8(base.c_str(), reinterpret_cast<const int8_t*>(data + t.begin),
+                                 reinterpret_cast<const float*>(data + sc->second.begin), t.shape[0], t.shape[1]);
+            if (r == FLUX2MI_ERR_INVALID_ARG) { ++skipped; continue; }   // unknown key
+            F2_TRY(r);
+            ++loaded;
+            continue;
+        }
+        const int dt = st_dtype(t.dtype);
+        if (dt < 0) { ++skipped; continue; }
+        const int r = set_tensor(key.c_str(), dt, t.shape.data(), (int)t.shape.size(), data + t.begin);
+        if (r == FLUX2MI_ERR_INVALID_ARG) { ++skipped; continue; }       // key of another component
+        F2_TRY(r);
+        ++loaded;
+    }
+    if (n_loaded) *n_loaded = loaded;
+    if (n_skipped) *n_skipped = skipped;
+    return FLUX2MI_OK;
+}
+
+}  // namespace
+
+extern "C" int flux2mi_dit_load_safetensors(flux2mi_dit* dit, const char* path, int* n_loaded, int* n_skipped) {
+    F2_REQUIRE(dit && path, FLUX2MI_ERR_INVALID_ARG, "dit_load_safetensors: NULL argument");
+    static const char* const prefixes[] = {"transformer.", "model.diffusion_model.", nullptr};
+    return load_all(
+        path, prefixes,
+        [&](const char* k, int dt, const int64_t* sh, int nd, const void* p) { return flux2mi_dit_set_tensor(dit, k, dt, sh, nd, p); },
+        [&](const char* k, const int8_t* d, const float* s, int64_t r, int64_t c) { return flux2mi_dit_set_tensor_q8(dit, k, d, s, r, c); },
+        n_loaded, n_skipped);
+}
+
+extern "C" int flux2mi_vae_load_safetensors(flux2mi_vae* vae, const char* path, int* n_loaded, int* n_skipped) {
+    F2_REQUIRE(vae && path, FLUX2MI_ERR_INVALID_ARG, "vae_load_safetensors: NULL argument");
+    static const char* const prefixes[] = {"vae.", nullptr};
+    return load_all(
+        path, prefixes,
+        [&](const char* k, int dt, const int64_t* sh, int nd, const void* p) { return flux2mi_vae_set_tensor(vae, k, dt, sh, nd, p); },
+        [&](const char*, const int8_t*, const float*, int64_t, int64_t) { return (int)FLUX2MI_ERR_INVALID_ARG; },
+        n_loaded, n_skipped);
+}

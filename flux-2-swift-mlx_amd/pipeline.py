@@ -18,6 +18,8 @@ import ctypes as C
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
 
+import os
+
 import numpy as np
 import torch
 
@@ -72,13 +74,74 @@ class Flux2Pipeline:
         self.transformer: Optional[DiT] = None
         self.vae: Optional[VAE] = None
 
-    # loadModels(progressCallback:) — weights are handed over as tensors by key
+    # loadModels(progressCallback:) — weights are handed over as tensors by key, or as .safetensors
+    # paths (a str, or a list of shard paths) read by the native loader
     def load_models(self, dit_tensors=None, vae_tensors=None):
+        def _is_paths(x):
+            return isinstance(x, (str, os.PathLike)) or (isinstance(x, (list, tuple)) and x and isinstance(x[0], (str, os.PathLike)))
+
         if dit_tensors is not None:
-            self.transformer = DiT(self.ctx, self.model, weights=self.quantization).load(dit_tensors).finalize()
+            dit = DiT(self.ctx, self.model, weights=self.quantization)
+            if _is_paths(dit_tensors):
+                for path in ([dit_tensors] if isinstance(dit_tensors, (str, os.PathLike)) else dit_tensors):
+                    dit.load_safetensors(path)
+            else:
+                dit.load(dit_tensors)
+            self.transformer = dit.finalize()
         if vae_tensors is not None:
-            self.vae = VAE(self.ctx, self.vae_variant).load(vae_tensors).finalize()
+            vae = VAE(self.ctx, self.vae_variant)
+            if _is_paths(vae_tensors):
+                for path in ([vae_tensors] if isinstance(vae_tensors, (str, os.PathLike)) else vae_tensors):
+                    vae.load_safetensors(path)
+            else:
+                vae.load(vae_tensors)
+            self.vae = vae.finalize()
         return self
+
+    # ---- LoRA (Flux2Pipeline.swift:618-689, LoRA/LoRALoader.swift, WeightLoader.mergeLoRAWeights) ------
+    def load_lora(self, path: str, scale: Optional[float] = None) -> int:
+        """`loadLoRA(LoRAConfig(filePath:scale:))`: reads `<layer>.lora_A.weight` / `.lora_B.weight` pairs
+        (prefixes `base_model.model.` / `transformer.` dropped), scale = (metadata lora_alpha / lora_rank,
+        default 1) x `scale` (LoRAConfig.effectiveScale, default 1), and merges W += s B A into the resident
+        bf16 weights.  Returns the number of merged layers; layers the transformer does not have are skipped
+        like in the reference (:783-789)."""
+        from safetensors import safe_open
+        if self.transformer is None:
+            raise Flux2Error(L.ERR_NOT_LOADED, "Transformer")
+        merged = 0
+        with safe_open(str(path), framework="pt") as f:
+            md = f.metadata() or {}
+            s = 1.0
+            try:
+                if float(md.get("lora_rank", 0)) > 0:
+                    s = float(md["lora_alpha"]) / float(md["lora_rank"])
+            except (KeyError, ValueError):
+                s = 1.0
+            s *= 1.0 if scale is None else float(scale)
+            keys = set(f.keys())
+            for k in sorted(keys):
+                if not k.endswith(".lora_A.weight"):
+                    continue
+                base = k[:-len(".lora_A.weight")]
+                kb = base + ".lora_B.weight"
+                if kb not in keys:
+                    continue
+                layer = base
+                for pre in ("base_model.model.", "transformer."):
+                    if layer.startswith(pre):
+                        layer = layer[len(pre):]
+                try:
+                    self.transformer.merge_lora(layer + ".weight", f.get_tensor(k), f.get_tensor(kb), s)
+                    merged += 1
+                except Flux2Error as e:
+                    if e.code != L.ERR_INVALID_ARG:   # unknown layer: skip; anything else is an error
+                        raise
+        self._lora = getattr(self, "_lora", []) + [str(path)]
+        return merged
+
+    @property
+    def hasLoRA(self) -> bool:
+        return bool(getattr(self, "_lora", []))
 
     @property
     def isLoaded(self) -> bool:

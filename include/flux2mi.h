@@ -135,7 +135,22 @@ int flux2mi_dit_destroy(flux2mi_dit* dit);
  * are built here. */
 int flux2mi_dit_set_tensor(flux2mi_dit* dit, const char* name, int dtype, const int64_t* shape, int ndim,
                            const void* data);
-int flux2mi_dit_finalize(flux2mi_dit* dit); /* error if a tensor is missing */
+int flux2mi_dit_finalize(flux2mi_dit* dit);
+
+/* ---- on-disk formats (Loading/WeightLoader.swift) ---------------------------------------------- */
+/* Read a .safetensors file (BFL or diffusers key scheme, F32/BF16/F16, optional "transformer." prefix,
+ * quanto qint8 "<key>._data" + "<key>._scale" pairs de-quantised on the device — WeightLoader.swift:24-78,
+ * 306-363) and ingest every tensor this model knows; tensors of other components are skipped and
+ * counted.  Call once per shard, then flux2mi_dit_finalize(). */
+int flux2mi_dit_load_safetensors(flux2mi_dit* dit, const char* path, int* n_loaded, int* n_skipped);
+/* One quanto qint8 tensor: data int8 [rows,cols], scale f32 [rows]; weight = data * scale (:347-363). */
+int flux2mi_dit_set_tensor_q8(flux2mi_dit* dit, const char* name, const int8_t* data, const float* scale,
+                              int64_t rows, int64_t cols);
+/* LoRA merge into the resident bf16 weight: W += scale * (B A), A [rank,in], B [out,rank] of `dtype`
+ * (WeightLoader.mergeLoRAWeights :736-856, LoRA/LoRAConfig.swift:7-35; scale = alpha/rank x user scale).
+ * `name` = checkpoint key of the target weight.  Not available for weight_format 1. */
+int flux2mi_dit_merge_lora(flux2mi_dit* dit, const char* name, int dtype, const void* A, const void* B, int rank,
+                           float scale); /* error if a tensor is missing */
 int64_t flux2mi_dit_param_bytes(const flux2mi_dit* dit);
 /* Flux2Transformer2DModel.callAsFunction (Transformer/Flux2Transformer.swift:123-327), async.
  *   latents   f32 [s_img, 128] device  (output tokens first, then reference tokens)
@@ -185,6 +200,7 @@ int flux2mi_vae_destroy(flux2mi_vae* vae);
 int flux2mi_vae_set_tensor(flux2mi_vae* vae, const char* name, int dtype, const int64_t* shape, int ndim,
                            const void* data);
 int flux2mi_vae_finalize(flux2mi_vae* vae);
+int flux2mi_vae_load_safetensors(flux2mi_vae* vae, const char* path, int* n_loaded, int* n_skipped);
 const float* flux2mi_vae_bn_mean(const flux2mi_vae* vae); /* device f32 [128] */
 const float* flux2mi_vae_bn_var(const flux2mi_vae* vae);  /* device f32 [128] */
 /* AutoencoderKLFlux2.decode (VAE/AutoencoderKL.swift:129-143) + postprocessVAEOutput

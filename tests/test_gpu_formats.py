@@ -1,0 +1,214 @@
+"""-m gpu: on-disk formats: native safetensors reader, quanto qint8 pairs, LoRA merge.
+The checks compare model outputs after ingestion through the format path with outputs after ingestion
+of the equivalent in-memory tensors (bit-identical where the arithmetic is the same), and the LoRA merge
+against the oracle run on merged weights."""
+import os
+
+import pytest
+import torch
+
+from oracle import flux2_ref as R
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _fwd(dit, cfg, inp, lat, h, w, s_txt):
+    from flux2mi import api
+    return dit.forward(lat.cuda(), inp["txt"].cuda(), 0.6, 4.0, torch.from_numpy(api.image_position_ids(h, w)).cuda(),
+                       torch.from_numpy(api.text_position_ids(s_txt)).cuda()).cpu()
+
+
+def _setup(seed=31):
+    from flux2mi import synthetic as syn
+    cfg = syn.DIT_PRESETS["tiny"]
+    P = syn.make_dit_weights(cfg, seed=seed, std=0.05)
+    inp = syn.make_inputs(cfg, 64, 64, s_txt=16)
+    return syn, cfg, P, inp, R.pack_patchified_to_sequence(inp["noise"])[0]
+
+
+def _to_diffusers(P, cfg):
+    """BFL-named synthetic weights re-keyed to the diffusers scheme (split q/k/v, swapped adaLN halves)."""
+    d = cfg["dim"]
+    D = {}
+    ren = {"img_in.weight": "x_embedder.weight", "txt_in.weight": "context_embedder.weight",
+           "time_in.in_layer.weight": "time_guidance_embed.timestep_embedder.linear_1.weight",
+           "time_in.out_layer.weight": "time_guidance_embed.timestep_embedder.linear_2.weight",
+           "double_stream_modulation_img.lin.weight": "double_stream_modulation_img.linear.weight",
+           "double_stream_modulation_txt.lin.weight": "double_stream_modulation_txt.linear.weight",
+           "single_stream_modulation.lin.weight": "single_stream_modulation.linear.weight",
+           "final_layer.linear.weight": "proj_out.weight"}
+    for k, v in P.items():
+        if k in ren:
+            D[ren[k]] = v
+        elif k == "final_layer.adaLN_modulation.1.weight":
+            D["norm_out.linear.weight"] = torch.cat([v[d:], v[:d]], 0)
+        elif k.startswith("double_blocks."):
+            i = k.split(".")[1]
+            t = f"transformer_blocks.{i}."
+            for s, (q, kk, vv, o, nq, nk, ff) in {"img": ("to_q", "to_k", "to_v", "to_out.0", "norm_q", "norm_k", "ff"),
+                                                  "txt": ("add_q_proj", "add_k_proj", "add_v_proj", "to_add_out", "norm_added_q", "norm_added_k", "ff_context")}.items():
+                if k.endswith(f"{s}_attn.qkv.weight"):
+                    D[t + f"attn.{q}.weight"], D[t + f"attn.{kk}.weight"], D[t + f"attn.{vv}.weight"] = v[:d], v[d:2 * d], v[2 * d:]
+                elif k.endswith(f"{s}_attn.proj.weight"):
+                    D[t + f"attn.{o}.weight"] = v
+                elif k.endswith(f"{s}_attn.norm.query_norm.scale"):
+                    D[t + f"attn.{nq}.weight"] = v
+                elif k.endswith(f"{s}_attn.norm.key_norm.scale"):
+                    D[t + f"attn.{nk}.weight"] = v
+                elif k.endswith(f"{s}_mlp.0.weight"):
+                    D[t + f"{ff}.linear_in.weight"] = v
+                elif k.endswith(f"{s}_mlp.2.weight"):
+                    D[t + f"{ff}.linear_out.weight"] = v
+        elif k.startswith("single_blocks."):
+            i = k.split(".")[1]
+            t = f"single_transformer_blocks.{i}.attn."
+            tail = k.split(".", 2)[2]
+            D[t + {"linear1.weight": "to_qkv_mlp_proj.weight", "linear2.weight": "to_out.weight",
+                   "norm.query_norm.scale": "norm_q.weight", "norm.key_norm.scale": "norm_k.weight"}[tail]] = v
+    return D
+
+
+def test_safetensors_bfl_and_diffusers_prefixed(flux2mi, ctx, tmp_path):
+    """The native reader on a BFL-keyed bf16 file and on a diffusers-keyed f16/f32 file with the
+    `transformer.` prefix and foreign tensors: same output as in-memory ingestion (bit-identical for
+    bf16; the f16 file carries bf16-exact values, so identical too)."""
+    from safetensors.torch import save_file
+    from flux2mi.api import DiT
+    syn, cfg, P, inp, lat = _setup()
+    base = DiT(ctx, cfg).load(P).finalize()
+    ref = _fwd(base, cfg, inp, lat, 64, 64, 16)
+    base.close()
+    f1 = str(tmp_path / "bfl.safetensors")
+    save_file({k: v.contiguous() for k, v in P.items()}, f1, metadata={"format": "pt"})
+    d1 = DiT(ctx, cfg)
+    n, skipped = d1.load_safetensors(f1)
+    assert n == len(P) and skipped == 0
+    assert torch.equal(_fwd(d1.finalize(), cfg, inp, lat, 64, 64, 16), ref)
+    d1.close()
+    D = _to_diffusers(P, cfg)
+    tens = {"transformer." + k: (v.to(torch.float16) if i % 2 else v.float()).contiguous() for i, (k, v) in enumerate(sorted(D.items()))}
+    tens["text_encoder.embed.weight"] = torch.zeros((4, 4))
+    tens["transformer.something.input_scale"] = torch.ones((1,))
+    f2 = str(tmp_path / "diffusers.safetensors")
+    save_file(tens, f2)
+    d2 = DiT(ctx, cfg)
+    n, skipped = d2.load_safetensors(f2)
+    assert n == len(D) and skipped == 1
+    out = _fwd(d2.finalize(), cfg, inp, lat, 64, 64, 16)
+    d2.close()
+    # f16 cannot hold every bf16 value exactly (exponent range), so allow rounding-level differences
+    assert rel_l2(out, ref) < 2e-3
+
+
+def test_safetensors_errors(flux2mi, ctx, tmp_path):
+    from flux2mi import Flux2Error
+    from flux2mi.api import DiT
+    syn, cfg, P, inp, lat = _setup()
+    d = DiT(ctx, cfg)
+    with pytest.raises(Flux2Error):
+        d.load_safetensors(str(tmp_path / "missing.safetensors"))
+    bad = tmp_path / "bad.safetensors"
+    bad.write_bytes(b"\x10\x00\x00\x00\x00\x00\x00\x00{not json at all}")
+    with pytest.raises(Flux2Error):
+        d.load_safetensors(str(bad))
+    with pytest.raises(Flux2Error):   # nothing loaded -> finalize names the first missing tensor
+        d.finalize()
+    d.close()
+
+
+def test_quanto_qint8_pairs(flux2mi, ctx, tmp_path):
+    """quanto `._data` / `._scale` pairs: weight = int8 * scale (WeightLoader.swift:347-363).  Checked
+    against in-memory ingestion of the same de-quantised values (bit-identical) and, loosely, against
+    the unquantised model (int8 per-row quantisation: ~1e-2)."""
+    from safetensors.torch import save_file
+    from flux2mi.api import DiT
+    syn, cfg, P, inp, lat = _setup()
+    tens, deq = {}, {}
+    for k, v in P.items():
+        if v.dim() == 2 and v.shape[0] >= 128 and "norm" not in k:
+            sc = (v.float().abs().amax(dim=1, keepdim=True) / 127.0).clamp_min(1e-12)
+            q = torch.round(v.float() / sc).clamp(-127, 127).to(torch.int8)
+            tens["transformer." + k + "._data"] = q
+            tens["transformer." + k + "._scale"] = sc.float()
+            deq[k] = (q.float() * sc).to(torch.bfloat16)
+        else:
+            tens["transformer." + k] = v.contiguous()
+            deq[k] = v
+    path = str(tmp_path / "qint8.safetensors")
+    save_file(tens, path)
+    a = DiT(ctx, cfg)
+    n, skipped = a.load_safetensors(path)
+    assert n == len(P) and skipped == 0
+    out_q = _fwd(a.finalize(), cfg, inp, lat, 64, 64, 16)
+    a.close()
+    b = DiT(ctx, cfg).load(deq).finalize()
+    assert torch.equal(out_q, _fwd(b, cfg, inp, lat, 64, 64, 16))
+    b.close()
+    c = DiT(ctx, cfg).load(P).finalize()
+    assert rel_l2(out_q, _fwd(c, cfg, inp, lat, 64, 64, 16)) < 3e-2
+    c.close()
+
+
+def test_lora_merge_vs_oracle(flux2mi, ctx, tmp_path):
+    """`loadLoRA` + merge: W += (alpha/rank) * scale * B A on layers of every layout class (fused q/k/v
+    via diffusers keys, SwiGLU-interleaved mlp, single-block linear1, plain proj) vs the oracle run on
+    weights merged in f32; rel-L2 <= 2e-2 and the merge must matter (> 1e-2 away from the base model)."""
+    from safetensors.torch import save_file
+    from flux2mi.pipeline import Flux2Pipeline
+    syn, cfg, P, inp, lat = _setup()
+    d, rank, alpha = cfg["dim"], 8, 16.0
+    g = torch.Generator().manual_seed(3)
+    targets = {  # LoRA layer path (diffusers naming) -> (BFL key, row slice)
+        "transformer_blocks.0.attn.to_k": ("double_blocks.0.img_attn.qkv.weight", slice(d, 2 * d)),
+        "transformer_blocks.0.attn.add_q_proj": ("double_blocks.0.txt_attn.qkv.weight", slice(0, d)),
+        "transformer_blocks.0.ff.linear_in": ("double_blocks.0.img_mlp.0.weight", slice(None)),
+        "transformer_blocks.0.attn.to_out.0": ("double_blocks.0.img_attn.proj.weight", slice(None)),
+        "single_transformer_blocks.1.attn.to_qkv_mlp_proj": ("single_blocks.1.linear1.weight", slice(None)),
+        "single_transformer_blocks.0.attn.to_out": ("single_blocks.0.linear2.weight", slice(None)),
+        "not_a_layer_of_this_model.proj": (None, None),
+    }
+    lora, Pm = {}, {k: v.float().clone() for k, v in P.items()}
+    user_scale = 0.8
+    for layer, (key, rows) in targets.items():
+        out_f, in_f = (64, 64) if key is None else (Pm[key][rows].shape[0], Pm[key].shape[1])
+        A = (torch.randn((rank, in_f), generator=g) * 0.1).to(torch.bfloat16)
+        B = (torch.randn((out_f, rank), generator=g) * 0.1).to(torch.bfloat16)
+        lora[f"transformer.{layer}.lora_A.weight"] = A
+        lora[f"transformer.{layer}.lora_B.weight"] = B
+        if key is not None:
+            Pm[key][rows] += (alpha / rank) * user_scale * (B.float() @ A.float())
+    path = str(tmp_path / "lora.safetensors")
+    save_file(lora, path, metadata={"lora_alpha": str(alpha), "lora_rank": str(rank)})
+    vcfg = syn.VAE_PRESETS["tiny"]
+    pipe = Flux2Pipeline(model=cfg, vae_variant=vcfg).load_models(P, syn.make_vae_weights(vcfg))
+    base = _fwd(pipe.transformer, cfg, inp, lat, 64, 64, 16)
+    assert not pipe.hasLoRA
+    assert pipe.load_lora(path, scale=user_scale) == 6
+    assert pipe.hasLoRA
+    out = _fwd(pipe.transformer, cfg, inp, lat, 64, 64, 16)
+    ref = R.dit_forward(Pm, cfg, lat.unsqueeze(0), inp["txt"].float(), torch.tensor([0.6]), None,
+                        R.image_position_ids(64, 64), R.text_position_ids(16))[0]
+    assert rel_l2(out, ref) < 2e-2
+    assert rel_l2(out, base) > 1e-2
+
+
+def test_vae_safetensors(flux2mi, ctx, tmp_path):
+    from safetensors.torch import save_file
+    from flux2mi import synthetic as syn
+    from flux2mi.api import VAE
+    vcfg = syn.VAE_PRESETS["tiny"]
+    VP = syn.make_vae_weights(vcfg)
+    path = str(tmp_path / "vae.safetensors")
+    tens = {k: v.contiguous() for k, v in VP.items()}
+    tens["bn.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    save_file(tens, path)
+    a = VAE(ctx, vcfg)
+    n, skipped = a.load_safetensors(path)
+    assert n == len(VP)
+    a.finalize()
+    b = VAE(ctx, vcfg).load(VP).finalize()
+    z = torch.randn((1, 32, 8, 8), generator=torch.Generator().manual_seed(2)).cuda()
+    assert torch.equal(a.decode(z)[1], b.decode(z)[1])
+    assert a.has_encoder
+    a.close(); b.close()
