@@ -11,7 +11,7 @@ from . import synthetic  # noqa: F401
 
 def __getattr__(name):
     # torch-dependent modules are imported lazily
-    if name in ("api", "pipeline", "parallel"):
+    if name in ("api", "pipeline", "parallel", "textenc"):
         import importlib
         return importlib.import_module(f"{__name__}.{name}")
     raise AttributeError(name)

@@ -30,6 +30,12 @@ class DitConfig(C.Structure):
                 ("joint_dim", C.c_int), ("guidance_embeds", C.c_int), ("weight_format", C.c_int)]
 
 
+class TextEncConfig(C.Structure):
+    _fields_ = [("vocab", C.c_int), ("hidden", C.c_int), ("intermediate", C.c_int), ("n_layers", C.c_int),
+                ("heads", C.c_int), ("kv_heads", C.c_int), ("head_dim", C.c_int), ("rope_theta", C.c_float),
+                ("rms_eps", C.c_float), ("extract_layers", C.c_int * 3)]
+
+
 class VaeConfig(C.Structure):
     _fields_ = [("channels", C.c_int * 4), ("latent_channels", C.c_int), ("groups", C.c_int),
                 ("layers_per_block", C.c_int)]
@@ -104,6 +110,13 @@ PROTOTYPES = {
     "flux2mi_kv_cache_destroy": (_I, [_P]),
     "flux2mi_dit_forward_kv_extract": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _F, _F, _P, _P, _P, _P]),
     "flux2mi_dit_forward_kv_cached": (_I, [_P, _P, _P, _I, _P, _I, _F, _F, _P, _P, _P]),
+    "flux2mi_textenc_preset": (_I, [C.c_char_p, C.POINTER(TextEncConfig)]),
+    "flux2mi_textenc_create": (_I, [_P, C.POINTER(TextEncConfig), C.POINTER(_P)]),
+    "flux2mi_textenc_destroy": (_I, [_P]),
+    "flux2mi_textenc_set_tensor": (_I, [_P, C.c_char_p, _I, C.POINTER(_I64), _I, _P]),
+    "flux2mi_textenc_finalize": (_I, [_P]),
+    "flux2mi_textenc_param_bytes": (_I64, [_P]),
+    "flux2mi_textenc_forward": (_I, [_P, _P, _I, _I, _P]),
     "flux2mi_vae_preset": (_I, [C.c_char_p, C.POINTER(VaeConfig)]),
     "flux2mi_vae_create": (_I, [_P, C.POINTER(VaeConfig), C.POINTER(_P)]),
     "flux2mi_vae_destroy": (_I, [_P]),

@@ -31,11 +31,14 @@ constexpr int K_TILE_BYTES = BKV * HD * 2;   // 16 KB
 constexpr int V_TILE_BYTES = HD * BKV * 2;   // 16 KB
 constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;
 
+// CAUSAL (text encoder, Qwen3Model.swift:176-212): query row i sees keys j <= i and j < valid_len
+// (right padding); kv_rep query heads share one K/V head (GQA, Qwen3Attention.swift:135-147).
+template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ q,
                                                           const uint16_t* __restrict__ k, int ldqk,
                                                           const uint16_t* __restrict__ vt, int s_pad,
                                                           uint16_t* __restrict__ out, int ldo, int Sq, int S,
-                                                          float scale_log2e) {
+                                                          float scale_log2e, int valid_len, int kv_rep) {
     // Sq query rows (q / out already point at the first of them), S keys (k / vt from key 0)
     __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE_BYTES];
 
@@ -52,8 +55,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
 
     // ---- staging assignment
-    const uint16_t* kbase = k + head * HD;
-    const uint16_t* vbase = vt + (size_t)head * HD * s_pad;
+    const int kv_head = CAUSAL ? head / kv_rep : head;
+    const uint16_t* kbase = k + kv_head * HD;
+    const uint16_t* vbase = vt + (size_t)kv_head * HD * s_pad;
     int k_row[4], k_chunk[4], k_lds[4], v_lds[4];
     const uint16_t* v_src[4];
 #pragma unroll
@@ -102,7 +106,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int nt = (S + BKV - 1) / BKV;
+    // keys this block can see at all, and the per-lane limit of the causal form
+    const int key_lim_blk = CAUSAL ? min(min(valid_len, S), q0 + BQ) : S;
+    const int key_lim = CAUSAL ? min(min(valid_len, S), qrow + 1) : S;
+    const int wave_lim = CAUSAL ? min(min(valid_len, S), q0 + wid * 32 + 1) : S;   // smallest limit in the wave
+    const int nt = (key_lim_blk + BKV - 1) / BKV;
     ATTN_LOAD_TILE(0)
     ATTN_STORE_TILE(0)
     // The Q fragments come from global loads issued before the loop.  Without this, hipcc's
@@ -142,14 +150,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
         // scores are only max-reduced; scale and running max go into one fma per element in
         // front of exp2; O and l are rescaled only when some lane's running max grew (exact:
         // alpha == 1 otherwise), which after the first tiles is rare.
-        const bool tail = (kt + 1) * BKV > S;
+        const bool tail = (kt + 1) * BKV > wave_lim;
         if (tail) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kt * BKV + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= S) sa[kb][r] = -INFINITY;
+                    if (key >= key_lim) sa[kb][r] = -INFINITY;
                 }
         }
         // 32 scores -> 16 x v_max3_f32 (asm: hipcc would put a canonicalising v_max in front of
@@ -230,7 +238,19 @@ int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, i
     if (Sq <= 0 || S <= 0 || heads <= 0 || (ldqk & 7) || (ldo & 3) || s_pad < attn_s_pad(S) || (s_pad & 7)) return 1;
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
     dim3 grid((Sq + BQ - 1) / BQ, heads);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S,
-                       scale_log2e);
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S,
+                       scale_log2e, S, 1);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_attention_causal(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
+                            int s_pad, uint16_t* out, int ldo, int S, int valid_len, int heads, int kv_heads) {
+    if (S <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads || valid_len < 1 || valid_len > S || (ldqk & 7) ||
+        (ldo & 3) || s_pad < attn_s_pad(S) || (s_pad & 7))
+        return 1;
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
+    dim3 grid((S + BQ - 1) / BQ, heads);
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, stream, q, k, ldqk, vt, s_pad, out, ldo, S, S,
+                       scale_log2e, valid_len, heads / kv_heads);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

@@ -97,6 +97,21 @@ __global__ void dequant_i8_rows_kernel(const int8_t* __restrict__ data, const fl
         out[i] = f32_to_bf16_bits((float)data[i] * scale[i / cols]);
 }
 
+__global__ void embed_rows_kernel(const int32_t* __restrict__ ids, const uint16_t* __restrict__ table,
+                                  float* __restrict__ hs, int dim, int vocab) {
+    const int row = blockIdx.x;
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // ids are validated on the host side of the C ABI
+    const uint16_t* src = table + (size_t)id * dim;
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) hs[(size_t)row * dim + c] = bf16_bits_to_f32(src[c]);
+}
+__global__ void f32_rows_to_bf16_cols_kernel(const float* __restrict__ hs, uint16_t* __restrict__ out, int dim, int ldo,
+                                             int c0) {
+    const int row = blockIdx.x;
+    for (int c = threadIdx.x; c < dim; c += blockDim.x)
+        out[(size_t)row * ldo + c0 + c] = f32_to_bf16_bits(hs[(size_t)row * dim + c]);
+}
+
 // ---- sampler arithmetic (f32, 16 B/lane)
 __global__ void axpy_kernel(float* __restrict__ x, const float* __restrict__ v, float a, int64_t n4, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -206,6 +221,16 @@ int launch_convert_to_f32(hipStream_t stream, const void* in, int dtype, float* 
 int launch_swiglu_interleave_rows(hipStream_t stream, const uint16_t* in, uint16_t* out, int hidden, int K) {
     if (hidden <= 0 || (hidden & 31) || (K & 7)) return 1;
     hipLaunchKernelGGL(swiglu_interleave_kernel, dim3(2 * hidden), dim3(256), 0, stream, in, out, hidden, K);
+    EW_DONE();
+}
+int launch_embed_rows(hipStream_t stream, const int32_t* ids, const uint16_t* table, float* hs, int S, int dim, int vocab) {
+    if (S <= 0 || dim <= 0 || vocab <= 0) return 1;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(S), dim3(256), 0, stream, ids, table, hs, dim, vocab);
+    EW_DONE();
+}
+int launch_f32_rows_to_bf16_cols(hipStream_t stream, const float* hs, uint16_t* out, int S, int dim, int ldo, int c0) {
+    if (S <= 0 || dim <= 0 || ldo < c0 + dim) return 1;
+    hipLaunchKernelGGL(f32_rows_to_bf16_cols_kernel, dim3(S), dim3(256), 0, stream, hs, out, dim, ldo, c0);
     EW_DONE();
 }
 int launch_bf16_add_inplace(hipStream_t stream, uint16_t* w, const uint16_t* delta, int64_t n) {

@@ -80,6 +80,22 @@ int launch_v_transpose_only(hipStream_t stream, const uint16_t* qkv, int ldqkv, 
 // [heads*128][nkeys]; to_cache = 1: vt -> cache, 0: cache -> vt.  (TransformerKVCache.swift)
 int launch_vt_keys_copy(hipStream_t stream, uint16_t* vt, int s_pad, uint16_t* cache, int heads, int key0, int nkeys,
                         int to_cache);
+// ---- text encoder (Qwen3, FluxTextEncoders/Model/Qwen3/*.swift)
+// y bf16 [rows, dim] = x f32 * rsqrt(mean(x^2) + eps) * w   (RMSNorm with a bf16 weight)
+int launch_rmsnorm_rows(hipStream_t stream, const float* x, const uint16_t* w, uint16_t* y, int rows, int dim, float eps);
+// In place on qkv bf16 [S, (hq + 2 hkv) * 128] = q | k | v: per-head RMSNorm(eps, weight) of q and k, then
+// RoPE in the split-half convention (MLXFast.RoPE traditional: false; pairs (i, i + 64)), position = row,
+// inv_freq_i = theta^(-2i/128).  V is written transposed + key-permuted into vt [hkv][128][s_pad].
+int launch_qk_norm_rope_llm_vt(hipStream_t stream, uint16_t* qkv, int S, int hq, int hkv, const uint16_t* q_w,
+                               const uint16_t* k_w, float eps, float theta, uint16_t* vt, int s_pad);
+// hs f32 [S, dim] = table bf16 [vocab, dim] rows ids[s] (ids on the device; out-of-range ids are an error flag)
+int launch_embed_rows(hipStream_t stream, const int32_t* ids, const uint16_t* table, float* hs, int S, int dim, int vocab);
+// out bf16 [S, ldo] columns [c0, c0 + dim) = hs f32 [S, dim]
+int launch_f32_rows_to_bf16_cols(hipStream_t stream, const float* hs, uint16_t* out, int S, int dim, int ldo, int c0);
+// Causal attention with a right-padding limit and grouped KV heads: query row i of head h attends to keys
+// j <= i, j < valid_len of KV head h / (heads / kv_heads).  Same operand layouts as launch_attention.
+int launch_attention_causal(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
+                            int s_pad, uint16_t* out, int ldo, int S, int valid_len, int heads, int kv_heads);
 int launch_rope_tables(hipStream_t stream, const int32_t* txt_ids, int s_txt, const int32_t* img_ids, int s_img,
                        float* cos_tab, float* sin_tab);
 

@@ -237,11 +237,11 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(uint16_t* __restrict_
 // 8h+4a+b (the k order of an MFMA 32x32 accumulator reused as operand; see attention.hip).
 // One workgroup = 64 keys x 128 d of one head, transposed through LDS.
 __global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __restrict__ qkv, int ldqkv, int S,
-                                                          int heads, uint16_t* __restrict__ vt, int s_pad) {
+                                                          int v_col0, uint16_t* __restrict__ vt, int s_pad) {
     __shared__ uint16_t tile[64][128 + 2];
     const int head = blockIdx.y;
     const int k0 = blockIdx.x * 64;
-    const uint16_t* vsrc = qkv + 2 * heads * 128 + head * 128;
+    const uint16_t* vsrc = qkv + v_col0 + head * 128;
     // load 64 rows x 256 B: 1024 chunks of 16 B, 4 per thread
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -289,6 +289,64 @@ __global__ __launch_bounds__(256) void vt_keys_copy_kernel(uint16_t* __restrict_
         if (to_cache) cache[i] = vt[row * s_pad + col];
         else vt[row * s_pad + col] = cache[i];
     }
+}
+
+// ------------------------------------------------------------------ text encoder (Qwen3)
+// RMSNorm of an f32 row with a bf16 weight -> bf16 (Qwen3DecoderLayer.swift:25-26, MLXNN RMSNorm)
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restrict__ x, const uint16_t* __restrict__ w,
+                                                           uint16_t* __restrict__ y, int dim, float eps) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const float* xr = x + (size_t)row * dim;
+    const int nvec = dim >> 2;
+    float4 v[LN_MAX_VEC];
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < nvec) {
+            v[i] = reinterpret_cast<const float4*>(xr)[c];
+            sq += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        }
+    }
+    const float rstd = rsqrtf(block_sum_256(sq, red) / (float)dim + eps);
+    uint16_t* yr = y + (size_t)row * dim;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < nvec) {
+            const uint2 wv = reinterpret_cast<const uint2*>(w)[c];
+            uint2 pk;
+            pk.x = pack_bf16x2(v[i].x * rstd * lo_bf16(wv.x), v[i].y * rstd * hi_bf16(wv.x));
+            pk.y = pack_bf16x2(v[i].z * rstd * lo_bf16(wv.y), v[i].w * rstd * hi_bf16(wv.y));
+            reinterpret_cast<uint2*>(yr)[c] = pk;
+        }
+    }
+}
+
+// Per (row, head) vector of 128: 64 lanes, lane i holds elements i and i + 64 = one RoPE pair of the
+// split-half convention (Qwen3Attention.swift:110-123: q_norm / k_norm before RoPE, traditional: false).
+__global__ __launch_bounds__(256) void qk_norm_rope_llm_kernel(uint16_t* __restrict__ qkv, int ld, int S, int nvec_heads,
+                                                               int hq, const uint16_t* __restrict__ q_w,
+                                                               const uint16_t* __restrict__ k_w, float eps,
+                                                               float log2_theta) {
+    const int lane = threadIdx.x & 63;
+    const long vec = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // (row, head) over the hq + hkv q/k heads
+    if (vec >= (long)S * nvec_heads) return;
+    const int row = (int)(vec / nvec_heads), head = (int)(vec % nvec_heads);   // heads 0..hq-1 = q, then k
+    uint16_t* p = qkv + (size_t)row * ld + head * 128;
+    const uint16_t* w = head < hq ? q_w : k_w;
+    const float a = bf16_bits_to_f32(p[lane]), b = bf16_bits_to_f32(p[lane + 64]);
+    const float ss = wave_sum(a * a + b * b);
+    const float rstd = rsqrtf(ss * (1.0f / 128.0f) + eps);
+    // the reference normalises in the activation dtype: round the normalised value to bf16 before RoPE
+    const float an = bf16_bits_to_f32(f32_to_bf16_bits(a * rstd * bf16_bits_to_f32(w[lane])));
+    const float bn = bf16_bits_to_f32(f32_to_bf16_bits(b * rstd * bf16_bits_to_f32(w[lane + 64])));
+    const float inv_freq = exp2f(-log2_theta * (float)(2 * lane) * (1.0f / 128.0f));
+    float sn, cs;
+    sincosf((float)row * inv_freq, &sn, &cs);
+    p[lane] = f32_to_bf16_bits(an * cs - bn * sn);
+    p[lane + 64] = f32_to_bf16_bits(bn * cs + an * sn);
 }
 
 // ------------------------------------------------------------------ RoPE tables
@@ -346,16 +404,16 @@ int launch_qk_norm_rope_vt(hipStream_t stream, uint16_t* qkv, int ldqkv, int S, 
     const long total = (long)S * 2 * heads;
     hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, qkv, ldqkv, S,
                        heads, split, qscale0, kscale0, qscale1, kscale1, cos_tab, sin_tab);
-    hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, heads), dim3(256), 0, stream, qkv, ldqkv, S, heads,
-                       vt, s_pad);
+    hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, heads), dim3(256), 0, stream, qkv, ldqkv, S,
+                       2 * heads * 128, vt, s_pad);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
 int launch_v_transpose_only(hipStream_t stream, const uint16_t* qkv, int ldqkv, int S, int heads, uint16_t* vt,
                             int s_pad) {
     if (S <= 0 || heads <= 0 || (ldqkv & 7) || s_pad < attn_s_pad(S)) return 1;
-    hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, heads), dim3(256), 0, stream, qkv, ldqkv, S, heads,
-                       vt, s_pad);
+    hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, heads), dim3(256), 0, stream, qkv, ldqkv, S,
+                       2 * heads * 128, vt, s_pad);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
@@ -366,6 +424,24 @@ int launch_vt_keys_copy(hipStream_t stream, uint16_t* vt, int s_pad, uint16_t* c
     const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
     hipLaunchKernelGGL(vt_keys_copy_kernel, dim3(blocks), dim3(256), 0, stream, vt, s_pad, cache, (long)heads * 128, key0,
                        nkeys, to_cache);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_rmsnorm_rows(hipStream_t stream, const float* x, const uint16_t* w, uint16_t* y, int rows, int dim, float eps) {
+    if (rows <= 0 || dim <= 0 || (dim & 3) || dim > LN_MAX_VEC * 1024) return 1;
+    hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(rows), dim3(256), 0, stream, x, w, y, dim, eps);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_qk_norm_rope_llm_vt(hipStream_t stream, uint16_t* qkv, int S, int hq, int hkv, const uint16_t* q_w,
+                               const uint16_t* k_w, float eps, float theta, uint16_t* vt, int s_pad) {
+    if (S <= 0 || hq <= 0 || hkv <= 0 || theta <= 1.0f || s_pad < attn_s_pad(S)) return 1;
+    const int ld = (hq + 2 * hkv) * 128;
+    const long total = (long)S * (hq + hkv);
+    hipLaunchKernelGGL(qk_norm_rope_llm_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, qkv, ld, S, hq + hkv,
+                       hq, q_w, k_w, eps, log2f(theta));
+    hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, hkv), dim3(256), 0, stream, qkv, ld, S, (hq + hkv) * 128,
+                       vt, s_pad);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -73,6 +73,7 @@ class Flux2Pipeline:
         self.vae_variant = vae_variant
         self.transformer: Optional[DiT] = None
         self.vae: Optional[VAE] = None
+        self.text_encoder = None   # flux2mi.textenc.TextEncoder (Klein: Qwen3), optional
 
     # loadModels(progressCallback:) — weights are handed over as tensors by key, or as .safetensors
     # paths (a str, or a list of shard paths) read by the native loader
@@ -96,6 +97,14 @@ class Flux2Pipeline:
             else:
                 vae.load(vae_tensors)
             self.vae = vae.finalize()
+        return self
+
+    def load_text_encoder(self, config, tensors, tokenizer_json: Optional[str] = None):
+        """Klein text encoder (Qwen3-4B / Qwen3-8B, `KleinTextEncoder`): HF tensors by key + tokenizer.json."""
+        from .textenc import TextEncoder
+        self.text_encoder = TextEncoder(self.ctx, config).load(tensors).finalize()
+        if tokenizer_json is not None:
+            self.text_encoder.set_tokenizer(tokenizer_json)
         return self
 
     # ---- LoRA (Flux2Pipeline.swift:618-689, LoRA/LoRALoader.swift, WeightLoader.mergeLoRAWeights) ------
@@ -184,7 +193,10 @@ class Flux2Pipeline:
         if self.vae is None and not skip_decode:
             raise Flux2Error(L.ERR_NOT_LOADED, "VAE")
         if precomputed_embeddings is None:
-            raise Flux2Error(L.ERR_NOT_LOADED, "TextEncoder (pass precomputed_embeddings; the text encoders are outside the hot path)")
+            # "2. Text Encoding" phase (Flux2Pipeline.swift:1228-1300): Klein models encode the prompt with Qwen3
+            if self.text_encoder is None:
+                raise Flux2Error(L.ERR_NOT_LOADED, "TextEncoder (pass precomputed_embeddings, or load_text_encoder(...) for Klein models)")
+            precomputed_embeddings = self.text_encoder.extract_klein_embeddings(prompt)
         dev = self.ctx.device
         H, W = validate_dimensions(height, width)
         s_img = (H // 16) * (W // 16)

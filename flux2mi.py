@@ -10,7 +10,7 @@ if _root not in sys.path:
     sys.path.insert(0, _root)
 _REAL = "flux-2-swift-mlx_amd"
 _pkg = importlib.import_module(_REAL)
-for _sub in ("_lib", "synthetic", "api", "pipeline", "parallel"):
+for _sub in ("_lib", "synthetic", "api", "pipeline", "parallel", "textenc"):
     _m = importlib.import_module(f"{_REAL}.{_sub}")
     sys.modules[f"{__name__}.{_sub}"] = _m
     setattr(_pkg, _sub, _m)

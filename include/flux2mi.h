@@ -183,6 +183,34 @@ int flux2mi_dit_forward_kv_cached(flux2mi_dit* dit, flux2mi_kv_cache* cache, con
                                   const void* txt_emb, int s_txt, float timestep, float guidance, const int32_t* img_ids,
                                   const int32_t* txt_ids, float* out);
 
+/* ---- text encoder: Qwen3 -> Klein prompt embeddings (FluxTextEncoders) ------------------------------
+ * Replaces Qwen3Model.forwardWithHiddenStates (Model/Qwen3/Qwen3Model.swift:109-174) as driven by
+ * KleinEmbeddingExtractor.extractKleinEmbeddings (Embeddings/KleinEmbeddingExtractor.swift:50-131).
+ * Tokenisation and the chat template stay on the host (string work, :143-162). */
+typedef struct flux2mi_textenc flux2mi_textenc;
+typedef struct flux2mi_textenc_config {
+    int vocab, hidden, intermediate;
+    int n_layers;            /* of the checkpoint; only layers <= extract_layers[2] are stored and run */
+    int heads, kv_heads, head_dim;   /* head_dim must be 128 */
+    float rope_theta;        /* 1e6 */
+    float rms_eps;           /* 1e-6 */
+    int extract_layers[3];   /* 1-based "after layer i" indices, Klein: 9, 18, 27 (KleinConfig.hiddenStateLayers) */
+} flux2mi_textenc_config;
+/* presets "klein-4b" (Qwen3-4B) | "klein-9b" (Qwen3-8B) */
+int flux2mi_textenc_preset(const char* name, flux2mi_textenc_config* out);
+int flux2mi_textenc_create(flux2mi_ctx* ctx, const flux2mi_textenc_config* cfg, flux2mi_textenc** out);
+int flux2mi_textenc_destroy(flux2mi_textenc* te);
+/* HF keys ("model.layers.N.self_attn.q_proj.weight", ..., with or without the "model." prefix);
+ * keys of layers that are not run return FLUX2MI_ERR_INVALID_ARG and can be skipped by the caller. */
+int flux2mi_textenc_set_tensor(flux2mi_textenc* te, const char* name, int dtype, const int64_t* shape, int ndim,
+                               const void* data);
+int flux2mi_textenc_finalize(flux2mi_textenc* te);
+int64_t flux2mi_textenc_param_bytes(const flux2mi_textenc* te);
+/* ids i32 [S] on the device, right-padded; valid_len = number of real tokens (attention mask
+ * [1]*valid_len + [0]*(S - valid_len), causal).  out bf16 [S, 3*hidden] (device) = hidden states
+ * after the three extract layers, concatenated: the DiT's txt_emb.  Async. */
+int flux2mi_textenc_forward(flux2mi_textenc* te, const int32_t* ids, int S, int valid_len, void* out);
+
 /* ---- VAE decoder (AutoencoderKLFlux2.decode) ---------------------------- */
 typedef struct flux2mi_vae_config {
     int channels[4];       /* decoder block_out_channels, e.g. 128,256,512,512 (small: 96,192,384,384) */

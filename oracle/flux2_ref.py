@@ -767,3 +767,70 @@ def generate(P: Dict[str, Tensor], cfg: dict, VP: Optional[Dict[str, Tensor]], v
         out["decoded"] = dec
         out["image"] = postprocess_vae_output(dec)
     return out
+
+
+# ---------------------------------------------------------------------------
+# Text encoder: Qwen3 hidden states -> Klein prompt embeddings
+# FluxTextEncoders/Model/Qwen3/{Qwen3Model,Qwen3DecoderLayer,Qwen3Attention,Qwen3MLP}.swift,
+# Embeddings/KleinEmbeddingExtractor.swift:50-131.
+# PINNED: unlike the DiT/VAE restatements this one is checked against an independent implementation
+# that runs here — HuggingFace transformers 5.15 `Qwen3Model` (the checkpoint's own reference code) —
+# through tests/golden/qwen3_tiny.npz (made by tests/golden/make_golden_qwen3.py).
+# ---------------------------------------------------------------------------
+def _rms(x: Tensor, w: Tensor, eps: float) -> Tensor:
+    return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * w.float()
+
+
+def _rope_split_half(x: Tensor, theta: float) -> Tensor:
+    """MLXFast.RoPE(traditional: false) (Qwen3Attention.swift:15-37): pairs (i, i + D/2), position = index.
+    x [B, H, S, D]."""
+    D, S = x.shape[-1], x.shape[-2]
+    inv = theta ** (-torch.arange(0, D, 2, dtype=torch.float32) / D)
+    ang = torch.arange(S, dtype=torch.float32)[:, None] * inv[None, :]
+    cos, sin = torch.cos(ang), torch.sin(ang)
+    a, b = x[..., : D // 2], x[..., D // 2:]
+    return torch.cat([a * cos - b * sin, b * cos + a * sin], dim=-1)
+
+
+def qwen3_hidden_states(P: Dict[str, Tensor], tcfg: dict, ids: Tensor, valid_len: int, layers: Sequence[int]) -> Dict[int, Tensor]:
+    """Qwen3Model.forwardWithHiddenStates (Qwen3Model.swift:109-174).  ids int64 [S]; returns
+    {layer index (1-based, "after layer i"): [1, S, hidden]}.  Causal mask + right-padding mask
+    (:176-212, pad keys get -1e9), GQA by repetition (Qwen3Attention.swift:135-147), q_norm/k_norm
+    before RoPE (:110-123), SwiGLU MLP (Qwen3MLP.swift)."""
+    H, Hkv, hd = tcfg["heads"], tcfg["kv_heads"], tcfg.get("head_dim", 128)
+    eps, theta = tcfg.get("rms_eps", 1e-6), tcfg.get("rope_theta", 1.0e6)
+    S = ids.shape[0]
+    g = lambda k: P[k] if k in P else P["model." + k]
+    x = g("embed_tokens.weight").float()[ids].unsqueeze(0)
+    i_idx = torch.arange(S)
+    mask = torch.where(i_idx[None, :] <= i_idx[:, None], 0.0, float("-inf"))
+    mask = mask + torch.where(i_idx < valid_len, 0.0, -1e9)[None, :]
+    out = {}
+    for l in range(max(layers)):
+        pre = f"layers.{l}."
+        h = _rms(x, g(pre + "input_layernorm.weight"), eps)
+        q = linear(h, g(pre + "self_attn.q_proj.weight")).reshape(1, S, H, hd)
+        k = linear(h, g(pre + "self_attn.k_proj.weight")).reshape(1, S, Hkv, hd)
+        v = linear(h, g(pre + "self_attn.v_proj.weight")).reshape(1, S, Hkv, hd)
+        q = _rms(q, g(pre + "self_attn.q_norm.weight"), eps).permute(0, 2, 1, 3)
+        k = _rms(k, g(pre + "self_attn.k_norm.weight"), eps).permute(0, 2, 1, 3)
+        v = v.permute(0, 2, 1, 3)
+        q, k = _rope_split_half(q, theta), _rope_split_half(k, theta)
+        rep = H // Hkv
+        k, v = k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1)
+        a = sdpa(q, k, v, mask).permute(0, 2, 1, 3).reshape(1, S, H * hd)
+        x = x + linear(a, g(pre + "self_attn.o_proj.weight"))
+        h = _rms(x, g(pre + "post_attention_layernorm.weight"), eps)
+        x = x + linear(F.silu(linear(h, g(pre + "mlp.gate_proj.weight"))) * linear(h, g(pre + "mlp.up_proj.weight")),
+                       g(pre + "mlp.down_proj.weight"))
+        if l + 1 in layers:
+            out[l + 1] = x
+    return out
+
+
+def klein_embeddings(P: Dict[str, Tensor], tcfg: dict, ids: Tensor, valid_len: int) -> Tensor:
+    """KleinEmbeddingExtractor.extractKleinEmbeddings steps 8-10: hidden states after the extract layers,
+    concatenated on the feature axis -> [1, S, 3*hidden]."""
+    ls = tuple(tcfg.get("extract_layers", (9, 18, 27)))
+    hs = qwen3_hidden_states(P, tcfg, ids, valid_len, ls)
+    return torch.cat([hs[i] for i in ls], dim=-1)

@@ -1,0 +1,47 @@
+"""CPU: the oracle's Qwen3 restatement against the committed HF-transformers fixture
+(tests/golden/qwen3_tiny.npz, made by tests/golden/make_golden_qwen3.py with `transformers.Qwen3Model`) —
+this part of the oracle is PINNED against an independent implementation — plus the host-side
+Klein prompt formatting rules."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from oracle import flux2_ref as R
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_golden_qwen3 as G  # noqa: E402
+
+
+def test_qwen3_restatement_matches_hf_fixture():
+    g = np.load("tests/golden/qwen3_tiny.npz")
+    P = G.make_qwen3_weights(G.TINY)
+    assert abs(float(sum(v.float().double().sum() for v in P.values())) - float(g["weight_checksum"][0])) < 1e-6
+    hs = R.qwen3_hidden_states(P, G.TINY, torch.from_numpy(g["ids"]), int(g["valid_len"][0]), (1, 2, 3))
+    for i in (1, 2, 3):
+        np.testing.assert_allclose(hs[i][0].numpy(), g[f"h{i}"], rtol=2e-5, atol=2e-5)
+    emb = R.klein_embeddings(P, G.TINY, torch.from_numpy(g["ids"]), int(g["valid_len"][0]))
+    assert emb.shape == (1, 48, 3 * 256)
+    np.testing.assert_allclose(emb[0, :, 256:512].numpy(), g["h2"], rtol=2e-5, atol=2e-5)
+
+
+def test_padding_does_not_change_real_tokens():
+    """Causal + right padding: hidden states of the real tokens do not depend on the pad length."""
+    g = np.load("tests/golden/qwen3_tiny.npz")
+    P = G.make_qwen3_weights(G.TINY)
+    ids, v = torch.from_numpy(g["ids"]), int(g["valid_len"][0])
+    a = R.qwen3_hidden_states(P, G.TINY, ids, v, (3,))[3][0, :v]
+    b = R.qwen3_hidden_states(P, G.TINY, ids[:v], v, (3,))[3][0]
+    np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_klein_prompt_formatting(flux2mi):
+    te = flux2mi.textenc
+    # KleinEmbeddingExtractor.swift:143-162
+    assert te.format_qwen3_chat_template("a cat") == "<|im_start|>user\na cat<|im_end|>\n<|im_start|>assistant\n<think>\n\n</think>\n\n"
+    assert te.format_qwen3_chat_template("x", False) == "<|im_start|>user\nx<|im_end|>\n"
+    ids, n = te.pad_klein_token_ids([5, 6, 7], 8)
+    assert ids == [5, 6, 7] + [151643] * 5 and n == 3       # RIGHT padding with <|endoftext|> (:70-90)
+    ids, n = te.pad_klein_token_ids(list(range(600)))
+    assert len(ids) == 512 and n == 512                     # truncation to maxSequenceLength

@@ -48,6 +48,39 @@ for w in which:
         pipe, cfg = load("klein-9b", quantization="fp8")
         inp = syn.make_inputs(cfg, 1024, 1024, device=dev)
         run("D8 klein-9b (fp8 e4m3 block GEMMs) 1024x1024 28 steps, 1 image per GPU", lambda: pipe.generate_text_to_image(height=1024, width=1024, steps=28, precomputed_embeddings=inp["txt"], noise=inp["noise"]))
+    elif w == "T":
+        # Klein-4B prompt embeddings: Qwen3-4B, 27 of 36 layers, 512 tokens (synthetic weights made on the GPU)
+        from flux2mi.textenc import TextEncoder
+        ctx = api.Context(0)
+        te = TextEncoder(ctx, "klein-4b")
+        g = torch.Generator(device=dev); g.manual_seed(3)
+        c = te.cfg
+        d, I, nq, nkv = c.hidden, c.intermediate, c.heads * 128, c.kv_heads * 128
+        rnd = lambda *sh, s=1.0: (torch.randn(sh, generator=g, device=dev) * s).to(torch.bfloat16)
+        P = {"embed_tokens.weight": rnd(c.vocab, d)}
+        for l in range(27):
+            p_ = f"layers.{l}."
+            P.update({p_ + "self_attn.q_proj.weight": rnd(nq, d, s=d ** -0.5), p_ + "self_attn.k_proj.weight": rnd(nkv, d, s=d ** -0.5),
+                      p_ + "self_attn.v_proj.weight": rnd(nkv, d, s=d ** -0.5), p_ + "self_attn.o_proj.weight": rnd(d, nq, s=nq ** -0.5),
+                      p_ + "self_attn.q_norm.weight": 1 + 0.1 * rnd(128), p_ + "self_attn.k_norm.weight": 1 + 0.1 * rnd(128),
+                      p_ + "mlp.gate_proj.weight": rnd(I, d, s=d ** -0.5), p_ + "mlp.up_proj.weight": rnd(I, d, s=d ** -0.5),
+                      p_ + "mlp.down_proj.weight": rnd(d, I, s=I ** -0.5), p_ + "input_layernorm.weight": 1 + 0.1 * rnd(d),
+                      p_ + "post_attention_layernorm.weight": 1 + 0.1 * rnd(d)})
+        te.load(P).finalize()
+        del P
+        ids = torch.randint(0, 150000, (512,), generator=g, device=dev).to(torch.int32)
+        for valid in (40, 512):
+            te.forward(ids, valid); ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                out = te.forward(ids, valid)
+            ctx.sync()
+            ms = (time.perf_counter() - t0) / 5 * 1e3
+            fl = 27 * 2.0 * 512 * (d * (nq + 2 * nkv) + nq * d + 3 * d * I)
+            print(json.dumps({"config": f"T klein-4b prompt embeddings (Qwen3-4B, 27 layers, S 512, {valid} real tokens)",
+                              "ms": round(ms, 2), "linear_tflops": round(fl / ms / 1e9, 1), "param_GB": round(te.param_bytes / 1e9, 2)}), flush=True)
+        te.close()
+        continue
     elif w == "K":
         # klein-9b-kv: one 1024^2 reference image (S_ref 4096), 4 steps like the distilled model; the
         # same I2I generation without and with the KV-cached path
