@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflux2mi.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("FLUX2MI_LIB", "libflux2mi.so"))   # FLUX2MI_LIB: timing-only ablation builds
 
 
 class Flux2Error(RuntimeError):
