@@ -24,6 +24,26 @@
 #include "kernels.h"
 #include <stdlib.h>
 
+#ifndef ATTN_DIAG
+#define ATTN_DIAG 0
+#endif
+#if ATTN_DIAG
+// timing-only diagnostic build (hipcc -DATTN_DIAG=1 -> libflux2mi_diag.so, read by tools/attn_diag.py;
+// never shipped): s_memtime stamps around the segments of a tile, summed per wave into a buffer no
+// kernel reads.  Read the SHARES, not the length: the stamps fence the schedule.
+__device__ unsigned long long g_attn_dbg[8];
+#define ATTN_STAMP(acc_)                                                                  \
+    {                                                                                     \
+        unsigned long long n__;                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n__)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        acc_ += n__ - dg_t;                                                               \
+        dg_t = n__;                                                                       \
+    }
+#else
+#define ATTN_STAMP(acc_)
+#endif
 namespace {
 
 constexpr int BKV = 64, HD = 128;   // BQ = 32 query rows per wave x NW waves
@@ -150,6 +170,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
     for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
     __syncthreads();
 
+#if ATTN_DIAG
+    unsigned long long dg_t = 0, dg_qk = 0, dg_sm = 0, dg_pv = 0, dg_st = 0;
+    { unsigned long long z = 0; ATTN_STAMP(z) }
+#endif
     for (int kt = 0; kt < nt; ++kt) {
         const int buf = kt & 1;
         const int ktn = min(kt + 1, nt - 1);   // the last tile re-fetches itself: harmless, keeps the loop branch-free
@@ -186,6 +210,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        ATTN_STAMP(dg_qk)
         // ---- online softmax (base-2), per query = per lane pair (lane, lane^32).
         // VALU budget matters as much as MFMA here (the wave issues both in order): the raw
         // scores are only max-reduced; scale and running max go into one fma per element in
@@ -235,6 +260,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
                     pf8[kb][s2][j] = (__bf16)pv;
                 }
         l_run += rs;
+        ATTN_STAMP(dg_sm)
 
         // ---- O^T += V^T P^T  (A = V^T rows d, B = P^T).  Step order: the four d-blocks of one
         // key sub-block back to back (independent accumulators); the V^T fragments of the next step
@@ -268,8 +294,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
 #pragma unroll
             for (int db = 0; db < 4; ++db) vc[db] = vn[db];
         }
+        ATTN_STAMP(dg_pv)
         __syncthreads();
+        ATTN_STAMP(dg_st)
     }
+#if ATTN_DIAG
+    if (lane == 0 && !CAUSAL) {
+        atomicAdd(&g_attn_dbg[1], dg_qk); atomicAdd(&g_attn_dbg[2], dg_sm);
+        atomicAdd(&g_attn_dbg[3], dg_pv); atomicAdd(&g_attn_dbg[4], dg_st); atomicAdd(&g_attn_dbg[5], (unsigned long long)nt);
+    }
+#endif
 #undef ATTN_LOAD_PIECE
 
     // ---- normalise and store.  o[db][r]: d = db*32 + (r&3) + 8*(r>>2) + 4*hi, query = l31
@@ -325,3 +359,16 @@ int launch_attention_causal(hipStream_t stream, const uint16_t* q, const uint16_
                        scale_log2e, valid_len, heads / kv_heads);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
+
+#if ATTN_DIAG
+extern "C" int flux2mi_debug_attn_stamps(double* out6, int reset) {
+    unsigned long long h[8] = {0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_attn_dbg), sizeof h) != hipSuccess) return 2;
+    for (int i = 0; i < 6; ++i) out6[i] = (double)h[i];
+    if (reset) {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg), z, sizeof z);
+    }
+    return 0;
+}
+#endif
