@@ -59,3 +59,17 @@ def test_param_counts_match_published_sizes(flux2mi):
     for name, gb in {"klein-4b": 7.75, "klein-9b": 18.16, "dev": 64.4}.items():
         n = sum(int(__import__("numpy").prod(s)) for _, s, _ in syn.dit_param_shapes(syn.DIT_PRESETS[name]))
         assert abs(n * 2 / 1e9 - gb) / gb < 0.02, (name, n * 2 / 1e9)
+
+
+def test_missing_library_fails_loudly():
+    """No CPU / PyTorch fallback: with the shared object absent the first API call raises ImportError
+    naming the build command (run in a child process with FLUX2MI_LIB pointing at a missing file)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import flux2mi\n"
+            "try:\n    flux2mi.lib()\n    print('loaded')\nexcept ImportError as e:\n    print('ImportError', 'no cpu fallback' in str(e).lower())\n") % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLUX2MI_LIB="libflux2mi_absent.so"),
+                       capture_output=True, text=True, timeout=120)
+    assert "ImportError True" in r.stdout, r.stdout + r.stderr

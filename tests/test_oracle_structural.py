@@ -157,10 +157,34 @@ def test_mask_packing():
     assert float(R.pack_mask_for_latent_blending(half, 512, 512).sum()) == 512.0
 
 
-def test_kv_extract_mask_pattern_documented_only():
-    """Flux2CoreTests.swift:2577-2681 pins the KV-extraction mask; the klein-9b-kv variant is a
-    'next' row and not built yet — placeholder so the gap is visible."""
-    pytest.skip("klein-9b-kv path not built (SURVEY §8f rank 4)")
+def test_kv_extract_mask_pattern():
+    """Mirrors the reference's mask-pattern test for the KV-extraction pass (Flux2Attention.swift:407-425):
+    additive mask over [txt | ref | out], -inf exactly for (reference query, output key) pairs."""
+    m = R._kv_mask(3, 2, 4)
+    assert m.shape == (9, 9)
+    blocked = torch.isinf(m) & (m < 0)
+    exp = torch.zeros((9, 9), dtype=torch.bool)
+    exp[3:5, 5:] = True
+    assert torch.equal(blocked, exp)
+    assert (m[~exp] == 0).all()
+
+
+def test_kv_cached_pass_reproduces_extraction_pass():
+    """Structural identity of the KV path (oracle): a cached pass fed the extraction pass's own inputs
+    returns the extraction pass's output exactly (same keys and values in the same softmax)."""
+    import flux2mi
+    syn = flux2mi.synthetic
+    cfg = syn.DIT_PRESETS["tiny"]
+    P = syn.make_dit_weights(cfg, seed=5, std=0.05)
+    inp = syn.make_inputs(cfg, 64, 64, s_txt=16)
+    lat = R.pack_patchified_to_sequence(inp["noise"])
+    ref = torch.randn((1, 24, 128), generator=torch.Generator().manual_seed(1))
+    ids = (R.image_position_ids(64, 64), R.text_position_ids(16), R.reference_position_ids([4], [6]))
+    t = torch.tensor([0.6])
+    o0, cache = R.dit_forward_kv(P, cfg, lat, inp["txt"].float(), t, None, ids[0], ids[1], ref_lat=ref, ref_ids=ids[2])
+    o1, _ = R.dit_forward_kv(P, cfg, lat, inp["txt"].float(), t, None, ids[0], ids[1], cache=cache)
+    assert len(cache) == cfg["n_double"] + cfg["n_single"] and cache[0][0].shape == (1, cfg["heads"], 24, 128)
+    assert torch.allclose(o0, o1, atol=1e-5)
 
 
 def test_rope_table_structure():
