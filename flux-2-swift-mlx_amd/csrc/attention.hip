@@ -75,12 +75,19 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 
 // NW waves per workgroup (4: two workgroups per CU; 8: one workgroup per CU, the K / V^T tile staged
 // once for 256 query rows, i.e. half the global loads and LDS stores per wave).
-template <bool CAUSAL, int NW>
+// FIXM: softmax against a FIXED offset instead of a running row maximum.  Valid when the caller can
+// bound the scaled scores: q and k come out of the per-head RMSNorm (|q| <= sqrt(128) max|w_q|, RoPE
+// is a rotation), so s * scale * log2(e) <= fixed_m by Cauchy-Schwarz; then p = exp2(s c - fixed_m) is
+// in (0, 1] for every key, the row maximum, its cross-lane exchange, the rescale branch and their
+// serial dependency in front of the first exp2 all disappear (same softmax: any offset cancels in
+// O / l).  The caller only asks for it when fixed_m is small enough that p cannot underflow.
+template <bool CAUSAL, int NW, bool FIXM = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(const uint16_t* __restrict__ q,
                                                           const uint16_t* __restrict__ k, int ldqk,
                                                           const uint16_t* __restrict__ vt, int s_pad,
                                                           uint16_t* __restrict__ out, int ldo, int Sq, int S,
-                                                          float scale_log2e, int valid_len, int kv_rep) {
+                                                          float scale_log2e, int valid_len, int kv_rep,
+                                                          float fixed_m) {
     // Sq query rows (q / out already point at the first of them), S keys (k / vt from key 0)
     __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE_BYTES];
 
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = FIXM ? fixed_m : -INFINITY, l_run = 0.f;
 
     // keys this block can see at all, and the per-lane limit of the causal form
     const int key_lim_blk = CAUSAL ? min(min(valid_len, S), q0 + BQ) : S;
@@ -226,6 +233,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
                     if (key >= key_lim) sa[kb][r] = -INFINITY;
                 }
         }
+        if (!FIXM) {
         // 32 scores -> 16 x v_max3_f32 (asm: hipcc would put a canonicalising v_max in front of
         // every fmaxf that reads an MFMA result)
         float mx;
@@ -245,6 +253,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
             for (int db = 0; db < 4; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
         }
         float rs = 0.f;
         bf16x8 pf8[2][2];
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
 }  // namespace
 
 int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
-                     int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads) {
+                     int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads, float score_bound_log2) {
     if (Sq <= 0 || S <= 0 || heads <= 0 || (ldqk & 7) || (ldo & 3) || s_pad < attn_s_pad(S) || (s_pad & 7)) return 1;
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
     static const int nw_env = [] {   // FLUX2MI_ATTN_NW=4|8 forces a workgroup size (A/B runs)
@@ -336,15 +345,17 @@ int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, i
     // 8-wave workgroups (one per CU) when the 4-wave grid would be under two full rounds of the 512
     // workgroup slots (Klein-4B: 864): +0.6 % on the step; 4-wave ones are faster on larger grids
     const int nw = nw_env ? nw_env : (((long)((Sq + 127) / 128) * heads < 1024 && Sq >= 1024) ? 8 : 4);
-    if (nw == 8) {
-        dim3 grid((Sq + 255) / 256, heads);
-        hipLaunchKernelGGL((attn_fwd_kernel<false, 8>), grid, dim3(512), 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S,
-                           scale_log2e, S, 1);
-    } else {
-        dim3 grid((Sq + 127) / 128, heads);
-        hipLaunchKernelGGL((attn_fwd_kernel<false, 4>), grid, dim3(256), 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S,
-                           scale_log2e, S, 1);
-    }
+    static const int fixm_on = [] {   // FLUX2MI_ATTN_FIXM=0 keeps the running maximum everywhere (A/B runs)
+        const char* e = getenv("FLUX2MI_ATTN_FIXM");
+        return e ? atoi(e) : 1;
+    }();
+    // p >= 2^(-2 bound): 2 * 40 stays far inside the f32 / bf16 exponent range
+    const bool fixm = fixm_on && score_bound_log2 > 0.f && score_bound_log2 <= 40.f;
+    const dim3 grid((Sq + nw * 32 - 1) / (nw * 32), heads), block(nw * 64);
+#define ATTN_GO(NW_, FX_) hipLaunchKernelGGL((attn_fwd_kernel<false, NW_, FX_>), grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, scale_log2e, S, 1, score_bound_log2)
+    if (nw == 8) { if (fixm) ATTN_GO(8, true); else ATTN_GO(8, false); }
+    else { if (fixm) ATTN_GO(4, true); else ATTN_GO(4, false); }
+#undef ATTN_GO
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
@@ -356,7 +367,7 @@ int launch_attention_causal(hipStream_t stream, const uint16_t* q, const uint16_
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
     dim3 grid((S + 127) / 128, heads);
     hipLaunchKernelGGL((attn_fwd_kernel<true, 4>), grid, dim3(256), 0, stream, q, k, ldqk, vt, s_pad, out, ldo, S, S,
-                       scale_log2e, valid_len, heads / kv_heads);
+                       scale_log2e, valid_len, heads / kv_heads, 0.f);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

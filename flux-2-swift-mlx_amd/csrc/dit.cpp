@@ -61,8 +61,9 @@ struct flux2mi_dit {
     uint16_t *guid_in = nullptr, *guid_out = nullptr;
     uint16_t *mod_img = nullptr, *mod_txt = nullptr, *mod_single = nullptr, *final_mod = nullptr, *final_lin = nullptr;
     struct W { const uint16_t* w = nullptr; const float* scale = nullptr; };  // bf16 pointer, or e4m3 bytes + scales
-    struct Dbl { W qkv[2], proj[2], mlp_in[2], mlp_out[2]; uint16_t *qn[2], *kn[2]; };  // [0]=txt, [1]=img
-    struct Sgl { W lin1, lin2; uint16_t *qn, *kn; };
+    // score_bound: upper bound of |q.k| / sqrt(128) * log2(e) after the block's QK-RMSNorm (see finalize)
+    struct Dbl { W qkv[2], proj[2], mlp_in[2], mlp_out[2]; uint16_t *qn[2], *kn[2]; float score_bound = 0.f; };  // [0]=txt, [1]=img
+    struct Sgl { W lin1, lin2; uint16_t *qn, *kn; float score_bound = 0.f; };
     std::vector<Dbl> dbl;
     std::vector<Sgl> sgl;
 
@@ -471,6 +472,37 @@ extern "C" int flux2mi_dit_finalize(flux2mi_dit* m) {
         snprintf(a, sizeof a, "single_blocks.%d.norm.key_norm.scale", i);
         m->sgl[i].kn = buf_by_label(m, a);
     }
+    // Score bound per block for the attention's fixed-offset softmax: after RMSNorm with weight w every
+    // q (k) vector has |q| <= sqrt(128) max|w_q|, RoPE is a rotation, so |q.k| <= 128 max|w_q| max|w_k|
+    // (Cauchy-Schwarz).  In the log2 domain with the 1/sqrt(128) scale: 16.32 max|w_q| max|w_k|; +3 % for
+    // the bf16 roundings of q and k.
+    {
+        F2_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+        auto wmax = [&](const uint16_t* dev, float& out) -> int {
+            uint16_t h[128];
+            F2_CHECK_HIP(hipMemcpy(h, dev, sizeof h, hipMemcpyDeviceToHost));
+            float mx = 0.f;
+            for (int i = 0; i < 128; ++i) {
+                uint32_t u = (uint32_t)h[i] << 16;
+                float f;
+                memcpy(&f, &u, 4);
+                mx = fmaxf(mx, fabsf(f));
+            }
+            out = mx;
+            return FLUX2MI_OK;
+        };
+        const float c = 128.0f / sqrtf(128.0f) * 1.4426950408889634f * 1.03f;
+        for (auto& b : m->dbl) {
+            float q0, q1, k0, k1;
+            F2_TRY(wmax(b.qn[0], q0)); F2_TRY(wmax(b.qn[1], q1)); F2_TRY(wmax(b.kn[0], k0)); F2_TRY(wmax(b.kn[1], k1));
+            b.score_bound = c * fmaxf(q0, q1) * fmaxf(k0, k1);
+        }
+        for (auto& b : m->sgl) {
+            float q, k;
+            F2_TRY(wmax(b.qn, q)); F2_TRY(wmax(b.kn, k));
+            b.score_bound = c * q * k;
+        }
+    }
     m->stage_raw.release();
     m->stage_bf16.release();
     m->stage_w.release();
@@ -661,7 +693,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     };
     // joint attention per query range; keys = all S rows except for the reference queries of the
     // extraction pass, which see [txt | ref] only.  Also moves the reference K / V^T to / from the cache.
-    auto attend = [&](int layer, uint16_t* o_buf, int ldo) -> int {
+    auto attend = [&](int layer, uint16_t* o_buf, int ldo, float score_bound) -> int {
         if (mode == FWD_KV_EXTRACT) {
             F2_CHECK_HIP(hipMemcpy2DAsync(cache->k(layer), (size_t)d * 2, qkv + (size_t)s_txt * 3 * d + d, (size_t)3 * d * 2,
                                           (size_t)d * 2, (size_t)s_ref, hipMemcpyDeviceToDevice, st));
@@ -682,7 +714,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         for (int i = 0; i < nr; ++i) {
             prof_before(m->ctx, PROF_ATTENTION);
             const int ar = launch_attention(st, qkv + (size_t)rg[i].q0 * 3 * d, qkv + d, 3 * d, vt, s_pad,
-                                            o_buf + (size_t)rg[i].q0 * ldo, ldo, rg[i].nq, rg[i].nk, H);
+                                            o_buf + (size_t)rg[i].q0 * ldo, ldo, rg[i].nq, rg[i].nk, H, score_bound);
             prof_after(m->ctx, PROF_ATTENTION, 4.0 * (double)rg[i].nq * rg[i].nk * d);
             F2_LAUNCH(ar, "attention");
         }
@@ -702,7 +734,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         }
         F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, s_txt, w.qn[0], w.kn[0], w.qn[1], w.kn[1], cos_tab, sin_tab,
                                          vt, s_pad), "qk_norm_rope");
-        F2_TRY(attend(i, comb, d));
+        F2_TRY(attend(i, comb, d, w.score_bound));
         F2_LAUNCH(quant(comb, d, d), "quantize(attn out)");
         {
             GemmProblem p[2];
@@ -753,7 +785,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         }
         F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, 0, w.qn, w.kn, w.qn, w.kn, cos_tab, sin_tab, vt, s_pad),
                   "qk_norm_rope");
-        F2_TRY(attend(m->cfg.n_double + i, comb, 4 * d));
+        F2_TRY(attend(m->cfg.n_double + i, comb, 4 * d, w.score_bound));
         F2_LAUNCH(quant(comb, 4 * d, 4 * d), "quantize(attn | ff hidden)");
         {
             GemmProblem p[2];

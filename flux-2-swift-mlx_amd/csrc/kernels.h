@@ -45,8 +45,11 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob);
 //   key-permuted layout produced by launch_qk_norm_rope_vt; out row s at out + s*ldo + head*128.
 // Sq query rows starting at q / out, S keys starting at k / column 0 of vt (Sq == S: plain self-attention;
 // the KV-cache paths launch it per query range, and with S = the key prefix a range may see).
+// score_bound_log2 > 0: the caller guarantees |q.k| / sqrt(128) * log2(e) <= score_bound_log2 for every
+// query/key pair (q, k out of the per-head RMSNorm); the softmax then uses it as a fixed offset instead
+// of tracking row maxima (used when <= 40).  0 = no bound known.
 int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
-                     int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads);
+                     int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads, float score_bound_log2 = 0.f);
 static inline int attn_s_pad(int S) { return ((S + 63) / 64) * 64; }
 
 // ---------------------------------------------------------------- norms / rope (norm.hip)

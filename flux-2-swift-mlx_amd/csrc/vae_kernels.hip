@@ -156,13 +156,12 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a, int Ho, int Wo,
 
 // ---------------------------------------------------------------- GroupNorm
 // stage 1: per-workgroup partial (sum, sumsq) per group.  Thread owns a fixed 8-channel
-// chunk and strides over pixels, so its group ids are loop-invariant.
+// chunk and strides over pixels.  The per-thread sums are combined per group in a FIXED order (no
+// atomics): the decode is bit-reproducible run to run.
 __global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* __restrict__ x, int64_t pixels, int C,
                                                          int groups, int64_t px_per_block,
                                                          float* __restrict__ partial) {
-    __shared__ float gsum[64], gsq[64];
-    if (threadIdx.x < 64) { gsum[threadIdx.x] = 0.f; gsq[threadIdx.x] = 0.f; }
-    __syncthreads();
+    __shared__ float sh_s[256][9], sh_q[256][9];   // [thread][channel of its chunk], padded
     const int cpb = C >> 3;             // 8-channel chunks per pixel
     const int ppi = 256 / cpb;          // pixels per iteration
     const int cc = threadIdx.x % cpb, pl = threadIdx.x / cpb;
@@ -179,18 +178,21 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* __restr
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
         }
-        const int cpg = C / groups;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int g = (cc * 8 + j) / cpg;
-            atomicAdd(&gsum[g], s[j]);
-            atomicAdd(&gsq[g], q[j]);
-        }
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sh_s[threadIdx.x][j] = s[j]; sh_q[threadIdx.x][j] = q[j]; }
     __syncthreads();
     if (threadIdx.x < groups) {
-        partial[((size_t)blockIdx.x * groups + threadIdx.x) * 2 + 0] = gsum[threadIdx.x];
-        partial[((size_t)blockIdx.x * groups + threadIdx.x) * 2 + 1] = gsq[threadIdx.x];
+        const int g = threadIdx.x, cpg = C / groups;
+        float gs = 0.f, gq = 0.f;
+        for (int l = 0; l < ppi; ++l)                       // pixel lanes, then the group's channels: fixed order
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+                const int tt = l * cpb + (c >> 3);
+                gs += sh_s[tt][c & 7];
+                gq += sh_q[tt][c & 7];
+            }
+        partial[((size_t)blockIdx.x * groups + g) * 2 + 0] = gs;
+        partial[((size_t)blockIdx.x * groups + g) * 2 + 1] = gq;
     }
 }
 

@@ -269,3 +269,29 @@ def test_kv_fp8_runs_and_matches_emulation(flux2mi, ctx):
     with R.fp8_block_gemms():
         (o0, o1), (h0, h1, _) = _kv_case(ctx, cfg, 16, 64, 64, (4, 4), weights="fp8")
     assert rel_l2(h0, o0) < 2e-2 and rel_l2(h1, o1) < 2e-2
+
+
+# ---- attention softmax offset: fixed bound vs running maximum --------------------------------------
+@pytest.mark.parametrize("factor,s_txt,h,w", [(1.0, 16, 128, 128), (1.12, 19, 80, 112), (1.5, 16, 128, 128), (3.0, 19, 80, 112)])
+def test_forward_with_scaled_qk_norm_weights(flux2mi, ctx, factor, s_txt, h, w):
+    """The DiT's attention replaces the running row maximum by a fixed offset when the QK-RMSNorm
+    weights bound the scores tightly enough (16.8 max|w_q| max|w_k| <= 40 in the log2 domain), and
+    keeps the running maximum otherwise.  factor 1.0 / 1.12: fixed-offset path (bound ~31 / ~39, the
+    second just under the switch); 1.5 / 3.0: running-max path with much peakier softmaxes.  All
+    against the oracle, rel-L2 <= 2e-2."""
+    from flux2mi import synthetic as syn
+    from flux2mi.api import DiT
+    cfg = syn.DIT_PRESETS["tiny"]
+    P = syn.make_dit_weights(cfg, seed=1234, std=0.05)
+    for k in list(P):
+        if k.endswith("norm.query_norm.scale") or k.endswith("norm.key_norm.scale"):
+            P[k] = (P[k].float() * factor).to(torch.bfloat16)
+    inp = syn.make_inputs(cfg, h, w, s_txt=s_txt)
+    lat = R.pack_patchified_to_sequence(inp["noise"])
+    img_ids, txt_ids = R.image_position_ids(h, w), R.text_position_ids(s_txt)
+    dit = DiT(ctx, cfg).load(P).finalize()
+    out = dit.forward(lat.cuda(), inp["txt"].cuda(), 0.731, 4.0, img_ids.cuda(), txt_ids.cuda()).cpu()
+    dit.close()
+    ref = R.dit_forward(P, cfg, lat, inp["txt"].float(), torch.tensor([0.731]), None, img_ids, txt_ids)[0]
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 2e-2

@@ -114,3 +114,23 @@ def test_encode_decode_roundtrip_shapes_via_pipeline(flux2mi, ctx):
     assert packed.shape == (1, 64, 128) and torch.isfinite(packed).all()
     ref = R.encode_image_to_packed_sequence(syn.make_vae_weights(vcfg), vcfg, R.preprocess_image_for_vae(img))
     assert rel_l2(packed, ref) < 3e-2
+
+
+def test_decode_is_bit_reproducible(flux2mi, ctx):
+    """Same weights, same latent -> identical bytes, across instances and repeated calls (GroupNorm
+    statistics are combined in a fixed order; no floating-point atomics anywhere in the decoder)."""
+    from flux2mi import synthetic as syn
+    from flux2mi.api import VAE
+    vcfg = syn.VAE_PRESETS["small"]
+    VP = syn.make_vae_weights(vcfg)
+    z = torch.randn((1, 32, 16, 24), generator=torch.Generator().manual_seed(8)).cuda()
+    a = VAE(ctx, vcfg).load(VP).finalize()
+    b = VAE(ctx, vcfg).load(VP).finalize()
+    ref_f, ref_u = a.decode(z)
+    ref_f, ref_u = ref_f.clone(), ref_u.clone()
+    for _ in range(5):
+        f1, u1 = a.decode(z)
+        f2, u2 = b.decode(z)
+        assert torch.equal(f1, ref_f) and torch.equal(u1, ref_u)
+        assert torch.equal(f2, ref_f) and torch.equal(u2, ref_u)
+    a.close(); b.close()
