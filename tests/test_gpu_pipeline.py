@@ -201,3 +201,18 @@ def test_generate_with_kv_cache_vs_oracle_loop(flux2mi, ctx):
     assert rel_l2(res.latents.cpu(), x) < 3e-2
     # and it is a different computation from the un-cached I2I path, not an alias of it
     assert rel_l2(res.latents.cpu(), plain.latents.cpu()) > 1e-4
+
+
+def test_generation_is_bit_reproducible(flux2mi, ctx):
+    """Same inputs -> identical latents and identical image bytes on repeated runs (no floating-point
+    atomics or timing-dependent summation orders anywhere on the path)."""
+    from flux2mi import synthetic as syn
+    from flux2mi.pipeline import Flux2Pipeline
+    cfg, vcfg = syn.DIT_PRESETS["tiny"], syn.VAE_PRESETS["tiny"]
+    pipe = Flux2Pipeline(model=cfg, vae_variant=vcfg).load_models(syn.make_dit_weights(cfg), syn.make_vae_weights(vcfg))
+    inp = syn.make_inputs(cfg, 128, 96, s_txt=16)
+    runs = [pipe.generate_with_result("textToImage", height=128, width=96, steps=3, precomputed_embeddings=inp["txt"],
+                                      noise=inp["noise"], return_latents=True) for _ in range(3)]
+    for r in runs[1:]:
+        assert torch.equal(r.latents, runs[0].latents)
+        assert np.array_equal(r.image, runs[0].image)
