@@ -33,7 +33,7 @@ class DitConfig(C.Structure):
 class TextEncConfig(C.Structure):
     _fields_ = [("vocab", C.c_int), ("hidden", C.c_int), ("intermediate", C.c_int), ("n_layers", C.c_int),
                 ("heads", C.c_int), ("kv_heads", C.c_int), ("head_dim", C.c_int), ("rope_theta", C.c_float),
-                ("rms_eps", C.c_float), ("extract_layers", C.c_int * 3)]
+                ("rms_eps", C.c_float), ("extract_layers", C.c_int * 3), ("qk_norm", C.c_int)]
 
 
 class VaeConfig(C.Structure):
@@ -116,7 +116,7 @@ PROTOTYPES = {
     "flux2mi_textenc_set_tensor": (_I, [_P, C.c_char_p, _I, C.POINTER(_I64), _I, _P]),
     "flux2mi_textenc_finalize": (_I, [_P]),
     "flux2mi_textenc_param_bytes": (_I64, [_P]),
-    "flux2mi_textenc_forward": (_I, [_P, _P, _I, _I, _P]),
+    "flux2mi_textenc_forward": (_I, [_P, _P, _I, _I, _I, _P]),
     "flux2mi_vae_preset": (_I, [C.c_char_p, C.POINTER(VaeConfig)]),
     "flux2mi_vae_create": (_I, [_P, C.POINTER(VaeConfig), C.POINTER(_P)]),
     "flux2mi_vae_destroy": (_I, [_P]),

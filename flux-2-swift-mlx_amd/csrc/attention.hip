@@ -51,8 +51,12 @@ constexpr int K_TILE_BYTES = BKV * HD * 2;   // 16 KB
 constexpr int V_TILE_BYTES = HD * BKV * 2;   // 16 KB
 constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;
 
-// CAUSAL (text encoder, Qwen3Model.swift:176-212): query row i sees keys j <= i and j < valid_len
-// (right padding); kv_rep query heads share one K/V head (GQA, Qwen3Attention.swift:135-147).
+// CAUSAL (text encoders, Qwen3Model.swift:176-212 / MistralModel.swift:150-195): real tokens are rows
+// [pad_lo, valid_len).  A real query row i sees keys pad_lo <= j <= i, j < valid_len.  Rows after
+// valid_len (right padding, Klein) see the real keys only.  Rows before pad_lo (left padding, Dev)
+// see keys 0..i, all of them pads carrying the reference's finite -1e9 mask, which in f32 swallows
+// the scores: uniform attention over those keys — reproduced by scoring them 0.
+// kv_rep query heads share one K/V head (GQA, Qwen3Attention.swift:135-147).
 // The two lanes l and l ^ 32 hold the two halves of a query's keys: exchange through
 // v_permlane32_swap (one VALU op) instead of ds_bpermute (an LDS round trip in the softmax's
 // dependent chain).  swap(a, b) with a == b == v leaves a = [lo, lo], b = [hi, hi].  Inline asm: on this
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
                                                           const uint16_t* __restrict__ vt, int s_pad,
                                                           uint16_t* __restrict__ out, int ldo, int Sq, int S,
                                                           float scale_log2e, int valid_len, int kv_rep,
-                                                          float fixed_m) {
+                                                          float fixed_m, int pad_lo) {
     // Sq query rows (q / out already point at the first of them), S keys (k / vt from key 0)
     __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE_BYTES];
 
@@ -158,15 +162,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = FIXM ? fixed_m : -INFINITY, l_run = 0.f;
+    // CAUSAL: a finite start value, so that a tile whose keys are all masked for a row (left padding
+    // inside a straddling workgroup) gives exp2(-inf) = 0 and not exp2(-inf + inf)
+    float m_run = FIXM ? fixed_m : (CAUSAL ? -1.0e30f : -INFINITY), l_run = 0.f;
 
     // keys this block can see at all, and the per-lane limit of the causal form
     const int key_lim_blk = CAUSAL ? min(min(valid_len, S), q0 + BQ) : S;
     const int key_lim = CAUSAL ? min(min(valid_len, S), qrow + 1) : S;
     const int wave_lim = CAUSAL ? min(min(valid_len, S), q0 + wid * 32 + 1) : S;   // smallest limit in the wave
     const int nt = (key_lim_blk + BKV - 1) / BKV;
+    // left padding: lower key bound of real rows, "uniform" pad rows, first tile of the workgroup
+    const bool pad_row = CAUSAL && qrow < pad_lo;
+    const int key_lo = (CAUSAL && !pad_row) ? pad_lo : 0;
+    const int key_hi = pad_row ? min(qrow + 1, S) : key_lim;
+    const bool wave_lo_mask = CAUSAL && pad_lo > 0;    // some lane of some wave needs the lower bound / the zero scores
+    const int kt0 = (CAUSAL && q0 >= pad_lo) ? pad_lo / BKV : 0;
 #pragma unroll
-    for (int i = 0; i < 2 * PP; ++i) { ATTN_LOAD_PIECE(0, i) }
+    for (int i = 0; i < 2 * PP; ++i) { ATTN_LOAD_PIECE(kt0, i) }
     ATTN_STORE_TILE(0)
     // The Q fragments come from global loads issued before the loop.  Without this, hipcc's
     // waitcnt pass carries "qf may still be in flight" around the back edge and puts
@@ -181,8 +193,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
     unsigned long long dg_t = 0, dg_qk = 0, dg_sm = 0, dg_pv = 0, dg_st = 0;
     { unsigned long long z = 0; ATTN_STAMP(z) }
 #endif
-    for (int kt = 0; kt < nt; ++kt) {
-        const int buf = kt & 1;
+    for (int kt = kt0; kt < nt; ++kt) {
+        const int buf = (kt - kt0) & 1;
         const int ktn = min(kt + 1, nt - 1);   // the last tile re-fetches itself: harmless, keeps the loop branch-free
         const uint8_t* sk = smem + buf * STAGE_BYTES;
         const uint8_t* sv = sk + K_TILE_BYTES;
@@ -223,14 +235,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
         // scores are only max-reduced; scale and running max go into one fma per element in
         // front of exp2; O and l are rescaled only when some lane's running max grew (exact:
         // alpha == 1 otherwise), which after the first tiles is rare.
-        const bool tail = (kt + 1) * BKV > wave_lim;
+        const bool tail = (kt + 1) * BKV > wave_lim || wave_lo_mask;
         if (tail) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kt * BKV + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= key_lim) sa[kb][r] = -INFINITY;
+                    if (key >= key_hi || key < key_lo) sa[kb][r] = -INFINITY;
+                    else if (pad_row) sa[kb][r] = 0.f;
                 }
         }
         if (!FIXM) {
@@ -352,7 +365,7 @@ int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, i
     // p >= 2^(-2 bound): 2 * 40 stays far inside the f32 / bf16 exponent range
     const bool fixm = fixm_on && score_bound_log2 > 0.f && score_bound_log2 <= 40.f;
     const dim3 grid((Sq + nw * 32 - 1) / (nw * 32), heads), block(nw * 64);
-#define ATTN_GO(NW_, FX_) hipLaunchKernelGGL((attn_fwd_kernel<false, NW_, FX_>), grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, scale_log2e, S, 1, score_bound_log2)
+#define ATTN_GO(NW_, FX_) hipLaunchKernelGGL((attn_fwd_kernel<false, NW_, FX_>), grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, scale_log2e, S, 1, score_bound_log2, 0)
     if (nw == 8) { if (fixm) ATTN_GO(8, true); else ATTN_GO(8, false); }
     else { if (fixm) ATTN_GO(4, true); else ATTN_GO(4, false); }
 #undef ATTN_GO
@@ -360,14 +373,14 @@ int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, i
 }
 
 int launch_attention_causal(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
-                            int s_pad, uint16_t* out, int ldo, int S, int valid_len, int heads, int kv_heads) {
-    if (S <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads || valid_len < 1 || valid_len > S || (ldqk & 7) ||
+                            int s_pad, uint16_t* out, int ldo, int S, int pad_lo, int valid_len, int heads, int kv_heads) {
+    if (S <= 0 || heads <= 0 || kv_heads <= 0 || heads % kv_heads || pad_lo < 0 || valid_len <= pad_lo || valid_len > S || (ldqk & 7) ||
         (ldo & 3) || s_pad < attn_s_pad(S) || (s_pad & 7))
         return 1;
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
     dim3 grid((S + 127) / 128, heads);
     hipLaunchKernelGGL((attn_fwd_kernel<true, 4>), grid, dim3(256), 0, stream, q, k, ldqk, vt, s_pad, out, ldo, S, S,
-                       scale_log2e, valid_len, heads / kv_heads, 0.f);
+                       scale_log2e, valid_len, heads / kv_heads, 0.f, pad_lo);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

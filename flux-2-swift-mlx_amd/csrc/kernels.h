@@ -86,7 +86,8 @@ int launch_vt_keys_copy(hipStream_t stream, uint16_t* vt, int s_pad, uint16_t* c
 // ---- text encoder (Qwen3, FluxTextEncoders/Model/Qwen3/*.swift)
 // y bf16 [rows, dim] = x f32 * rsqrt(mean(x^2) + eps) * w   (RMSNorm with a bf16 weight)
 int launch_rmsnorm_rows(hipStream_t stream, const float* x, const uint16_t* w, uint16_t* y, int rows, int dim, float eps);
-// In place on qkv bf16 [S, (hq + 2 hkv) * 128] = q | k | v: per-head RMSNorm(eps, weight) of q and k, then
+// In place on qkv bf16 [S, (hq + 2 hkv) * 128] = q | k | v: per-head RMSNorm(eps, weight) of q and k (skipped
+// when q_w == nullptr: Mistral has no q/k norm), then
 // RoPE in the split-half convention (MLXFast.RoPE traditional: false; pairs (i, i + 64)), position = row,
 // inv_freq_i = theta^(-2i/128).  V is written transposed + key-permuted into vt [hkv][128][s_pad].
 int launch_qk_norm_rope_llm_vt(hipStream_t stream, uint16_t* qkv, int S, int hq, int hkv, const uint16_t* q_w,
@@ -95,10 +96,12 @@ int launch_qk_norm_rope_llm_vt(hipStream_t stream, uint16_t* qkv, int S, int hq,
 int launch_embed_rows(hipStream_t stream, const int32_t* ids, const uint16_t* table, float* hs, int S, int dim, int vocab);
 // out bf16 [S, ldo] columns [c0, c0 + dim) = hs f32 [S, dim]
 int launch_f32_rows_to_bf16_cols(hipStream_t stream, const float* hs, uint16_t* out, int S, int dim, int ldo, int c0);
-// Causal attention with a right-padding limit and grouped KV heads: query row i of head h attends to keys
-// j <= i, j < valid_len of KV head h / (heads / kv_heads).  Same operand layouts as launch_attention.
+// Causal attention over a padded sequence with grouped KV heads: real tokens are rows [pad_lo, valid_len);
+// a real query row i of head h attends to keys pad_lo <= j <= i, j < valid_len of KV head
+// h / (heads / kv_heads); rows >= valid_len (right padding) see the real keys, rows < pad_lo (left
+// padding) attend uniformly to keys 0..i (see attention.hip).  Operand layouts as launch_attention.
 int launch_attention_causal(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
-                            int s_pad, uint16_t* out, int ldo, int S, int valid_len, int heads, int kv_heads);
+                            int s_pad, uint16_t* out, int ldo, int S, int pad_lo, int valid_len, int heads, int kv_heads);
 int launch_rope_tables(hipStream_t stream, const int32_t* txt_ids, int s_txt, const int32_t* img_ids, int s_img,
                        float* cos_tab, float* sin_tab);
 

@@ -337,11 +337,14 @@ __global__ __launch_bounds__(256) void qk_norm_rope_llm_kernel(uint16_t* __restr
     uint16_t* p = qkv + (size_t)row * ld + head * 128;
     const uint16_t* w = head < hq ? q_w : k_w;
     const float a = bf16_bits_to_f32(p[lane]), b = bf16_bits_to_f32(p[lane + 64]);
-    const float ss = wave_sum(a * a + b * b);
-    const float rstd = rsqrtf(ss * (1.0f / 128.0f) + eps);
-    // the reference normalises in the activation dtype: round the normalised value to bf16 before RoPE
-    const float an = bf16_bits_to_f32(f32_to_bf16_bits(a * rstd * bf16_bits_to_f32(w[lane])));
-    const float bn = bf16_bits_to_f32(f32_to_bf16_bits(b * rstd * bf16_bits_to_f32(w[lane + 64])));
+    float an = a, bn = b;
+    if (w != nullptr) {   // wave-uniform
+        const float ss = wave_sum(a * a + b * b);
+        const float rstd = rsqrtf(ss * (1.0f / 128.0f) + eps);
+        // the reference normalises in the activation dtype: round the normalised value to bf16 before RoPE
+        an = bf16_bits_to_f32(f32_to_bf16_bits(a * rstd * bf16_bits_to_f32(w[lane])));
+        bn = bf16_bits_to_f32(f32_to_bf16_bits(b * rstd * bf16_bits_to_f32(w[lane + 64])));
+    }
     const float inv_freq = exp2f(-log2_theta * (float)(2 * lane) * (1.0f / 128.0f));
     float sn, cs;
     sincosf((float)row * inv_freq, &sn, &cs);

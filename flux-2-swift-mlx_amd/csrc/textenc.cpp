@@ -71,8 +71,13 @@ extern "C" int flux2mi_textenc_preset(const char* name, flux2mi_textenc_config* 
     F2_REQUIRE(name && out, FLUX2MI_ERR_INVALID_ARG, "textenc_preset: NULL argument");
     // Qwen3-4B / Qwen3-8B as published (config.json: head_dim 128; the reference reads it at load,
     // Configuration/Qwen3Configuration.swift:52-70) with Klein's extraction layers (KleinConfig: 9, 18, 27)
-    if (!strcmp(name, "klein-4b")) *out = flux2mi_textenc_config{151936, 2560, 9728, 36, 32, 8, 128, 1.0e6f, 1.0e-6f, {9, 18, 27}};
-    else if (!strcmp(name, "klein-9b")) *out = flux2mi_textenc_config{151936, 4096, 12288, 36, 32, 8, 128, 1.0e6f, 1.0e-6f, {9, 18, 27}};
+    if (!strcmp(name, "klein-4b")) *out = flux2mi_textenc_config{151936, 2560, 9728, 36, 32, 8, 128, 1.0e6f, 1.0e-6f, {9, 18, 27}, 1};
+    else if (!strcmp(name, "klein-9b")) *out = flux2mi_textenc_config{151936, 4096, 12288, 36, 32, 8, 128, 1.0e6f, 1.0e-6f, {9, 18, 27}, 1};
+    // Dev: Mistral-Small-3.2-24B text model as published (config.json; the reference's in-code fallback
+    // EncoderConfiguration.swift:86-103 has intermediate 14336 / theta 1e6 and is overridden by the file),
+    // hidden states 10, 20, 30 (EmbeddingExtractor.swift:60); no q/k norm.  The position-dependent
+    // "Llama-4" query scale (MistralAttention.swift:422-431) is 1 for positions < 16384, i.e. for all 512.
+    else if (!strcmp(name, "dev")) *out = flux2mi_textenc_config{131072, 5120, 32768, 40, 32, 8, 128, 1.0e9f, 1.0e-5f, {10, 20, 30}, 0};
     else {
         flux2mi_set_error("textenc_preset: unknown model '%s'", name);
         return FLUX2MI_ERR_INVALID_ARG;
@@ -114,8 +119,14 @@ extern "C" int flux2mi_textenc_create(flux2mi_ctx* ctx, const flux2mi_textenc_co
         te_slot(m, nm("mlp.down_proj.weight"), te_add_buf(m, d, I, nm("down_proj")), 0, d, I, 0);
         te_slot(m, nm("input_layernorm.weight"), te_add_buf(m, 1, d, nm("ln_in")), 0, 1, d, 0);
         te_slot(m, nm("post_attention_layernorm.weight"), te_add_buf(m, 1, d, nm("ln_post")), 0, 1, d, 0);
-        te_slot(m, nm("self_attn.q_norm.weight"), te_add_buf(m, 1, 128, nm("q_norm")), 0, 1, 128, 0);
-        te_slot(m, nm("self_attn.k_norm.weight"), te_add_buf(m, 1, 128, nm("k_norm")), 0, 1, 128, 0);
+        // always allocated so that the buffer order per layer is fixed; without qk_norm they stay unused
+        const int bqn = te_add_buf(m, 1, 128, nm("q_norm")), bkn = te_add_buf(m, 1, 128, nm("k_norm"));
+        if (c->qk_norm) {
+            te_slot(m, nm("self_attn.q_norm.weight"), bqn, 0, 1, 128, 0);
+            te_slot(m, nm("self_attn.k_norm.weight"), bkn, 0, 1, 128, 0);
+        } else {
+            m->bufs[bqn].got = m->bufs[bkn].got = 1;
+        }
     }
     for (TBuf& b : m->bufs) {
         const size_t bytes = (size_t)b.rows * b.cols * 2;
@@ -210,10 +221,11 @@ extern "C" int flux2mi_textenc_finalize(flux2mi_textenc* m) {
     return FLUX2MI_OK;
 }
 
-extern "C" int flux2mi_textenc_forward(flux2mi_textenc* m, const int32_t* ids, int S, int valid_len, void* out) {
+extern "C" int flux2mi_textenc_forward(flux2mi_textenc* m, const int32_t* ids, int S, int pad_left, int valid_len, void* out) {
     F2_REQUIRE(m && ids && out, FLUX2MI_ERR_INVALID_ARG, "textenc_forward: NULL argument");
     F2_REQUIRE(m->finalized, FLUX2MI_ERR_NOT_LOADED, "textenc_forward: weights not finalized");
-    F2_REQUIRE(S > 0 && valid_len >= 1 && valid_len <= S, FLUX2MI_ERR_SHAPE, "textenc_forward: S %d valid_len %d", S, valid_len);
+    F2_REQUIRE(S > 0 && pad_left >= 0 && valid_len >= 1 && pad_left + valid_len <= S, FLUX2MI_ERR_SHAPE,
+               "textenc_forward: S %d pad_left %d valid_len %d", S, pad_left, valid_len);
     F2_CHECK_HIP(hipSetDevice(m->ctx->device));
     hipStream_t st = m->ctx->stream;
     const flux2mi_textenc_config& c = m->cfg;
@@ -253,8 +265,10 @@ extern "C" int flux2mi_textenc_forward(flux2mi_textenc* m, const int32_t* ids, i
             GemmProblem p = te_mk(xn, d, w.qkv, d, qkv, nqkv, S, nqkv, d, EPI_BF16);
             F2_LAUNCH(launch_gemm(st, &p, 1), "qkv_proj");
         }
-        F2_LAUNCH(launch_qk_norm_rope_llm_vt(st, qkv, S, hq, hkv, w.qn, w.kn, c.rms_eps, c.rope_theta, vt, s_pad), "qk_norm_rope");
-        F2_LAUNCH(launch_attention_causal(st, qkv, qkv + nq, nqkv, vt, s_pad, attn, nq, S, valid_len, hq, hkv), "attention");
+        F2_LAUNCH(launch_qk_norm_rope_llm_vt(st, qkv, S, hq, hkv, c.qk_norm ? w.qn : nullptr, c.qk_norm ? w.kn : nullptr,
+                                             c.rms_eps, c.rope_theta, vt, s_pad), "qk_norm_rope");
+        F2_LAUNCH(launch_attention_causal(st, qkv, qkv + nq, nqkv, vt, s_pad, attn, nq, S, pad_left, pad_left + valid_len, hq, hkv),
+                  "attention");
         {
             GemmProblem p = te_mk(attn, nq, w.o, nq, hs, d, S, d, nq, EPI_GATE_RESID);
             p.vec = m->ones.as<float>();

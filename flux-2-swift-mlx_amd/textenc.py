@@ -49,6 +49,7 @@ class TextEncoder:
             cfg.rms_eps = float(config.get("rms_eps", 1.0e-6))
             for i, v in enumerate(config.get("extract_layers", (9, 18, 27))):
                 cfg.extract_layers[i] = int(v)
+            cfg.qk_norm = int(config.get("qk_norm", 1))
         self.cfg = cfg
         h = C.c_void_p()
         check(lib().flux2mi_textenc_create(ctx.handle, C.byref(cfg), C.byref(h)))
@@ -79,13 +80,13 @@ class TextEncoder:
     def param_bytes(self) -> int:
         return int(lib().flux2mi_textenc_param_bytes(self.handle))
 
-    def forward(self, token_ids: torch.Tensor, valid_len: int) -> torch.Tensor:
-        """ids i32 [S] (device) -> bf16 [1, S, 3*hidden]  (async)."""
+    def forward(self, token_ids: torch.Tensor, valid_len: int, pad_left: int = 0) -> torch.Tensor:
+        """ids i32 [S] (device), real tokens [pad_left, pad_left + valid_len) -> bf16 [1, S, 3*hidden]  (async)."""
         ids = _req(token_ids.reshape(-1), torch.int32, "token_ids")
         S = ids.shape[0]
         out = torch.empty((1, S, 3 * self.cfg.hidden), dtype=torch.bfloat16, device=ids.device)
         self.ctx._enter()
-        check(lib().flux2mi_textenc_forward(self.handle, _ptr(ids), S, int(valid_len), _ptr(out)))
+        check(lib().flux2mi_textenc_forward(self.handle, _ptr(ids), S, int(pad_left), int(valid_len), _ptr(out)))
         self.ctx._exit()
         return out
 
@@ -108,6 +109,19 @@ class TextEncoder:
             raise Flux2Error(L.ERR_INVALID_ARG, "empty prompt")
         t = torch.tensor(ids, dtype=torch.int32, device=self.ctx.device)
         return self.forward(t, n)
+
+    # ---- EmbeddingExtractor.extractFluxEmbeddings(prompt:maxLength:) (Dev, Mistral) -------------------
+    def extract_flux_embeddings(self, token_ids: Sequence[int], max_length: int = KLEIN_MAX_SEQUENCE_LENGTH,
+                                pad_id: int = 11) -> torch.Tensor:
+        """`token_ids` = the chat-template encoding of [system message, user prompt] (tokenizer work stays
+        with the caller: EmbeddingExtractor.swift:206-218); truncated to max_length and LEFT-padded with the
+        tokenizer's pad token (:226-237).  -> [1, max_length, 3*hidden] bf16."""
+        ids = list(token_ids)[:max_length]
+        n = len(ids)
+        if n == 0:
+            raise Flux2Error(L.ERR_INVALID_ARG, "empty prompt")
+        t = torch.tensor([pad_id] * (max_length - n) + ids, dtype=torch.int32, device=self.ctx.device)
+        return self.forward(t, n, pad_left=max_length - n)
 
     def close(self):
         if self.handle and self.ctx.handle:

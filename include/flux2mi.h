@@ -194,9 +194,11 @@ typedef struct flux2mi_textenc_config {
     int heads, kv_heads, head_dim;   /* head_dim must be 128 */
     float rope_theta;        /* 1e6 */
     float rms_eps;           /* 1e-6 */
-    int extract_layers[3];   /* 1-based "after layer i" indices, Klein: 9, 18, 27 (KleinConfig.hiddenStateLayers) */
+    int extract_layers[3];   /* 1-based "after layer i" indices, Klein: 9, 18, 27 (KleinConfig.hiddenStateLayers); Dev: 10, 20, 30 */
+    int qk_norm;             /* 1: per-head RMSNorm of q and k before RoPE (Qwen3); 0: none (Mistral) */
 } flux2mi_textenc_config;
-/* presets "klein-4b" (Qwen3-4B) | "klein-9b" (Qwen3-8B) */
+/* presets "klein-4b" (Qwen3-4B) | "klein-9b" (Qwen3-8B) | "dev" (Mistral-Small-3.2-24B text model:
+ * Model/MistralModel.swift, MistralAttention.swift, Embeddings/EmbeddingExtractor.swift:202-278) */
 int flux2mi_textenc_preset(const char* name, flux2mi_textenc_config* out);
 int flux2mi_textenc_create(flux2mi_ctx* ctx, const flux2mi_textenc_config* cfg, flux2mi_textenc** out);
 int flux2mi_textenc_destroy(flux2mi_textenc* te);
@@ -206,10 +208,14 @@ int flux2mi_textenc_set_tensor(flux2mi_textenc* te, const char* name, int dtype,
                                const void* data);
 int flux2mi_textenc_finalize(flux2mi_textenc* te);
 int64_t flux2mi_textenc_param_bytes(const flux2mi_textenc* te);
-/* ids i32 [S] on the device, right-padded; valid_len = number of real tokens (attention mask
- * [1]*valid_len + [0]*(S - valid_len), causal).  out bf16 [S, 3*hidden] (device) = hidden states
- * after the three extract layers, concatenated: the DiT's txt_emb.  Async. */
-int flux2mi_textenc_forward(flux2mi_textenc* te, const int32_t* ids, int S, int valid_len, void* out);
+/* ids i32 [S] on the device; real tokens are [pad_left, pad_left + valid_len): Klein right-pads
+ * (pad_left 0, KleinEmbeddingExtractor.swift:70-90), Dev left-pads (pad_left = S - valid_len,
+ * EmbeddingExtractor.swift:226-247).  Attention mask as the reference builds it: causal, pad keys
+ * masked (rows of left-pad tokens end up attending uniformly to the pads before them, the effect of
+ * its finite -1e9 mask in f32).  Positions are the row indices in both cases.
+ * out bf16 [S, 3*hidden] (device) = hidden states after the three extract layers, concatenated:
+ * the DiT's txt_emb.  Async. */
+int flux2mi_textenc_forward(flux2mi_textenc* te, const int32_t* ids, int S, int pad_left, int valid_len, void* out);
 
 /* ---- VAE decoder (AutoencoderKLFlux2.decode) ---------------------------- */
 typedef struct flux2mi_vae_config {

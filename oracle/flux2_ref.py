@@ -792,11 +792,16 @@ def _rope_split_half(x: Tensor, theta: float) -> Tensor:
     return torch.cat([a * cos - b * sin, b * cos + a * sin], dim=-1)
 
 
-def qwen3_hidden_states(P: Dict[str, Tensor], tcfg: dict, ids: Tensor, valid_len: int, layers: Sequence[int]) -> Dict[int, Tensor]:
+def qwen3_hidden_states(P: Dict[str, Tensor], tcfg: dict, ids: Tensor, valid_len: int, layers: Sequence[int],
+                        pad_left: int = 0) -> Dict[int, Tensor]:
     """Qwen3Model.forwardWithHiddenStates (Qwen3Model.swift:109-174).  ids int64 [S]; returns
     {layer index (1-based, "after layer i"): [1, S, hidden]}.  Causal mask + right-padding mask
     (:176-212, pad keys get -1e9), GQA by repetition (Qwen3Attention.swift:135-147), q_norm/k_norm
-    before RoPE (:110-123), SwiGLU MLP (Qwen3MLP.swift)."""
+    before RoPE (:110-123), SwiGLU MLP (Qwen3MLP.swift).
+    With tcfg["qk_norm"] == 0 and pad_left > 0 this is the Dev path (MistralModel.swift:95-195,
+    MistralAttention.swift:395-470, EmbeddingExtractor.swift:202-278): no q/k norm, real tokens at
+    [pad_left, pad_left + valid_len), same additive mask; the position-dependent query scale of
+    MistralAttention.swift:422-431 is exactly 1 below position 16384."""
     H, Hkv, hd = tcfg["heads"], tcfg["kv_heads"], tcfg.get("head_dim", 128)
     eps, theta = tcfg.get("rms_eps", 1e-6), tcfg.get("rope_theta", 1.0e6)
     S = ids.shape[0]
@@ -804,7 +809,7 @@ def qwen3_hidden_states(P: Dict[str, Tensor], tcfg: dict, ids: Tensor, valid_len
     x = g("embed_tokens.weight").float()[ids].unsqueeze(0)
     i_idx = torch.arange(S)
     mask = torch.where(i_idx[None, :] <= i_idx[:, None], 0.0, float("-inf"))
-    mask = mask + torch.where(i_idx < valid_len, 0.0, -1e9)[None, :]
+    mask = mask + torch.where((i_idx >= pad_left) & (i_idx < pad_left + valid_len), 0.0, -1e9)[None, :]
     out = {}
     for l in range(max(layers)):
         pre = f"layers.{l}."
@@ -812,8 +817,9 @@ def qwen3_hidden_states(P: Dict[str, Tensor], tcfg: dict, ids: Tensor, valid_len
         q = linear(h, g(pre + "self_attn.q_proj.weight")).reshape(1, S, H, hd)
         k = linear(h, g(pre + "self_attn.k_proj.weight")).reshape(1, S, Hkv, hd)
         v = linear(h, g(pre + "self_attn.v_proj.weight")).reshape(1, S, Hkv, hd)
-        q = _rms(q, g(pre + "self_attn.q_norm.weight"), eps).permute(0, 2, 1, 3)
-        k = _rms(k, g(pre + "self_attn.k_norm.weight"), eps).permute(0, 2, 1, 3)
+        if tcfg.get("qk_norm", 1):
+            q, k = _rms(q, g(pre + "self_attn.q_norm.weight"), eps), _rms(k, g(pre + "self_attn.k_norm.weight"), eps)
+        q, k = q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3)
         v = v.permute(0, 2, 1, 3)
         q, k = _rope_split_half(q, theta), _rope_split_half(k, theta)
         rep = H // Hkv
@@ -828,9 +834,10 @@ def qwen3_hidden_states(P: Dict[str, Tensor], tcfg: dict, ids: Tensor, valid_len
     return out
 
 
-def klein_embeddings(P: Dict[str, Tensor], tcfg: dict, ids: Tensor, valid_len: int) -> Tensor:
-    """KleinEmbeddingExtractor.extractKleinEmbeddings steps 8-10: hidden states after the extract layers,
-    concatenated on the feature axis -> [1, S, 3*hidden]."""
+def klein_embeddings(P: Dict[str, Tensor], tcfg: dict, ids: Tensor, valid_len: int, pad_left: int = 0) -> Tensor:
+    """KleinEmbeddingExtractor.extractKleinEmbeddings steps 8-10 (pad_left 0) / EmbeddingExtractor.
+    extractFluxEmbeddings steps 7-9 (Dev: pad_left = S - valid_len): hidden states after the extract
+    layers, concatenated on the feature axis -> [1, S, 3*hidden]."""
     ls = tuple(tcfg.get("extract_layers", (9, 18, 27)))
-    hs = qwen3_hidden_states(P, tcfg, ids, valid_len, ls)
+    hs = qwen3_hidden_states(P, tcfg, ids, valid_len, ls, pad_left)
     return torch.cat([hs[i] for i in ls], dim=-1)

@@ -19,6 +19,10 @@ TINY = dict(vocab=1000, hidden=256, intermediate=512, n_layers=4, heads=4, kv_he
             rope_theta=1.0e6, rms_eps=1.0e-6, extract_layers=(1, 2, 3))
 
 
+MISTRAL_TINY = dict(vocab=1000, hidden=256, intermediate=512, n_layers=4, heads=4, kv_heads=2, head_dim=128,
+                    rope_theta=1.0e9, rms_eps=1.0e-5, extract_layers=(1, 2, 3), qk_norm=0)
+
+
 def make_qwen3_weights(tcfg, seed=77):
     """Deterministic bf16-exact weights in HF naming (model.* prefix dropped)."""
     g = torch.Generator().manual_seed(seed)
@@ -30,8 +34,9 @@ def make_qwen3_weights(tcfg, seed=77):
         P[p + "self_attn.k_proj.weight"] = torch.randn((Hkv * hd, d), generator=g) * d ** -0.5
         P[p + "self_attn.v_proj.weight"] = torch.randn((Hkv * hd, d), generator=g) * d ** -0.5
         P[p + "self_attn.o_proj.weight"] = torch.randn((d, H * hd), generator=g) * (H * hd) ** -0.5
-        P[p + "self_attn.q_norm.weight"] = 1.0 + 0.1 * torch.randn((hd,), generator=g)
-        P[p + "self_attn.k_norm.weight"] = 1.0 + 0.1 * torch.randn((hd,), generator=g)
+        if tcfg.get("qk_norm", 1):
+            P[p + "self_attn.q_norm.weight"] = 1.0 + 0.1 * torch.randn((hd,), generator=g)
+            P[p + "self_attn.k_norm.weight"] = 1.0 + 0.1 * torch.randn((hd,), generator=g)
         P[p + "mlp.gate_proj.weight"] = torch.randn((I, d), generator=g) * d ** -0.5
         P[p + "mlp.up_proj.weight"] = torch.randn((I, d), generator=g) * d ** -0.5
         P[p + "mlp.down_proj.weight"] = torch.randn((d, I), generator=g) * I ** -0.5
@@ -64,6 +69,33 @@ def main():
                         h1=hs[1][0].numpy(), h2=hs[2][0].numpy(), h3=hs[3][0].numpy(),
                         weight_checksum=np.array([float(sum(v.float().double().sum() for v in P.values()))]))
     print("written", os.path.join(OUT, "qwen3_tiny.npz"), [tuple(h.shape) for h in hs])
+
+    # ---- Mistral (Dev's encoder): LEFT padding.  Only the rows of real tokens are comparable with HF:
+    # a fully masked (pad) query row is implementation-defined there, while the reference's finite
+    # -1e9 mask makes it a uniform average (restated and tested in the oracle).
+    from transformers import MistralConfig, MistralModel
+    t = MISTRAL_TINY
+    P = make_qwen3_weights(t, seed=78)
+    cfg = MistralConfig(vocab_size=t["vocab"], hidden_size=t["hidden"], intermediate_size=t["intermediate"],
+                        num_hidden_layers=t["n_layers"], num_attention_heads=t["heads"], num_key_value_heads=t["kv_heads"],
+                        head_dim=t["head_dim"], max_position_embeddings=1024, rope_theta=t["rope_theta"],
+                        rms_norm_eps=t["rms_eps"], sliding_window=None, attention_dropout=0.0)
+    m = MistralModel(cfg).eval().float()
+    sd = {k: v.float() for k, v in P.items()}
+    sd["norm.weight"] = torch.ones(t["hidden"])
+    m.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(6)
+    S, valid = 48, 29
+    pad = S - valid
+    ids = torch.randint(0, t["vocab"], (S,), generator=g)
+    ids[:pad] = 11
+    mask = (torch.arange(S) >= pad).long()[None]
+    with torch.no_grad():
+        out = m(input_ids=ids[None], attention_mask=mask, position_ids=torch.arange(S)[None], output_hidden_states=True)
+    hs = out.hidden_states
+    np.savez_compressed(os.path.join(OUT, "mistral_tiny.npz"), ids=ids.numpy(), valid_len=np.array([valid]),
+                        pad_left=np.array([pad]), h1=hs[1][0].numpy(), h2=hs[2][0].numpy(), h3=hs[3][0].numpy())
+    print("written", os.path.join(OUT, "mistral_tiny.npz"))
 
 
 if __name__ == "__main__":

@@ -103,3 +103,56 @@ def test_errors(flux2mi, ctx):
     with pytest.raises(Flux2Error):   # not finalized
         te.forward(torch.zeros(8, dtype=torch.int32, device="cuda"), 4)
     te.close()
+
+
+# ---- Dev's encoder: Mistral (no q/k norm), LEFT padding ----------------------------------------------
+def test_mistral_tiny_vs_hf_fixture_and_oracle(flux2mi, ctx):
+    g = np.load("tests/golden/mistral_tiny.npz")
+    P = G.make_qwen3_weights(G.MISTRAL_TINY, seed=78)
+    te = _encoder(ctx, G.MISTRAL_TINY, P)
+    v, pad = int(g["valid_len"][0]), int(g["pad_left"][0])
+    ids = torch.from_numpy(g["ids"])
+    out = te.forward(ids.to(torch.int32).cuda(), v, pad_left=pad).float().cpu()[0]
+    ref = R.klein_embeddings(P, G.MISTRAL_TINY, ids, v, pad_left=pad)[0]
+    assert torch.isfinite(out).all()
+    for i in range(3):   # real rows against HF, every row (pads included) against the oracle
+        assert rel_l2(out[pad:, 256 * i:256 * (i + 1)], torch.from_numpy(g[f"h{i + 1}"][pad:])) < 2e-2
+    assert rel_l2(out, ref) < 2e-2
+    assert rel_l2(out[:pad], ref[:pad]) < 2e-2
+    te.close()
+
+
+@pytest.mark.parametrize("S,valid", [(512, 60), (512, 449), (512, 512), (200, 3), (130, 1)])
+def test_left_padding_lengths_vs_oracle(flux2mi, ctx, S, valid):
+    """Left padding across the attention tiling: pad/real boundary inside a 64-key tile, inside a
+    128-row workgroup, workgroups entirely in the pads, no padding at all."""
+    P = G.make_qwen3_weights(G.MISTRAL_TINY, seed=78)
+    te = _encoder(ctx, G.MISTRAL_TINY, P)
+    gen = torch.Generator().manual_seed(S + valid)
+    ids = torch.randint(0, G.MISTRAL_TINY["vocab"], (S,), generator=gen)
+    pad = S - valid
+    ids[:pad] = 11
+    out = te.forward(ids.to(torch.int32).cuda(), valid, pad_left=pad).float().cpu()
+    ref = R.klein_embeddings(P, G.MISTRAL_TINY, ids, valid, pad_left=pad)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 2e-2
+    assert rel_l2(out[0, pad:], ref[0, pad:]) < 2e-2
+    if pad:
+        assert rel_l2(out[0, :pad], ref[0, :pad]) < 2e-2
+    te.close()
+
+
+def test_mistral_width_slice(flux2mi, ctx):
+    """Mistral-Small widths for attention (hidden 5120, 32 / 8 heads of 128) with a narrowed MLP, 2 of 3
+    layers run, through `extract_flux_embeddings` (left padding to 512)."""
+    tcfg = dict(vocab=2048, hidden=5120, intermediate=4096, n_layers=4, heads=32, kv_heads=8, head_dim=128,
+                rope_theta=1.0e9, rms_eps=1.0e-5, extract_layers=(1, 2, 3), qk_norm=0)
+    P = G.make_qwen3_weights(tcfg, seed=10)
+    te = _encoder(ctx, tcfg, P)
+    toks = list(range(100, 171))
+    out = te.extract_flux_embeddings(toks, 512, pad_id=11).float().cpu()
+    ids = torch.tensor([11] * (512 - len(toks)) + toks)
+    ref = R.klein_embeddings(P, tcfg, ids, len(toks), pad_left=512 - len(toks))
+    assert out.shape == (1, 512, 15360)
+    assert rel_l2(out, ref) < 2e-2
+    te.close()

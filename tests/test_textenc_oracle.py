@@ -45,3 +45,22 @@ def test_klein_prompt_formatting(flux2mi):
     assert ids == [5, 6, 7] + [151643] * 5 and n == 3       # RIGHT padding with <|endoftext|> (:70-90)
     ids, n = te.pad_klein_token_ids(list(range(600)))
     assert len(ids) == 512 and n == 512                     # truncation to maxSequenceLength
+
+
+def test_mistral_left_padding_matches_hf_fixture_on_real_rows():
+    """Dev's encoder (Mistral: no q/k norm, LEFT padding).  The rows of real tokens are pinned against
+    HF `MistralModel` (tests/golden/mistral_tiny.npz); pad rows are implementation-defined in HF, the
+    reference's finite -1e9 pad mask makes them uniform averages over the pads before them."""
+    g = np.load("tests/golden/mistral_tiny.npz")
+    P = G.make_qwen3_weights(G.MISTRAL_TINY, seed=78)
+    v, pad = int(g["valid_len"][0]), int(g["pad_left"][0])
+    ids = torch.from_numpy(g["ids"])
+    hs = R.qwen3_hidden_states(P, G.MISTRAL_TINY, ids, v, (1, 2, 3), pad_left=pad)
+    for i in (1, 2, 3):
+        np.testing.assert_allclose(hs[i][0, pad:].numpy(), g[f"h{i}"][pad:], rtol=2e-5, atol=2e-5)
+    # pad query row i attends uniformly to keys 0..i: layer-1 attention output of row 0 = V row 0 path,
+    # checked through the defining property: the first pad rows do not depend on any later token
+    ids2 = ids.clone()
+    ids2[pad:] = (ids2[pad:] + 17) % G.MISTRAL_TINY["vocab"]
+    hs2 = R.qwen3_hidden_states(P, G.MISTRAL_TINY, ids2, v, (3,), pad_left=pad)
+    np.testing.assert_allclose(hs[3][0, :pad].numpy(), hs2[3][0, :pad].numpy(), rtol=1e-5, atol=1e-5)
