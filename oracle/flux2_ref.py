@@ -20,6 +20,10 @@ structural/known-answer facts the reference's tests assert (scheduler counts
 and end points, strength slicing, custom-sigma terminal append, position-ID
 layout, pack/unpack shapes, dimension rounding, mask packing sums) — see
 `tests/test_oracle_structural.py`, which cites each XCTest it mirrors.
+Exception: the TEXT-ENCODER restatements at the end of this file (Qwen3 for Klein, Mistral for Dev)
+ARE pinned against an independent implementation that runs here, HuggingFace transformers 5.15
+(`Qwen3Model`, `MistralModel`): `tests/golden/{qwen3,mistral}_tiny.npz` made by
+`tests/golden/make_golden_qwen3.py`, checked in `tests/test_textenc_oracle.py` (max abs diff 3e-6).
 
 Numerics: the reference runs fp16 weights x fp32 activations.  The
 oracle runs everything in fp32 on the weights it is handed (tests hand it
