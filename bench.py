@@ -114,6 +114,7 @@ def main():
     elapsed = par.all_reduce_max(elapsed, dev)
 
     if rank != 0:
+        par.finalize()
         return
 
     K = args.steps
@@ -174,7 +175,8 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
     }
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    par.finalize()
 
 
 def run_cpu_baseline(P_dev, cfg, syn):

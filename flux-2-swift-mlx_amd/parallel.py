@@ -64,6 +64,13 @@ def all_gather_images(local_images: torch.Tensor) -> torch.Tensor:
     return stacked.reshape(-1, *local_images.shape[1:])
 
 
+def finalize():
+    """Tear the process group down (ranks leave together; no-op for a single process)."""
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
