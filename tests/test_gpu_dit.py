@@ -295,3 +295,38 @@ def test_forward_with_scaled_qk_norm_weights(flux2mi, ctx, factor, s_txt, h, w):
     ref = R.dit_forward(P, cfg, lat, inp["txt"].float(), torch.tensor([0.731]), None, img_ids, txt_ids)[0]
     assert torch.isfinite(out).all()
     assert rel_l2(out, ref) < 2e-2
+
+
+# ---- edge sizes ------------------------------------------------------------------------------------
+def test_maximum_size_2048_forward(flux2mi, ctx):
+    """The reference's largest output, 2048 x 2048 (S_img 16384, S 16400): long KV loops (257 tiles),
+    the 8-wave attention workgroups with the fixed-offset softmax, GEMMs with M = 16400.  Tiny widths
+    so that the f32 oracle stays affordable on the CPU; rel-L2 <= 2e-2."""
+    from flux2mi import synthetic as syn
+    out, ref = _forward_both(flux2mi, ctx, syn.DIT_PRESETS["tiny"], s_txt=16, h=2048, w=2048)
+    assert out.shape == (16384, 128)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 2e-2
+
+
+def test_three_reference_images(flux2mi, ctx):
+    """I2I with the maximum of three reference images (Flux2Pipeline.swift:921), T offsets 10, 20, 30
+    (LatentUtils.swift:324-346), different sizes, appended after the output tokens."""
+    from flux2mi import synthetic as syn
+    g = torch.Generator().manual_seed(6)
+    hs, ws = [4, 2, 6], [6, 8, 4]
+    n = sum(a * b for a, b in zip(hs, ws))
+    ref_lat = torch.randn((1, n, 128), generator=g)
+    ref_ids = R.reference_position_ids(hs, ws)
+    assert ref_ids.shape == (n, 4) and set(ref_ids[:, 0].tolist()) == {10, 20, 30}
+    out, ref = _forward_both(flux2mi, ctx, syn.DIT_PRESETS["tiny"], s_txt=16, h=96, w=64, refs=(ref_lat, ref_ids))
+    s_out = (96 // 16) * (64 // 16)
+    assert rel_l2(out[:s_out], ref[:s_out]) < 2e-2
+
+
+def test_smallest_image(flux2mi, ctx):
+    """16 x 16 pixels = ONE image token (+ 1 text token): S = 2."""
+    from flux2mi import synthetic as syn
+    out, ref = _forward_both(flux2mi, ctx, syn.DIT_PRESETS["tiny"], s_txt=1, h=16, w=16)
+    assert out.shape == (1, 128)
+    assert rel_l2(out, ref) < 2e-2
