@@ -205,6 +205,17 @@ class Context:
         self._exit()
         return out
 
+    def op_gemm_gate_resid(self, a: torch.Tensor, w: torch.Tensor, gate: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """x f32 [M,N] += gate[N] * (a @ w.T), in place; returns x."""
+        a, w = _req(a, torch.bfloat16, "A"), _req(w, torch.bfloat16, "W")
+        gate, x = _req(gate, torch.float32, "gate"), _req(x, torch.float32, "x")
+        m, k = a.shape
+        n = w.shape[0]
+        self._enter()
+        check(lib().flux2mi_op_gemm_gate_resid(self.handle, _ptr(a), _ptr(w), _ptr(gate), _ptr(x), m, n, k))
+        self._exit()
+        return x
+
     def op_gemm_fp8(self, a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
         a, w = _req(a, torch.bfloat16, "A"), _req(w, torch.bfloat16, "W")
         m, k = a.shape

@@ -891,6 +891,20 @@ extern "C" int flux2mi_op_gemm_bf16(flux2mi_ctx* ctx, const void* A, const void*
     return FLUX2MI_OK;
 }
 
+// x += gate (per column) * (A W^T): the epilogue of the proj / mlp_out / linear2 GEMMs, exposed for tests and
+// microbenchmarks (tools/gate_resid_bench.py)
+extern "C" int flux2mi_op_gemm_gate_resid(flux2mi_ctx* ctx, const void* A, const void* W, const float* gate, float* X,
+                                          int M, int N, int K) {
+    F2_REQUIRE(ctx && A && W && gate && X && M > 0 && N > 0 && K > 0, FLUX2MI_ERR_INVALID_ARG, "op_gemm_gate_resid: bad argument");
+    GemmProblem p = mk(reinterpret_cast<const uint16_t*>(A), K, reinterpret_cast<const uint16_t*>(W), K, X, N, M, N, K, EPI_GATE_RESID);
+    p.vec = gate;
+    prof_before(ctx, PROF_DIT_GEMM);
+    const int r = launch_gemm(ctx->stream, &p, 1);
+    prof_after(ctx, PROF_DIT_GEMM, 2.0 * M * (double)N * K);
+    F2_LAUNCH(r, "op_gemm_gate_resid");
+    return FLUX2MI_OK;
+}
+
 extern "C" int flux2mi_op_gemm_fp8(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K) {
     F2_REQUIRE(ctx && A && W && C && M > 0 && N > 0 && K > 0 && K % 128 == 0, FLUX2MI_ERR_INVALID_ARG, "op_gemm_fp8: bad argument");
     const size_t need = (size_t)M * K + (size_t)N * K + ((size_t)M + N) * 4 + 1024;

@@ -322,6 +322,10 @@ int flux2mi_prof_end(flux2mi_ctx* ctx, int* n_launches, double* total_ms, double
 /* Standalone op entry points (tests / microbenchmarks; same kernels the forward uses). */
 /* C[M,N] (f32) = A[M,K] (bf16) * W[N,K]^T (bf16) */
 int flux2mi_op_gemm_bf16(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K);
+/* X f32 [M,N] += gate f32 [N] (per column) * (A W^T): the gate + residual epilogue of the block output GEMMs
+ * (Flux2TransformerBlock.swift:117-166 applyGate + residual). */
+int flux2mi_op_gemm_gate_resid(flux2mi_ctx* ctx, const void* A, const void* W, const float* gate, float* X, int M,
+                               int N, int K);
 /* same product through the fp8 path: A and W (bf16) are quantised row-wise to OCP e4m3 with
  * per-row scales (what the fp8 model does to activations / weights), then
  * v_mfma_f32_16x16x32_fp8_fp8; K % 128 == 0. */

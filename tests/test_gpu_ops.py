@@ -219,3 +219,38 @@ def test_gemm_race_screen(ctx):
         for it in range(25):
             out = ctx.op_gemm_bf16(a, w)
             assert torch.equal(out, ref), (M, N, K, it)
+
+
+# ---- gate + residual epilogue of the block-output GEMMs ------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [
+    (4608, 3072, 12288),   # single.linear2: 216 tiles, 192 K-tiles
+    (4608, 3072, 9216),    # double.mlp_out
+    (4500, 3000, 6144),    # ragged edges
+    (4608, 3072, 3072),    # attention projection
+    (2304, 3072, 12288),   # 512x512 image
+])
+def test_gemm_gate_resid_exact(ctx, M, N, K):
+    """x += gate * (A W^T) on integer-valued data (every partial sum exact in f32): bit-exact against
+    the reference and identical on repeated launches."""
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    a = torch.randint(-2, 3, (M, K), generator=g, device="cuda").to(torch.bfloat16)
+    w = torch.randint(-2, 3, (N, K), generator=g, device="cuda").to(torch.bfloat16)
+    gate = torch.randint(-2, 3, (N,), generator=g, device="cuda").float()
+    x0 = torch.randint(-8, 9, (M, N), generator=g, device="cuda").float()
+    ref = x0 + gate[None, :] * (a.float() @ w.float().t())
+    for it in range(6):
+        x = ctx.op_gemm_gate_resid(a, w, gate, x0.clone())
+        assert torch.equal(x, ref), (M, N, K, it)
+
+
+def test_gemm_gate_resid_random_deterministic(ctx):
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randn((4608, 12288), generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn((3072, 12288), generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    gate = torch.randn((3072,), generator=g, device="cuda")
+    x0 = torch.randn((4608, 3072), generator=g, device="cuda")
+    outs = [ctx.op_gemm_gate_resid(a, w, gate, x0.clone()) for _ in range(4)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    ref = x0 + gate[None, :] * (a.float() @ w.float().t())
+    assert rel_l2(outs[0], ref) < 2e-3
