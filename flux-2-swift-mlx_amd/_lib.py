@@ -92,6 +92,11 @@ PROTOTYPES = {
     "flux2mi_scale_noise": (_I, [_P, _P, _P, _P, _F, _I64]),
     "flux2mi_cfg_combine": (_I, [_P, _P, _P, _F, _I64]),
     "flux2mi_repaint_blend": (_I, [_P, _P, _P, _P, _P, _F, _I, _I]),
+    "flux2mi_mlx_random_key": (None, [C.c_uint64, C.POINTER(C.c_uint32)]),
+    "flux2mi_mlx_random_split": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "flux2mi_mlx_random_bits": (_I, [_P, C.POINTER(C.c_uint32), _P, _I64]),
+    "flux2mi_mlx_random_uniform": (_I, [_P, C.POINTER(C.c_uint32), _P, _I64, _F, _F]),
+    "flux2mi_mlx_random_normal": (_I, [_P, C.POINTER(C.c_uint32), _P, _I64]),
     "flux2mi_pack_patchified_to_sequence": (_I, [_P, _P, _P, _I, _I, _I]),
     "flux2mi_unpack_sequence_to_patchified": (_I, [_P, _P, _P, _I, _I, _I]),
     "flux2mi_latents_to_vae_input": (_I, [_P, _P, _P, _P, _P, _I, _I]),

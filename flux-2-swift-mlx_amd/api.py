@@ -245,6 +245,45 @@ def _set_tensors(fn, handle, tensors: Dict[str, torch.Tensor]):
         check(fn(handle, name.encode(), _DT[t.dtype], shape, t.dim(), C.c_void_p(t.data_ptr())))
 
 
+class MLXRandom:
+    """The reference's global random state: `MLXRandom.seed(seed)` followed by keyless `MLXRandom.normal(shape)` /
+    `uniform` draws (LatentUtils.swift:32-41, Flux2Pipeline.swift:1203-1204, 2313, 2403).  Each draw splits the
+    state key on the host (two Threefry hashes) and generates on the device with the sub-key, so a given seed yields
+    the stream MLX yields (include/flux2mi.h, "MLX-compatible random stream")."""
+
+    def __init__(self, ctx: "Context", seed: int = 0):
+        self.ctx = ctx
+        self.state = (C.c_uint32 * 2)()
+        self.seed(seed)
+
+    def seed(self, seed: int):
+        lib().flux2mi_mlx_random_key(C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), self.state)
+
+    def next_key(self):
+        first, second = (C.c_uint32 * 2)(), (C.c_uint32 * 2)()
+        lib().flux2mi_mlx_random_split(self.state, first, second)
+        self.state = first
+        return second
+
+    def _draw(self, shape, fn, dtype=torch.float32, *extra):
+        out = torch.empty(tuple(shape), dtype=dtype, device=self.ctx.device)
+        key = self.next_key()
+        self.ctx._enter()
+        check(fn(self.ctx.handle, key, _ptr(out), out.numel(), *extra))
+        self.ctx._exit()
+        return out
+
+    def bits(self, shape) -> torch.Tensor:
+        """uint32 words, returned as int32 bit patterns (torch has no uint32 arithmetic)."""
+        return self._draw(shape, lib().flux2mi_mlx_random_bits, torch.int32)
+
+    def uniform(self, shape, low: float = 0.0, high: float = 1.0) -> torch.Tensor:
+        return self._draw(shape, lib().flux2mi_mlx_random_uniform, torch.float32, float(low), float(high))
+
+    def normal(self, shape) -> torch.Tensor:
+        return self._draw(shape, lib().flux2mi_mlx_random_normal)
+
+
 class DiT:
     """Flux2Transformer2DModel (flux2mi_dit)."""
 

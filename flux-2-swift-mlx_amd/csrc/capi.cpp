@@ -263,6 +263,53 @@ extern "C" int flux2mi_reference_position_ids(const int* latent_heights, const i
     return FLUX2MI_OK;
 }
 
+// ------------------------------------------------------------------ MLX-compatible random stream
+// (MLXRandom.seed / MLXRandom.normal as the reference calls them: LatentUtils.swift:32-41, Flux2Pipeline.swift:1203).
+// Key bookkeeping is a handful of integer hashes and stays on the host; the draws run on the device.
+namespace {
+void host_threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1) {
+    static const int rot[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+    const uint32_t ks[3] = {k0, k1, 0x1BD11BDAu ^ k0 ^ k1};
+    x0 += ks[0];
+    x1 += ks[1];
+    for (int r = 0; r < 5; ++r) {
+        for (int q = 0; q < 4; ++q) {
+            x0 += x1;
+            x1 = (x1 << rot[r & 1][q]) | (x1 >> (32 - rot[r & 1][q]));
+            x1 ^= x0;
+        }
+        x0 += ks[(r + 1) % 3];
+        x1 += ks[(r + 2) % 3] + (uint32_t)(r + 1);
+    }
+}
+}  // namespace
+extern "C" void flux2mi_mlx_random_key(uint64_t seed, uint32_t key[2]) {
+    key[0] = (uint32_t)(seed >> 32);
+    key[1] = (uint32_t)(seed & 0xFFFFFFFFull);
+}
+extern "C" void flux2mi_mlx_random_split(const uint32_t key[2], uint32_t first[2], uint32_t second[2]) {
+    // bits([2,2]) with one key: words (0,2) from counter (0,2), words (1,3) from counter (1,3)
+    uint32_t a0 = 0, a1 = 2, b0 = 1, b1 = 3;
+    host_threefry2x32(key[0], key[1], a0, a1);
+    host_threefry2x32(key[0], key[1], b0, b1);
+    first[0] = a0, first[1] = b0, second[0] = a1, second[1] = b1;
+}
+extern "C" int flux2mi_mlx_random_bits(flux2mi_ctx* ctx, const uint32_t key[2], uint32_t* out, int64_t n) {
+    F2_REQUIRE(ctx && key && out && n > 0 && n <= 0xFFFFFFFFll, FLUX2MI_ERR_INVALID_ARG, "mlx_random_bits: bad args");
+    F2_LAUNCH(launch_mlx_random(ctx->stream, key[0], key[1], reinterpret_cast<float*>(out), n, 0, 0.f, 1.f), "mlx_random_bits");
+    return FLUX2MI_OK;
+}
+extern "C" int flux2mi_mlx_random_uniform(flux2mi_ctx* ctx, const uint32_t key[2], float* out, int64_t n, float lo, float hi) {
+    F2_REQUIRE(ctx && key && out && n > 0 && n <= 0xFFFFFFFFll && hi > lo, FLUX2MI_ERR_INVALID_ARG, "mlx_random_uniform: bad args");
+    F2_LAUNCH(launch_mlx_random(ctx->stream, key[0], key[1], out, n, 1, lo, hi), "mlx_random_uniform");
+    return FLUX2MI_OK;
+}
+extern "C" int flux2mi_mlx_random_normal(flux2mi_ctx* ctx, const uint32_t key[2], float* out, int64_t n) {
+    F2_REQUIRE(ctx && key && out && n > 0 && n <= 0xFFFFFFFFll, FLUX2MI_ERR_INVALID_ARG, "mlx_random_normal: bad args");
+    F2_LAUNCH(launch_mlx_random(ctx->stream, key[0], key[1], out, n, 2, -0.99999994f, 1.f), "mlx_random_normal");
+    return FLUX2MI_OK;
+}
+
 // ------------------------------------------------------------------ elementwise device ops
 extern "C" int flux2mi_sched_step(flux2mi_ctx* ctx, float* x, const float* v, float dt, int64_t n) {
     F2_REQUIRE(ctx && x && v && n > 0, FLUX2MI_ERR_INVALID_ARG, "sched_step: bad args");

@@ -84,6 +84,76 @@ __global__ void swiglu_interleave_kernel(const uint16_t* __restrict__ in, uint16
     for (int c = threadIdx.x; c < K / 8; c += blockDim.x) d[c] = s[c];
 }
 
+// ---- MLX-compatible random stream (MLXRandom.seed + MLXRandom.normal, LatentUtils.swift:32-41).  The generator is
+// MLX's: Threefry-2x32 (20 rounds) keyed by a uint32 pair; word i and word half+i of a draw are the two outputs of
+// the counter (i, half+i), an odd count takes its middle word from counter (half, 0).  HBM-bound: 4 B written per
+// element, ~100 integer ops — one counter per thread, grid-stride.
+__device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1) {
+    const uint32_t ks[3] = {k0, k1, 0x1BD11BDAu ^ k0 ^ k1};
+    x0 += ks[0];
+    x1 += ks[1];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rot = (r & 1) ? (q == 0 ? 17 : q == 1 ? 29 : q == 2 ? 16 : 24) : (q == 0 ? 13 : q == 1 ? 15 : q == 2 ? 26 : 6);
+            x0 += x1;
+            x1 = (x1 << rot) | (x1 >> (32 - rot));
+            x1 ^= x0;
+        }
+        x0 += ks[(r + 1) % 3];
+        x1 += ks[(r + 2) % 3] + (uint32_t)(r + 1);
+    }
+}
+// mode 0: raw words (uint32 bit pattern), 1: uniform [lo, hi), 2: standard normal
+__device__ __forceinline__ float mlx_transform(uint32_t w, int mode, float lo, float range) {
+    if (mode == 0) return __uint_as_float(w);
+    float u = __fdiv_rn((float)w, 4294967296.0f);
+    u = fminf(u, 0.99999994f);
+    u = __fadd_rn(__fmul_rn(range, u), lo);  // multiply, then add: two roundings as two MLX ops
+    if (mode == 1) return u;
+    // erfinv, single-precision polynomial pair in t = log(1 - u^2)
+    float t = logf(fmaf(u, -u, 1.0f));
+    float p;
+    if (fabsf(t) > 6.125f) {
+        p = 3.03697567e-10f;
+        p = fmaf(p, t, 2.93243101e-8f);
+        p = fmaf(p, t, 1.22150334e-6f);
+        p = fmaf(p, t, 2.84108955e-5f);
+        p = fmaf(p, t, 3.93552968e-4f);
+        p = fmaf(p, t, 3.02698812e-3f);
+        p = fmaf(p, t, 4.83185798e-3f);
+        p = fmaf(p, t, -2.64646143e-1f);
+        p = fmaf(p, t, 8.40016484e-1f);
+    } else {
+        p = 5.43877832e-9f;
+        p = fmaf(p, t, 1.43285448e-7f);
+        p = fmaf(p, t, 1.22774793e-6f);
+        p = fmaf(p, t, 1.12963626e-7f);
+        p = fmaf(p, t, -5.61530760e-5f);
+        p = fmaf(p, t, -1.47697632e-4f);
+        p = fmaf(p, t, 2.31468678e-3f);
+        p = fmaf(p, t, 1.15392581e-2f);
+        p = fmaf(p, t, -2.32015476e-1f);
+        p = fmaf(p, t, 8.86226892e-1f);
+    }
+    return 1.41421356f * (u * p);
+}
+__global__ void mlx_random_kernel(uint32_t k0, uint32_t k1, float* __restrict__ out, int64_t n, int mode, float lo, float range) {
+    const int64_t half = n >> 1;
+    const int64_t odd = n & 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half + odd; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t x0 = (uint32_t)i, x1 = (i < half) ? (uint32_t)(i + half + odd) : 0u;
+        threefry2x32(k0, k1, x0, x1);
+        if (i < half) {
+            out[i] = mlx_transform(x0, mode, lo, range);
+            out[i + half + odd] = mlx_transform(x1, mode, lo, range);
+        } else {
+            out[half] = mlx_transform(x0, mode, lo, range);
+        }
+    }
+}
+
 __global__ void bf16_add_kernel(uint16_t* __restrict__ w, const uint16_t* __restrict__ dl, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
@@ -231,6 +301,12 @@ int launch_embed_rows(hipStream_t stream, const int32_t* ids, const uint16_t* ta
 int launch_f32_rows_to_bf16_cols(hipStream_t stream, const float* hs, uint16_t* out, int S, int dim, int ldo, int c0) {
     if (S <= 0 || dim <= 0 || ldo < c0 + dim) return 1;
     hipLaunchKernelGGL(f32_rows_to_bf16_cols_kernel, dim3(S), dim3(256), 0, stream, hs, out, dim, ldo, c0);
+    EW_DONE();
+}
+int launch_mlx_random(hipStream_t stream, uint32_t k0, uint32_t k1, float* out, int64_t n, int mode, float lo, float hi) {
+    if (n <= 0 || n > 0xFFFFFFFFll || mode < 0 || mode > 2) return 1;
+    const float range = hi - lo;
+    hipLaunchKernelGGL(mlx_random_kernel, dim3(ew_grid((n + 1) / 2)), dim3(EW_BLOCK), 0, stream, k0, k1, out, n, mode, lo, range);
     EW_DONE();
 }
 int launch_bf16_add_inplace(hipStream_t stream, uint16_t* w, const uint16_t* delta, int64_t n) {

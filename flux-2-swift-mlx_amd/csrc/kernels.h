@@ -118,6 +118,8 @@ int launch_convert_to_f32(hipStream_t stream, const void* in, int dtype, float* 
 // out rows permuted: out[r,:] = in[perm(r),:], SwiGLU interleave of a [2h,K] matrix (see gemm.hip)
 int launch_swiglu_interleave_rows(hipStream_t stream, const uint16_t* in, uint16_t* out, int hidden, int K);
 // w[i] = bf16(f32(w[i]) + f32(delta[i]))  (LoRA merge, WeightLoader.swift:823-838)
+// MLX random stream (Threefry-2x32): mode 0 raw words, 1 uniform [lo,hi), 2 standard normal
+int launch_mlx_random(hipStream_t stream, uint32_t k0, uint32_t k1, float* out, int64_t n, int mode, float lo, float hi);
 int launch_bf16_add_inplace(hipStream_t stream, uint16_t* w, const uint16_t* delta, int64_t n);
 // quanto qint8: out_bf16[r, c] = bf16(f32(data[r, c]) * scale[r])  (WeightLoader.swift:347-363)
 int launch_dequant_i8_rows(hipStream_t stream, const int8_t* data, const float* scale, uint16_t* out, int rows, int cols);

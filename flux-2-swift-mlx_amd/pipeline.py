@@ -8,9 +8,10 @@ reference's argument names onto the C ABI so that tests read like the reference'
 What is an explicit input here and implicit in the reference:
   * text embeddings (`precomputed_embeddings`, bf16 [1,S_txt,J]) — the text encoders
     are outside the path (SURVEY §8f rank 1);
-  * noise — the reference draws MLX threefry noise from `seed`; here `noise`
-    ([1,128,H/16,W/16] f32) is explicit, or drawn with torch's Philox generator from
-    `seed` (NOT MLX-compatible; documented in DESIGN.md).
+  * noise — `noise` ([1,128,H/16,W/16] f32) may be passed explicitly; otherwise it is drawn as the
+    reference draws it, `MLXRandom.seed(seed)` + `MLXRandom.normal` (MLX's Threefry stream restated in
+    csrc/elementwise.hip; `self.random` carries the key state on for later draws such as the RePaint
+    blend noise).
 """
 from __future__ import annotations
 
@@ -25,7 +26,7 @@ import torch
 
 from . import _lib as L
 from ._lib import Flux2Error, check, lib
-from .api import Context, DiT, VAE, resolve_chain_dimensions, validate_dimensions
+from .api import Context, DiT, MLXRandom, VAE, resolve_chain_dimensions, validate_dimensions
 
 
 @dataclass
@@ -74,6 +75,7 @@ class Flux2Pipeline:
         self.transformer: Optional[DiT] = None
         self.vae: Optional[VAE] = None
         self.text_encoder = None   # flux2mi.textenc.TextEncoder (Klein: Qwen3), optional
+        self.random = MLXRandom(self.ctx)  # the reference's global MLXRandom state
 
     # loadModels(progressCallback:) — weights are handed over as tensors by key, or as .safetensors
     # paths (a str, or a list of shard paths) read by the native loader
@@ -202,9 +204,10 @@ class Flux2Pipeline:
         s_img = (H // 16) * (W // 16)
         txt = precomputed_embeddings.to(device=dev, dtype=torch.bfloat16).reshape(-1, precomputed_embeddings.shape[-1]).contiguous()
         if noise is None:
-            g = torch.Generator(device=dev)
-            g.manual_seed(0 if seed is None else int(seed))
-            noise = torch.randn((1, 128, H // 16, W // 16), generator=g, device=dev, dtype=torch.float32)
+            # Flux2Pipeline.swift:1203-1204 + LatentUtils.generatePatchifiedLatents (:32-41): seed, then one normal draw
+            if seed is not None:
+                self.random.seed(seed)
+            noise = self.random.normal((1, 128, H // 16, W // 16))
         noise = noise.to(device=dev, dtype=torch.float32).contiguous()
         if tuple(noise.shape[-3:]) != (128, H // 16, W // 16):
             raise Flux2Error(L.ERR_SHAPE, f"noise shape {tuple(noise.shape)} != [1,128,{H // 16},{W // 16}]")
@@ -346,15 +349,17 @@ def _tensor_from_ptr(ptr: int, shape, device) -> torch.Tensor:
 class Flux2MaskedInpaintingChain:
     """RePaint inpainting chain (Flux2Chains/Flux2MaskedInpaintingChain.swift:300-431) on
     already-encoded inputs: image latents [1,S,128] (VAE-encoded, BN-normalised, packed),
-    mask [1,S,1] (1 = inpaint), blend noise [1,S,128] drawn once."""
+    mask [1,S,1] (1 = inpaint), blend noise [1,S,128] drawn once — passed in, or drawn at `run` the way
+    the reference draws it (:380-385: `MLXRandom.seed(seed)` then `MLXRandom.normal(imageLatents.shape)`,
+    before the pipeline re-seeds for the initial noise)."""
 
     def __init__(self, pipeline: Flux2Pipeline, image_latents: torch.Tensor, mask_latents: torch.Tensor,
-                 blend_noise: torch.Tensor):
+                 blend_noise: Optional[torch.Tensor] = None):
         self.pipeline = pipeline
         dev = pipeline.ctx.device
         self.image_latents = image_latents.to(dev, torch.float32).contiguous()
         self.mask_latents = mask_latents.to(dev, torch.float32).contiguous()
-        self.blend_noise = blend_noise.to(dev, torch.float32).contiguous()
+        self.blend_noise = None if blend_noise is None else blend_noise.to(dev, torch.float32).contiguous()
 
     def on_step(self, ctx: Flux2StepContext, latents: torch.Tensor) -> torch.Tensor:
         """:399-403 — orig = (1-s')*img + s'*noise ; x = (1-m)*orig + m*x, one fused kernel, in place."""
@@ -366,6 +371,10 @@ class Flux2MaskedInpaintingChain:
 
     def run(self, precomputed_embeddings, height: int, width: int, steps: int, guidance: float = 4.0,
             strength: float = 1.0, noise=None, seed=None, **kw) -> Flux2GenerationResult:
+        if self.blend_noise is None:
+            if seed is not None:
+                self.pipeline.random.seed(seed)
+            self.blend_noise = self.pipeline.random.normal(tuple(self.image_latents.shape))
         return self.pipeline.generate_with_result(
             "textToImage", height=height, width=width, steps=steps, guidance=guidance, seed=seed, noise=noise,
             precomputed_embeddings=precomputed_embeddings,

@@ -89,6 +89,16 @@ int flux2mi_sched_step(flux2mi_ctx* ctx, float* x, const float* v, float dt, int
 /* FlowMatchEulerScheduler.scaleNoise (:195-204): out = (1-sigma)*sample + sigma*noise. */
 int flux2mi_scale_noise(flux2mi_ctx* ctx, float* out, const float* sample, const float* noise,
                         float sigma, int64_t n);
+/* ---- MLX-compatible random stream.  The reference draws its noise with `MLXRandom.seed(seed)` +
+ * `MLXRandom.normal(shape)` (LatentUtils.swift:32-41, Flux2Pipeline.swift:1203-1204, 2313, 2403): Threefry-2x32
+ * keyed by {seed>>32, seed&0xffffffff}; every keyless draw first splits the global key (state, sub) = split(state)
+ * and draws with `sub`.  Key bookkeeping is host integer work; draws are device kernels on the context's stream.
+ * n <= 2^32-1 elements per draw. */
+void flux2mi_mlx_random_key(uint64_t seed, uint32_t key[2]);
+void flux2mi_mlx_random_split(const uint32_t key[2], uint32_t first[2], uint32_t second[2]);
+int flux2mi_mlx_random_bits(flux2mi_ctx* ctx, const uint32_t key[2], uint32_t* out, int64_t n);
+int flux2mi_mlx_random_uniform(flux2mi_ctx* ctx, const uint32_t key[2], float* out, int64_t n, float lo, float hi);
+int flux2mi_mlx_random_normal(flux2mi_ctx* ctx, const uint32_t key[2], float* out, int64_t n);
 /* classical CFG, Flux2Pipeline.swift:1955-1973: v = v_uncond + g*(v_cond - v_uncond), in place on v_cond. */
 int flux2mi_cfg_combine(flux2mi_ctx* ctx, float* v_cond, const float* v_uncond, float guidance, int64_t n);
 /* RePaint hook body, Flux2Chains/Flux2MaskedInpaintingChain.swift:399-403:
