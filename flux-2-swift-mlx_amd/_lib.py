@@ -21,6 +21,7 @@ class Flux2Error(RuntimeError):
         self.message = message
 
 
+MASK_GRAYSCALE_WHITE_INPAINT, MASK_ALPHA_TRANSPARENT_INPAINT = 0, 1  # Flux2MaskConvention
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_NOT_LOADED, ERR_SHAPE, ERR_CANCELLED, ERR_UNSUPPORTED, ERR_OOM = range(8)
 F32, BF16, F16 = 0, 1, 2
 
@@ -92,6 +93,14 @@ PROTOTYPES = {
     "flux2mi_scale_noise": (_I, [_P, _P, _P, _P, _F, _I64]),
     "flux2mi_cfg_combine": (_I, [_P, _P, _P, _F, _I64]),
     "flux2mi_repaint_blend": (_I, [_P, _P, _P, _P, _P, _F, _I, _I]),
+    "flux2mi_image_resample_u8": (_I, [_P, _P, _I, _I, _I, C.POINTER(_F), _P, _I, _I]),
+    "flux2mi_mask_inpaint_weights": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(_F), _P, _I, _I]),
+    "flux2mi_mask_bounding_box": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _PI, _PI]),
+    "flux2mi_expand_crop_region": (None, [_PI, _I, _I, _I, _PI]),
+    "flux2mi_composite_u8": (_I, [_P, _P, _I, _I, _I, _P, _I, _PI, _P]),
+    "flux2mi_preprocess_image_for_vae": (_I, [_P, _P, _I, _I, _I, _P]),
+    "flux2mi_outpaint_canvas": (_I, [_P, _P, _I, _I, _I, _P, _I, _I, _I, _I, C.c_uint64]),
+    "flux2mi_outpaint_smart_mask": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I]),
     "flux2mi_mlx_random_key": (None, [C.c_uint64, C.POINTER(C.c_uint32)]),
     "flux2mi_mlx_random_split": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "flux2mi_mlx_random_bits": (_I, [_P, C.POINTER(C.c_uint32), _P, _I64]),

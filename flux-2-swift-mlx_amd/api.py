@@ -152,6 +152,101 @@ class Context:
                                           sigma_next, seq, c))
         self._exit()
 
+    # ---- pixel-space pre/post-processing of the chains (u8 [H,W,C] device tensors; csrc/imaging.hip)
+    def _u8(self, image) -> torch.Tensor:
+        t = torch.as_tensor(image)
+        if t.dtype != torch.uint8:
+            raise Flux2Error(L.ERR_INVALID_ARG, f"expected a uint8 image, got {t.dtype}")
+        if t.dim() == 2:
+            t = t.unsqueeze(-1)
+        return t.to(self.device).contiguous()
+
+    @staticmethod
+    def _box(box):
+        return None if box is None else (C.c_float * 4)(*[float(v) for v in box])
+
+    def image_resample_u8(self, image, out_h: int, out_w: int, box=None) -> torch.Tensor:
+        """`CGContext.draw(image, in:)` of renderRGBA (Flux2InpaintCompositing.swift:166-182) with the library's
+        documented filter; box = (x0, y0, x1, y1) source rectangle."""
+        src = self._u8(image)
+        h, w, c = src.shape
+        out = torch.empty((out_h, out_w, c), dtype=torch.uint8, device=self.device)
+        self._enter()
+        check(lib().flux2mi_image_resample_u8(self.handle, _ptr(src), h, w, c, self._box(box), _ptr(out), out_h, out_w))
+        self._exit()
+        return out
+
+    def mask_inpaint_weights(self, mask, out_h: int, out_w: int, convention: int = 0, box=None) -> torch.Tensor:
+        """renderInpaintWeights (:196-227) -> f32 [out_h, out_w], 1 = inpaint."""
+        src = self._u8(mask)
+        h, w, c = src.shape
+        out = torch.empty((out_h, out_w), dtype=torch.float32, device=self.device)
+        self._enter()
+        check(lib().flux2mi_mask_inpaint_weights(self.handle, _ptr(src), h, w, c, convention, self._box(box), _ptr(out), out_h, out_w))
+        self._exit()
+        return out
+
+    def mask_bounding_box(self, mask, convention: int, image_width: int, image_height: int, threshold: float = 8.0 / 255.0):
+        """maskBoundingBox (:23-65) -> (x, y, w, h) or None."""
+        src = self._u8(mask)
+        h, w, c = src.shape
+        rect, found = (C.c_int * 4)(), C.c_int(0)
+        self._enter()
+        check(lib().flux2mi_mask_bounding_box(self.handle, _ptr(src), h, w, c, convention, image_width, image_height, threshold,
+                                              rect, C.byref(found)))
+        self._exit()
+        return tuple(rect) if found.value else None
+
+    @staticmethod
+    def expand_crop_region(bbox, padding: int, image_width: int, image_height: int):
+        """expandCropRegion (:69-108) -> (x, y, w, h)."""
+        out = (C.c_int * 4)()
+        lib().flux2mi_expand_crop_region((C.c_int * 4)(*[int(v) for v in bbox]), int(padding), image_width, image_height, out)
+        return tuple(out)
+
+    def composite_u8(self, base, generated, crop_rect, weights) -> torch.Tensor:
+        """composite (:112-162); returns the composited copy of `base` (u8 [H,W,3|4])."""
+        b = self._u8(base).clone()
+        g = self._u8(generated)
+        wt = weights.to(self.device, torch.float32).contiguous()
+        cx, cy, cw, ch = [int(v) for v in crop_rect]
+        if tuple(g.shape[:2]) != (ch, cw) or wt.numel() != cw * ch:
+            raise Flux2Error(L.ERR_SHAPE, f"generated {tuple(g.shape)} / weights {tuple(wt.shape)} do not match the crop {cw}x{ch}")
+        self._enter()
+        check(lib().flux2mi_composite_u8(self.handle, _ptr(b), b.shape[0], b.shape[1], b.shape[2], _ptr(g), g.shape[2],
+                                         (C.c_int * 4)(cx, cy, cw, ch), _ptr(wt)))
+        self._exit()
+        return b
+
+    def preprocess_image_for_vae(self, image) -> torch.Tensor:
+        """preprocessImageForVAE (Flux2Pipeline.swift:2359-2418): u8 [H,W,3|4] -> f32 [1,3,H,W] in [-1,1]."""
+        src = self._u8(image)
+        h, w, c = src.shape
+        out = torch.empty((1, 3, h, w), dtype=torch.float32, device=self.device)
+        self._enter()
+        check(lib().flux2mi_preprocess_image_for_vae(self.handle, _ptr(src), h, w, c, _ptr(out)))
+        self._exit()
+        return out
+
+    def outpaint_canvas(self, source, canvas_h: int, canvas_w: int, offset_x: int, offset_y: int, noise_seed: int) -> torch.Tensor:
+        """Flux2OutpaintingChain.buildOutpaintCanvas (:331-395) -> u8 [canvas_h, canvas_w, 3]."""
+        src = self._u8(source)
+        out = torch.empty((canvas_h, canvas_w, 3), dtype=torch.uint8, device=self.device)
+        self._enter()
+        check(lib().flux2mi_outpaint_canvas(self.handle, _ptr(src), src.shape[0], src.shape[1], src.shape[2], _ptr(out), canvas_h, canvas_w,
+                                            offset_x, offset_y, C.c_uint64(int(noise_seed) & 0xFFFFFFFFFFFFFFFF)))
+        self._exit()
+        return out
+
+    def outpaint_smart_mask(self, canvas_h: int, canvas_w: int, keep_x: int, keep_y: int, keep_w: int, keep_h: int,
+                            transition_pixels: int) -> torch.Tensor:
+        """Flux2OutpaintingChain.buildSmartMask (:397-474) -> u8 [canvas_h, canvas_w]."""
+        out = torch.empty((canvas_h, canvas_w), dtype=torch.uint8, device=self.device)
+        self._enter()
+        check(lib().flux2mi_outpaint_smart_mask(self.handle, _ptr(out), canvas_h, canvas_w, keep_x, keep_y, keep_w, keep_h, transition_pixels))
+        self._exit()
+        return out
+
     def pack_patchified_to_sequence(self, p: torch.Tensor) -> torch.Tensor:
         _, c, h, w = p.shape
         out = torch.empty((1, h * w, c), dtype=torch.float32, device=p.device)

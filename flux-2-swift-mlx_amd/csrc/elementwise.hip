@@ -107,10 +107,13 @@ __device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t&
 }
 // mode 0: raw words (uint32 bit pattern), 1: uniform [lo, hi), 2: standard normal
 __device__ __forceinline__ float mlx_transform(uint32_t w, int mode, float lo, float range) {
+#pragma clang fp contract(off)  // multiply and add are two MLX ops with two roundings (plain operators: the __fmul_rn /
+    // __fadd_rn header inlines still get fused); the explicit fmaf calls below stay fused
     if (mode == 0) return __uint_as_float(w);
-    float u = __fdiv_rn((float)w, 4294967296.0f);
+    float u = (float)w * 2.3283064365386963e-10f;  // / 2^32, exact
     u = fminf(u, 0.99999994f);
-    u = __fadd_rn(__fmul_rn(range, u), lo);  // multiply, then add: two roundings as two MLX ops
+    const float ru = range * u;
+    u = ru + lo;  // multiply, then add: two roundings as two MLX ops
     if (mode == 1) return u;
     // erfinv, single-precision polynomial pair in t = log(1 - u^2)
     float t = logf(fmaf(u, -u, 1.0f));

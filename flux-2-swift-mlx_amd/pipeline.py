@@ -298,33 +298,64 @@ class Flux2Pipeline:
     # ---- chain helpers (Flux2Pipeline+ChainHelpers.swift) ------------------------
     resolveChainDimensions = staticmethod(resolve_chain_dimensions)
 
-    @staticmethod
-    def pack_mask_for_latent_blending(mask_hw: torch.Tensor, target_height: int, target_width: int) -> torch.Tensor:
-        """[H,W] in [0,1], 1 = inpaint -> [1,(H/16)(W/16),1] (+ChainHelpers.swift:148-236).  The reference
-        rasterises with CoreGraphics `.high` interpolation into 8 bits; this uses an exact area
-        average rounded to 8 bits (host-side pre-processing, not a hot-path kernel)."""
-        m = mask_hw.float().reshape(1, 1, *mask_hw.shape)
-        m = torch.nn.functional.adaptive_avg_pool2d(m, (target_height // 16, target_width // 16))
-        return (torch.round(m * 255.0) / 255.0).reshape(1, -1, 1)
+    def pack_mask_for_latent_blending(self, mask, target_height: int, target_width: int,
+                                      convention: int = L.MASK_GRAYSCALE_WHITE_INPAINT, box=None) -> torch.Tensor:
+        """`Flux2Pipeline.packMaskForLatentBlending` (+ChainHelpers.swift:148-236): mask u8 [H,W] (grayscale,
+        white = inpaint) or u8 [H,W,4] with `MASK_ALPHA_TRANSPARENT_INPAINT` -> f32 [1,(H/16)(W/16),1], 1 = inpaint,
+        rendered to the latent grid in 8 bits.  A float [H,W] mask in [0,1] is quantised to 8 bits first.  The
+        reference rasterises with CoreGraphics; see include/flux2mi.h for the filter used here."""
+        m = torch.as_tensor(mask)
+        if m.dtype != torch.uint8:
+            m = torch.round(m.float().clamp(0, 1) * 255.0).to(torch.uint8)
+        w = self.ctx.mask_inpaint_weights(m, target_height // 16, target_width // 16, convention, box)
+        return w.reshape(1, -1, 1)
 
     def encode_image_to_packed_sequence(self, image, target_height: Optional[int] = None,
                                         target_width: Optional[int] = None) -> torch.Tensor:
         """`encodeImageToPackedSequence(_:targetHeight:targetWidth:samplePosterior: false)`
-        (+ChainHelpers.swift:75-103).  `image`: u8 [H,W,3] (numpy or tensor) or f32 [1,3,H,W] already in
-        [-1,1].  The reference resizes with CoreGraphics first; here the image must already have the
-        target size (resampling is host-side pre-processing outside the hot path)."""
+        (+ChainHelpers.swift:75-103).  `image`: u8 [H,W,3|4] (numpy or tensor), resampled to the target size on the
+        device when it differs (the reference draws it into a target-sized CGContext), or f32 [1,3,H,W] already in
+        [-1,1] at the target size."""
         if self.vae is None:
             raise Flux2Error(L.ERR_NOT_LOADED, "VAE not loaded")
         dev = self.ctx.device
         x = torch.as_tensor(image)
         if x.dtype == torch.uint8:
-            x = (x.to(dev).float() / 127.5 - 1.0).permute(2, 0, 1).unsqueeze(0).contiguous()   # Flux2Pipeline.swift:2408-2418
+            H, W = x.shape[0], x.shape[1]
+            th, tw = target_height or H, target_width or W
+            if (th, tw) != (H, W):
+                x = self.ctx.image_resample_u8(x, th, tw)
+            x = self.ctx.preprocess_image_for_vae(x)   # Flux2Pipeline.swift:2359-2418
         else:
             x = x.to(dev, torch.float32).reshape(1, 3, x.shape[-2], x.shape[-1]).contiguous()
-        H, W = x.shape[-2], x.shape[-1]
-        if (target_height not in (None, H)) or (target_width not in (None, W)):
-            raise Flux2Error(L.ERR_SHAPE, f"image is {H}x{W}, target {target_height}x{target_width}: resize it first")
+            H, W = x.shape[-2], x.shape[-1]
+            if (target_height not in (None, H)) or (target_width not in (None, W)):
+                raise Flux2Error(L.ERR_SHAPE, f"image is {H}x{W}, target {target_height}x{target_width}: pass the u8 image to have it resized")
         return self.vae.encode_to_packed(x)
+
+    def encode_reference_images(self, images, max_reference_pixels: int = 1024 * 1024):
+        """`encodeReferenceImages` (Flux2Pipeline.swift:2143-2260): each u8 [H,W,3] image is scaled down to at most
+        `max_reference_pixels`, floored to multiples of 32, VAE-encoded (posterior mean), patchified, BN-normalised and
+        packed; the sequences are concatenated and get position ids with T = 10, 20, ... per image.
+        -> (latents f32 [1,S_ref,128], ids i32 [S_ref,4])."""
+        import math
+        from .api import reference_position_ids
+        if not images:
+            raise Flux2Error(L.ERR_INVALID_ARG, "No reference images provided")
+        max_area = max(int(max_reference_pixels), 32 * 32)
+        packed, lh, lw = [], [], []
+        for img in images:
+            img = self.ctx._u8(img)
+            th, tw = img.shape[0], img.shape[1]
+            if tw * th > max_area:
+                scale = math.sqrt(max_area / float(tw * th))
+                tw, th = int(tw * scale), int(th * scale)
+            tw, th = max((tw // 32) * 32, 32), max((th // 32) * 32, 32)
+            packed.append(self.encode_image_to_packed_sequence(img, th, tw).reshape(-1, 128))
+            lh.append(th // 16)
+            lw.append(tw // 16)
+        ids = torch.from_numpy(reference_position_ids(lh, lw)).to(self.ctx.device)
+        return torch.cat(packed, 0).unsqueeze(0), ids
 
     def clearAll(self):
         if self.transformer:
@@ -344,6 +375,45 @@ def _tensor_from_ptr(ptr: int, shape, device) -> torch.Tensor:
     h = _Holder()
     h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
     return torch.as_tensor(h, device=device).view(*shape)
+
+
+class Flux2InpaintCompositing:
+    """Crop-and-stitch + pixel composite helpers (Flux2Chains/Flux2InpaintCompositing.swift), on the device.
+    Rects are (x, y, w, h) in image space, top-left origin."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+
+    def maskBoundingBox(self, mask, convention: int, imageWidth: int, imageHeight: int, threshold: float = 8.0 / 255.0):
+        return self.ctx.mask_bounding_box(mask, convention, imageWidth, imageHeight, threshold)
+
+    @staticmethod
+    def expandCropRegion(bbox, padding: int, imageWidth: int, imageHeight: int):
+        return Context.expand_crop_region(bbox, padding, imageWidth, imageHeight)
+
+    def renderInpaintWeights(self, mask, width: int, height: int, convention: int):
+        return self.ctx.mask_inpaint_weights(mask, height, width, convention)
+
+    def composite(self, original, generated, cropRect, maskCrop, convention: int):
+        """:112-162 — None when the crop leaves the image, like the reference."""
+        o = torch.as_tensor(original)
+        cx, cy, cw, ch = [int(v) for v in cropRect]
+        if not (cw > 0 and ch > 0 and cx >= 0 and cy >= 0 and cx + cw <= o.shape[1] and cy + ch <= o.shape[0]):
+            return None
+        g = torch.as_tensor(generated)
+        if tuple(g.shape[:2]) != (ch, cw):
+            g = self.ctx.image_resample_u8(g, ch, cw)
+        weights = self.ctx.mask_inpaint_weights(maskCrop, ch, cw, convention)
+        return self.ctx.composite_u8(o, g, (cx, cy, cw, ch), weights)
+
+
+def _crop_integral(img: torch.Tensor, rect):
+    """`CGImage.cropping(to:)`: the rect is made integral (origin floored, far edge ceiled) and clipped."""
+    import math
+    x0, y0 = int(math.floor(rect[0])), int(math.floor(rect[1]))
+    x1, y1 = int(math.ceil(rect[0] + rect[2])), int(math.ceil(rect[1] + rect[3]))
+    x0, y0, x1, y1 = max(0, x0), max(0, y0), min(img.shape[1], x1), min(img.shape[0], y1)
+    return img[y0:y1, x0:x1]
 
 
 class Flux2MaskedInpaintingChain:
@@ -375,8 +445,96 @@ class Flux2MaskedInpaintingChain:
             if seed is not None:
                 self.pipeline.random.seed(seed)
             self.blend_noise = self.pipeline.random.normal(tuple(self.image_latents.shape))
+        mode = "imageToImage" if kw.get("reference_latents") is not None else "textToImage"   # :405-412
         return self.pipeline.generate_with_result(
-            "textToImage", height=height, width=width, steps=steps, guidance=guidance, seed=seed, noise=noise,
+            mode, height=height, width=width, steps=steps, guidance=guidance, seed=seed, noise=noise,
             precomputed_embeddings=precomputed_embeddings,
             init_latents=self.image_latents if strength < 1.0 else None, strength=strength,
             on_step=self.on_step, **kw)
+
+
+    @classmethod
+    def run_on_image(cls, pipeline: Flux2Pipeline, image, mask, precomputed_embeddings, steps: int, guidance: float = 4.0,
+                     strength: float = 1.0, seed=None, maskConvention: int = L.MASK_GRAYSCALE_WHITE_INPAINT,
+                     maskCropPadding: Optional[int] = None, maxPixels: int = 1024 * 1024, compositeOnOriginal: bool = False,
+                     referenceImages=None, useImageAsReference: bool = False, **kw) -> Flux2GenerationResult:
+        """The chain's `run()` from pixels (:300-431): optional crop-and-stitch around the mask, VAE-encode the (cropped)
+        source, rasterise the mask to the latent grid, draw the blend noise, denoise with the RePaint hook, and paste the
+        result back onto the untouched original with the soft mask as per-pixel alpha.
+        image: u8 [H,W,3]; mask: u8 [h,w] (grayscale) or [h,w,4] (alpha convention)."""
+        comp = Flux2InpaintCompositing(pipeline.ctx)
+        image = pipeline.ctx._u8(image)
+        mask_t = torch.as_tensor(mask)
+        mask_t = mask_t.to(pipeline.ctx.device).contiguous()
+        ih, iw = image.shape[0], image.shape[1]
+        mh, mw = mask_t.shape[0], mask_t.shape[1]
+        work_image, work_mask, crop_rect = image, mask_t, None
+        if maskCropPadding is not None:
+            bbox = comp.maskBoundingBox(mask_t, maskConvention, iw, ih)
+            if bbox is not None:
+                region = comp.expandCropRegion(bbox, maskCropPadding, iw, ih)
+                mask_region = (region[0] * mw / iw, region[1] * mh / ih, region[2] * mw / iw, region[3] * mh / ih)
+                ci, cm = _crop_integral(image, region), _crop_integral(mask_t, mask_region)
+                if ci.numel() and cm.numel():
+                    work_image, work_mask, crop_rect = ci.contiguous(), cm.contiguous(), region
+        target_h, target_w = resolve_chain_dimensions(work_image.shape[1], work_image.shape[0], maxPixels)
+        image_latents = pipeline.encode_image_to_packed_sequence(work_image, target_h, target_w)
+        mask_latents = pipeline.pack_mask_for_latent_blending(work_mask, target_h, target_w, maskConvention)
+        chain = cls(pipeline, image_latents, mask_latents)
+        refs = list(referenceImages) if referenceImages else ([work_image] if useImageAsReference else [])   # :405-412
+        if refs:
+            kw["reference_latents"], kw["reference_ids"] = pipeline.encode_reference_images(refs)
+        result = chain.run(precomputed_embeddings, target_h, target_w, steps, guidance=guidance, strength=strength, seed=seed, **kw)
+        if (crop_rect is not None or maskCropPadding is not None or compositeOnOriginal) and result.image is not None:
+            region = crop_rect if crop_rect is not None else (0, 0, iw, ih)
+            out = comp.composite(image, torch.as_tensor(result.image), region, work_mask, maskConvention)
+            if out is not None:
+                result.image = out.cpu().numpy()
+            elif crop_rect is not None:
+                raise Flux2Error(L.ERR_SHAPE, "Inpainting crop composite failed — cannot assemble the full-resolution output")
+        return result
+
+
+class Flux2OutpaintingChain:
+    """`Flux2OutpaintingChain` (Flux2Chains/Flux2OutpaintingChain.swift): extend the canvas by top/bottom/left/right
+    pixels (rounded UP to multiples of 32), fill the strips with seeded grey Gaussian noise, build the smart mask (white
+    strips, ramp inside the keep, black keep) and run the masked-inpainting chain on the canvas with the original image
+    as I2I reference."""
+
+    def __init__(self, pipeline: Flux2Pipeline, image, top: int = 0, bottom: int = 0, left: int = 0, right: int = 0,
+                 steps: int = 4, guidance: float = 1.0, seed: Optional[int] = None, transitionPixels: int = 32,
+                 maxPixels: int = 1024 * 1024):
+        self.pipeline, self.image = pipeline, image
+        self.top, self.bottom, self.left, self.right = top, bottom, left, right
+        self.steps, self.guidance, self.seed = steps, guidance, seed
+        self.transitionPixels, self.maxPixels = transitionPixels, maxPixels
+
+    @staticmethod
+    def roundUpToMultipleOf32(x: int) -> int:   # :324-326
+        return 0 if x == 0 else ((x + 31) // 32) * 32
+
+    def buildOutpaintCanvas(self, sourceImage, canvasWidth: int, canvasHeight: int, offsetX: int, offsetY: int, noiseSeed: int):
+        return self.pipeline.ctx.outpaint_canvas(sourceImage, canvasHeight, canvasWidth, offsetX, offsetY, noiseSeed)
+
+    def buildSmartMask(self, canvasWidth: int, canvasHeight: int, keepX: int, keepY: int, keepWidth: int, keepHeight: int,
+                       transitionPixels: int):
+        return self.pipeline.ctx.outpaint_smart_mask(canvasHeight, canvasWidth, keepX, keepY, keepWidth, keepHeight, transitionPixels)
+
+    def run(self, precomputed_embeddings, **kw) -> Flux2GenerationResult:
+        """:185-277."""
+        if min(self.top, self.bottom, self.left, self.right) < 0:
+            raise Flux2Error(L.ERR_INVALID_ARG, "Padding values must be non-negative")
+        if self.top + self.bottom + self.left + self.right <= 0:
+            raise Flux2Error(L.ERR_INVALID_ARG, "At least one side must have non-zero padding")
+        t, b, l, r = (self.roundUpToMultipleOf32(v) for v in (self.top, self.bottom, self.left, self.right))
+        image = self.pipeline.ctx._u8(self.image)
+        ih, iw = image.shape[0], image.shape[1]
+        canvas_w, canvas_h = iw + l + r, ih + t + b
+        if canvas_w % 32 or canvas_h % 32:
+            raise Flux2Error(L.ERR_INVALID_ARG, f"Canvas dimensions {canvas_w}x{canvas_h} are not multiples of 32 — the input "
+                             "image's own dimensions need to be padded by the caller, or supply paddings that compensate.")
+        canvas = self.buildOutpaintCanvas(image, canvas_w, canvas_h, l, t, self.seed or 0)
+        mask = self.buildSmartMask(canvas_w, canvas_h, l, t, iw, ih, self.transitionPixels)
+        return Flux2MaskedInpaintingChain.run_on_image(
+            self.pipeline, canvas, mask, precomputed_embeddings, steps=self.steps, guidance=self.guidance, seed=self.seed,
+            referenceImages=[image], maxPixels=max(self.maxPixels, canvas_w * canvas_h), **kw)

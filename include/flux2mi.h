@@ -89,6 +89,46 @@ int flux2mi_sched_step(flux2mi_ctx* ctx, float* x, const float* v, float dt, int
 /* FlowMatchEulerScheduler.scaleNoise (:195-204): out = (1-sigma)*sample + sigma*noise. */
 int flux2mi_scale_noise(flux2mi_ctx* ctx, float* out, const float* sample, const float* noise,
                         float sigma, int64_t n);
+/* ---- pixel-space pre/post-processing of the inpainting / outpainting chains (device buffers, u8 interleaved
+ * [H,W,C] images).  The reference resamples with CoreGraphics' closed `.high` filter; this library uses the
+ * antialiased triangle filter in Pillow's 8-bit fixed-point form (bit-exact against Pillow's
+ * Image.resize(BILINEAR, box=)), see DESIGN.md.  `box` = {x0, y0, x1, y1} source rectangle in pixels or NULL for
+ * the whole image.  These calls synchronise the context's stream (they upload small host tables). */
+enum { FLUX2MI_MASK_GRAYSCALE_WHITE_INPAINT = 0, FLUX2MI_MASK_ALPHA_TRANSPARENT_INPAINT = 1 }; /* Flux2MaskConvention */
+/* CGContext.draw(image, in: rect) of renderRGBA (Flux2InpaintCompositing.swift:166-182): channels 1..4, each
+ * filtered independently. */
+int flux2mi_image_resample_u8(flux2mi_ctx* ctx, const uint8_t* src, int src_h, int src_w, int channels, const float* box,
+                              uint8_t* dst, int dst_h, int dst_w);
+/* renderInpaintWeights (Flux2InpaintCompositing.swift:196-227) and, with out = (H/16, W/16),
+ * Flux2Pipeline.packMaskForLatentBlending (Flux2Pipeline+ChainHelpers.swift:148-236): mask rendered to out_h x out_w
+ * in 8 bits, then grayscale v/255 (white = inpaint) or 1 - alpha/255 (transparent = inpaint; RGBA mask).
+ * weights f32 [out_h*out_w]. */
+int flux2mi_mask_inpaint_weights(flux2mi_ctx* ctx, const uint8_t* mask, int mask_h, int mask_w, int channels, int convention,
+                                 const float* box, float* weights, int out_h, int out_w);
+/* maskBoundingBox (:23-65): scan at <= 512 px, weights > threshold (reference default 8/255), rect {x,y,w,h} in image
+ * space rounded outward by one scan pixel; *found = 0 for an empty mask. */
+int flux2mi_mask_bounding_box(flux2mi_ctx* ctx, const uint8_t* mask, int mask_h, int mask_w, int channels, int convention,
+                              int image_width, int image_height, float threshold, int out_rect[4], int* found);
+/* expandCropRegion (:69-108, diffusers get_crop_region): pad, grow to the image aspect, shift inside, clamp. Host. */
+void flux2mi_expand_crop_region(const int bbox[4], int padding, int image_width, int image_height, int out_rect[4]);
+/* composite (:112-162, diffusers apply_overlay): base [full_h,full_w,base_channels] in place; generated
+ * [crop_h,crop_w,gen_channels]; weights f32 [crop_h*crop_w] (1 = take the generated pixel).
+ * FLUX2MI_ERR_SHAPE when the crop rect leaves the image (the reference returns nil). */
+int flux2mi_composite_u8(flux2mi_ctx* ctx, uint8_t* base, int full_h, int full_w, int base_channels, const uint8_t* generated,
+                         int gen_channels, const int crop_rect[4], const float* weights);
+/* preprocessImageForVAE (Flux2Pipeline.swift:2359-2418): u8 [H,W,3|4] -> f32 [3,H,W] = x / 127.5 - 1. */
+int flux2mi_preprocess_image_for_vae(flux2mi_ctx* ctx, const uint8_t* image, int height, int width, int channels, float* out);
+
+/* Flux2OutpaintingChain.buildOutpaintCanvas (Flux2Chains/Flux2OutpaintingChain.swift:331-395): canvas u8
+ * [canvas_h,canvas_w,3] = grey Gaussian noise (mean 128, sigma 32, SplitMix64 + Box-Muller seeded by noise_seed)
+ * with the source [src_h,src_w,3|4] pasted at (offset_x, offset_y), top-left origin. */
+int flux2mi_outpaint_canvas(flux2mi_ctx* ctx, const uint8_t* source, int src_h, int src_w, int channels, uint8_t* canvas,
+                            int canvas_h, int canvas_w, int offset_x, int offset_y, uint64_t noise_seed);
+/* Flux2OutpaintingChain.buildSmartMask (:397-474): u8 [canvas_h,canvas_w], 255 in the strips, 0 deep in the keep
+ * rectangle, linear ramps of `transition_pixels` (capped at half the keep) inside the keep on the padded sides. */
+int flux2mi_outpaint_smart_mask(flux2mi_ctx* ctx, uint8_t* mask, int canvas_h, int canvas_w, int keep_x, int keep_y, int keep_w,
+                                int keep_h, int transition_pixels);
+
 /* ---- MLX-compatible random stream.  The reference draws its noise with `MLXRandom.seed(seed)` +
  * `MLXRandom.normal(shape)` (LatentUtils.swift:32-41, Flux2Pipeline.swift:1203-1204, 2313, 2403): Threefry-2x32
  * keyed by {seed>>32, seed&0xffffffff}; every keyless draw first splits the global key (state, sub) = split(state)

@@ -235,15 +235,13 @@ def denormalize_latents_bn(x: Tensor, mean: Tensor, var: Tensor, eps: float = 1e
 
 
 def pack_mask_for_latent_blending(mask_hw: Tensor, height: int, width: int) -> Tensor:
-    """Shape contract of Flux2Pipeline+ChainHelpers.swift:148-236: a [H,W] mask in
-    [0,1] (1 = regenerate) -> [1, (H/16)*(W/16), 1].  The reference rasterises with
-    CoreGraphics high-quality resampling into an 8-bit grey context and divides by
-    255 (not reproducible off-platform); the oracle uses an exact area average
-    rounded to 8 bits, documented in DESIGN.md."""
-    m = mask_hw.float().reshape(1, 1, mask_hw.shape[0], mask_hw.shape[1])
-    m = F.adaptive_avg_pool2d(m, (height // 16, width // 16))
-    m = torch.round(m * 255.0) / 255.0
-    return m.reshape(1, -1, 1)
+    """Flux2Pipeline+ChainHelpers.swift:148-236: a [H,W] mask in [0,1] (1 = regenerate) ->
+    [1, (H/16)*(W/16), 1], rendered to the latent grid in 8 bits.  The reference rasterises with
+    CoreGraphics (closed filter); the filter used instead is restated and pinned in
+    oracle/imaging_ref.py (`pack_mask_for_latent_blending`), which this delegates to."""
+    from . import imaging_ref
+    m8 = torch.round(mask_hw.float().clamp(0, 1) * 255.0).to(torch.uint8).numpy()
+    return torch.from_numpy(imaging_ref.pack_mask_for_latent_blending(m8, height, width))
 
 
 # ---------------------------------------------------------------------------

@@ -43,8 +43,9 @@ def test_uniform_exact(ctx):
     ks = M.KeySequence(99)
     got = r.uniform((100003,)).cpu().numpy()
     assert np.array_equal(got, ks.uniform((100003,)))  # divide, min, multiply, add: all correctly rounded
-    got = r.uniform((4096,), -3.0, 5.0).cpu().numpy()
-    assert np.array_equal(got, ks.uniform((4096,), -3.0, 5.0))
+    for lo, hi in [(-3.0, 5.0), (0.1, 0.7), (-1.3, 2.9)]:   # ranges that are not powers of two: multiply, THEN add
+        got = r.uniform((4096,), lo, hi).cpu().numpy()
+        assert np.array_equal(got, ks.uniform((4096,), lo, hi))
 
 
 @pytest.mark.parametrize("shape", [(1, 128, 64, 64), (1, 128, 16, 16), (1, 4096, 128), (1, 3, 33, 35)])
