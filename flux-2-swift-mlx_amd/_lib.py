@@ -93,6 +93,8 @@ PROTOTYPES = {
     "flux2mi_scale_noise": (_I, [_P, _P, _P, _P, _F, _I64]),
     "flux2mi_cfg_combine": (_I, [_P, _P, _P, _F, _I64]),
     "flux2mi_repaint_blend": (_I, [_P, _P, _P, _P, _P, _F, _I, _I]),
+    "flux2mi_dit_export_prequantized": (_I, [_P, C.c_char_p, C.c_char_p]),
+    "flux2mi_dit_load_prequantized": (_I, [_P, C.c_char_p, C.c_char_p, _PI]),
     "flux2mi_image_resample_u8": (_I, [_P, _P, _I, _I, _I, C.POINTER(_F), _P, _I, _I]),
     "flux2mi_mask_inpaint_weights": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(_F), _P, _I, _I]),
     "flux2mi_mask_bounding_box": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _PI, _PI]),

@@ -421,6 +421,24 @@ class DiT:
         self.ctx._exit()
         return n.value, k.value
 
+    def export_prequantized(self, path: str, source_fingerprint: str = ""):
+        """`Flux2PrequantizedCheckpoint.save`: the resident (finalized) weights in the library's own layout, written
+        atomically; see include/flux2mi.h."""
+        self.ctx._enter()
+        check(lib().flux2mi_dit_export_prequantized(self.handle, str(path).encode(), source_fingerprint.encode()))
+        self.ctx._exit()
+        return path
+
+    def load_prequantized(self, path: str, expected_fingerprint: Optional[str] = None) -> bool:
+        """`Flux2PrequantizedCheckpoint.load(into:)`: validates before touching the model (raises Flux2Error and leaves
+        the model as it was), finalizes on success.  Returns True when the export was taken with a LoRA merged in."""
+        baked = C.c_int(0)
+        fp = None if expected_fingerprint is None else expected_fingerprint.encode()
+        self.ctx._enter()
+        check(lib().flux2mi_dit_load_prequantized(self.handle, str(path).encode(), fp, C.byref(baked)))
+        self.ctx._exit()
+        return bool(baked.value)
+
     def set_tensor_q8(self, name: str, data: torch.Tensor, scale: torch.Tensor):
         """One quanto qint8 tensor: int8 [out,in] x f32 scale [out] (WeightLoader.swift:347-363)."""
         d = data.contiguous()

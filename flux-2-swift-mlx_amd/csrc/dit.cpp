@@ -14,15 +14,21 @@
 // f32 scale per output channel; their A operands are e4m3 too, quantised per token:
 //   xq    e4m3 [S, 4d] + xs f32 [S]   LN+modulate output / quantised comb rows
 // Embedders, modulation GEMVs and proj_out stay bf16.
+#include <errno.h>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <map>
 
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 #include "common.h"
+#include "loader.h"
 #include "kernels.h"
 
 namespace {
@@ -54,6 +60,7 @@ struct flux2mi_dit {
     std::vector<Buf> bufs;
     std::unordered_map<std::string, Slot> slots;
     bool finalized = false;
+    bool lora_merged = false;  // a LoRA was merged into the resident weights (tagged in pre-quantized exports)
     int64_t param_bytes = 0;
 
     // resolved weight pointers
@@ -420,6 +427,7 @@ extern "C" int flux2mi_dit_merge_lora(flux2mi_dit* m, const char* name, int dtyp
     const size_t off = (s.transform == T_DIRECT) ? (size_t)s.row_off * cols : 0;
     F2_LAUNCH(launch_bf16_add_inplace(st, b.ptr + off, m->stage_d.as<uint16_t>() + off, rows * cols), "lora merge");
     F2_CHECK_HIP(hipStreamSynchronize(st));
+    m->lora_merged = true;
     return FLUX2MI_OK;
 }
 
@@ -509,6 +517,155 @@ extern "C" int flux2mi_dit_finalize(flux2mi_dit* m) {
     m->stage_q8.release();
     m->finalized = true;
     return FLUX2MI_OK;
+}
+
+// ------------------------------------------------------------------ pre-quantized checkpoint
+// Flux2PrequantizedCheckpoint (Loading/PrequantizedCheckpoint.swift) + Flux2Pipeline.exportPrequantizedTransformer
+// (Pipeline/Flux2Pipeline.swift:759-840): the resident weights in the library's OWN layout and naming — e4m3 bytes +
+// per-row f32 scales for the block GEMMs, bf16 for the rest — so that a reload is a validated file -> HBM copy: no key
+// mapping, no layout transform, no quantise pass, about half the bytes.  The save is atomic (temp file + rename); the
+// load validates metadata, payload size, key set, dtypes and shapes BEFORE it touches the model.
+namespace {
+const char* const PREQ_FORMAT = "flux2mi-prequantized-v1";
+
+std::string json_escape(const char* s) {
+    std::string o;
+    for (const char* p = s ? s : ""; *p; ++p) {
+        if (*p == '"' || *p == '\\') { o += '\\'; o += *p; }
+        else if ((unsigned char)*p < 0x20) o += ' ';
+        else o += *p;
+    }
+    return o;
+}
+std::string cfg_string(const flux2mi_dit_config& c) {
+    char b[200];
+    snprintf(b, sizeof(b), "dim=%d,heads=%d,n_double=%d,n_single=%d,joint_dim=%d,guidance=%d", c.dim, c.heads, c.n_double, c.n_single,
+             c.joint_dim, c.guidance_embeds);
+    return b;
+}
+struct PreqEntry { std::string key, dtype; int rows, cols; const void* dev; size_t bytes; };
+std::vector<PreqEntry> preq_entries(const flux2mi_dit* m) {
+    std::vector<PreqEntry> v;
+    for (const Buf& b : m->bufs) {
+        if (b.fp8) {
+            v.push_back({b.label + ".weight", "F8_E4M3", b.rows, b.cols, b.q, (size_t)b.rows * b.cols});
+            v.push_back({b.label + ".scale", "F32", b.rows, 0, b.scale, (size_t)b.rows * 4});
+        } else {
+            v.push_back({b.label + ".weight", "BF16", b.rows, b.cols, b.ptr, (size_t)b.rows * b.cols * 2});
+        }
+    }
+    return v;
+}
+}  // namespace
+
+extern "C" int flux2mi_dit_export_prequantized(flux2mi_dit* m, const char* path, const char* source_fingerprint) {
+    F2_REQUIRE(m && path && *path, FLUX2MI_ERR_INVALID_ARG, "dit_export_prequantized: bad argument");
+    F2_REQUIRE(m->finalized, FLUX2MI_ERR_NOT_LOADED, "dit_export_prequantized: weights not finalized");
+    F2_CHECK_HIP(hipSetDevice(m->ctx->device));
+    F2_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
+    const std::vector<PreqEntry> ent = preq_entries(m);
+    // header
+    std::string h = "{\"__metadata__\":{";
+    h += "\"format\":\"" + std::string(PREQ_FORMAT) + "\",";
+    h += "\"quantization\":\"" + std::string(m->cfg.weight_format == 1 ? "fp8" : "bf16") + "\",";
+    h += "\"bits\":\"" + std::string(m->cfg.weight_format == 1 ? "8" : "16") + "\",";
+    h += "\"component\":\"transformer\",";
+    h += "\"config\":\"" + cfg_string(m->cfg) + "\",";
+    h += "\"lora_baked\":\"" + std::string(m->lora_merged ? "true" : "false") + "\",";
+    h += "\"source_fingerprint\":\"" + json_escape(source_fingerprint) + "\"}";
+    uint64_t off = 0;
+    size_t max_bytes = 0;
+    for (const PreqEntry& e : ent) {
+        char b[256];
+        if (e.cols) snprintf(b, sizeof(b), ",\"%s\":{\"dtype\":\"%s\",\"shape\":[%d,%d],\"data_offsets\":[%llu,%llu]}", e.key.c_str(), e.dtype.c_str(),
+                             e.rows, e.cols, (unsigned long long)off, (unsigned long long)(off + e.bytes));
+        else snprintf(b, sizeof(b), ",\"%s\":{\"dtype\":\"%s\",\"shape\":[%d],\"data_offsets\":[%llu,%llu]}", e.key.c_str(), e.dtype.c_str(), e.rows,
+                      (unsigned long long)off, (unsigned long long)(off + e.bytes));
+        h += b;
+        off += e.bytes;
+        max_bytes = std::max(max_bytes, e.bytes);
+    }
+    h += "}";
+    while (h.size() % 8) h += ' ';
+    // atomic save: a crash or a full disk never leaves a truncated file at `path` (PrequantizedCheckpoint.swift, "Safety model")
+    const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) {
+        flux2mi_set_error("dit_export_prequantized: cannot create '%s': %s", tmp.c_str(), strerror(errno));
+        return FLUX2MI_ERR_INVALID_ARG;
+    }
+    const uint64_t hlen = h.size();
+    bool ok = fwrite(&hlen, 8, 1, f) == 1 && fwrite(h.data(), 1, h.size(), f) == h.size();
+    std::vector<uint8_t> host(max_bytes);
+    for (size_t i = 0; ok && i < ent.size(); ++i) {
+        if (hipMemcpy(host.data(), ent[i].dev, ent[i].bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+            flux2mi_set_error("dit_export_prequantized: device read of '%s' failed", ent[i].key.c_str());
+            fclose(f);
+            unlink(tmp.c_str());
+            return FLUX2MI_ERR_HIP;
+        }
+        ok = fwrite(host.data(), 1, ent[i].bytes, f) == ent[i].bytes;
+    }
+    ok = ok && fflush(f) == 0 && fsync(fileno(f)) == 0;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path) != 0) {
+        flux2mi_set_error("dit_export_prequantized: writing '%s' failed: %s", path, strerror(errno));
+        unlink(tmp.c_str());
+        return FLUX2MI_ERR_INVALID_ARG;
+    }
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_dit_load_prequantized(flux2mi_dit* m, const char* path, const char* expected_fingerprint, int* lora_baked) {
+    F2_REQUIRE(m && path, FLUX2MI_ERR_INVALID_ARG, "dit_load_prequantized: bad argument");
+    MappedFile f;
+    std::map<std::string, TensorInfo> ts;
+    std::map<std::string, std::string> md;
+    const uint8_t* data = nullptr;
+    uint64_t hlen = 0;
+    F2_TRY(parse_safetensors(path, f, ts, &data, &md, &hlen));
+    // ---- validate everything before the model is touched
+    const std::pair<const char*, std::string> expect[] = {
+        {"format", PREQ_FORMAT}, {"quantization", m->cfg.weight_format == 1 ? "fp8" : "bf16"},
+        {"bits", m->cfg.weight_format == 1 ? "8" : "16"}, {"component", "transformer"}, {"config", cfg_string(m->cfg)}};
+    for (const auto& kv : expect) {
+        auto it = md.find(kv.first);
+        F2_REQUIRE(it != md.end() && it->second == kv.second, FLUX2MI_ERR_INVALID_ARG,
+                   "dit_load_prequantized: '%s': metadata %s = '%s', this model needs '%s'", path, kv.first,
+                   it == md.end() ? "<missing>" : it->second.c_str(), kv.second.c_str());
+    }
+    if (expected_fingerprint) {
+        auto it = md.find("source_fingerprint");
+        F2_REQUIRE(it != md.end() && it->second == expected_fingerprint, FLUX2MI_ERR_INVALID_ARG,
+                   "dit_load_prequantized: '%s' was exported from different source weights (fingerprint '%s', expected '%s')", path,
+                   it == md.end() ? "<missing>" : it->second.c_str(), expected_fingerprint);
+    }
+    uint64_t max_end = 0;
+    for (const auto& kv : ts) max_end = std::max(max_end, kv.second.end);
+    F2_REQUIRE(8 + hlen + max_end == f.size, FLUX2MI_ERR_INVALID_ARG,
+               "dit_load_prequantized: '%s' is truncated or corrupt (%zu bytes on disk, header declares %llu)", path, f.size,
+               (unsigned long long)(8 + hlen + max_end));
+    const std::vector<PreqEntry> ent = preq_entries(m);
+    F2_REQUIRE(ts.size() == ent.size(), FLUX2MI_ERR_INVALID_ARG, "dit_load_prequantized: '%s' holds %zu tensors, this model has %zu", path,
+               ts.size(), ent.size());
+    for (const PreqEntry& e : ent) {
+        auto it = ts.find(e.key);
+        F2_REQUIRE(it != ts.end(), FLUX2MI_ERR_INVALID_ARG, "dit_load_prequantized: '%s': tensor '%s' missing", path, e.key.c_str());
+        const TensorInfo& t = it->second;
+        const bool shape_ok = e.cols ? (t.shape.size() == 2 && t.shape[0] == e.rows && t.shape[1] == e.cols)
+                                     : (t.shape.size() == 1 && t.shape[0] == e.rows);
+        F2_REQUIRE(t.dtype == e.dtype && shape_ok && t.end - t.begin == e.bytes, FLUX2MI_ERR_SHAPE,
+                   "dit_load_prequantized: '%s': tensor '%s' has the wrong dtype or shape", path, e.key.c_str());
+    }
+    // ---- copy (file mapping -> HBM)
+    F2_CHECK_HIP(hipSetDevice(m->ctx->device));
+    for (const PreqEntry& e : ent)
+        F2_CHECK_HIP(hipMemcpy(const_cast<void*>(e.dev), data + ts[e.key].begin, e.bytes, hipMemcpyHostToDevice));
+    for (Buf& b : m->bufs) b.got_rows = b.rows;
+    m->lora_merged = md.count("lora_baked") && md["lora_baked"] == "true";
+    if (lora_baked) *lora_baked = m->lora_merged ? 1 : 0;
+    m->finalized = false;
+    return flux2mi_dit_finalize(m);
 }
 
 // ------------------------------------------------------------------ forward

@@ -22,15 +22,10 @@
 #include <vector>
 
 #include "common.h"
+#include "loader.h"
 #include "../../include/flux2mi.h"
 
 namespace {
-
-struct TensorInfo {
-    std::string dtype;
-    std::vector<int64_t> shape;
-    uint64_t begin = 0, end = 0;
-};
 
 // Minimal JSON reader for the safetensors header (objects, arrays, strings, integers).
 struct Json {
@@ -91,17 +86,15 @@ struct Json {
     }
 };
 
-struct MappedFile {
-    int fd = -1;
-    uint8_t* base = nullptr;
-    size_t size = 0;
-    ~MappedFile() {
-        if (base) munmap(base, size);
-        if (fd >= 0) close(fd);
-    }
-};
+}  // namespace
 
-int parse_safetensors(const char* path, MappedFile& f, std::map<std::string, TensorInfo>& out, const uint8_t** data) {
+MappedFile::~MappedFile() {
+    if (base) munmap(base, size);
+    if (fd >= 0) close(fd);
+}
+
+int parse_safetensors(const char* path, MappedFile& f, std::map<std::string, TensorInfo>& out, const uint8_t** data,
+                      std::map<std::string, std::string>* metadata, uint64_t* header_len) {
     f.fd = open(path, O_RDONLY);
     if (f.fd < 0) {
         flux2mi_set_error("load_safetensors: cannot open '%s': %s", path, strerror(errno));
@@ -132,7 +125,20 @@ int parse_safetensors(const char* path, MappedFile& f, std::map<std::string, Ten
         std::string key = j.str();
         if (!j.ok || !j.eat(':')) { j.ok = false; break; }
         if (key == "__metadata__") {
-            j.skip_value();
+            if (!metadata) {
+                j.skip_value();
+            } else {   // flat string -> string object
+                if (!j.eat('{')) { j.ok = false; break; }
+                while (j.ok) {
+                    if (j.eat('}')) break;
+                    std::string k = j.str();
+                    if (!j.eat(':')) { j.ok = false; break; }
+                    j.ws();
+                    if (j.p < j.e && *j.p == '"') (*metadata)[k] = j.str();
+                    else j.skip_value();
+                    (void)j.eat(',');
+                }
+            }
         } else {
             TensorInfo t;
             if (!j.eat('{')) { j.ok = false; break; }
@@ -165,8 +171,11 @@ int parse_safetensors(const char* path, MappedFile& f, std::map<std::string, Ten
         return FLUX2MI_ERR_INVALID_ARG;
     }
     *data = f.base + 8 + hlen;
+    if (header_len) *header_len = hlen;
     return FLUX2MI_OK;
 }
+
+namespace {
 
 int st_dtype(const std::string& s) {
     if (s == "F32") return FLUX2MI_F32;

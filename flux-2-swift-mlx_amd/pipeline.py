@@ -150,6 +150,17 @@ class Flux2Pipeline:
         self._lora = getattr(self, "_lora", []) + [str(path)]
         return merged
 
+    def exportPrequantizedTransformer(self, path: str, source_fingerprint: str = "", allowLoRABaked: bool = False) -> str:
+        """`Flux2Pipeline.exportPrequantizedTransformer` (Flux2Pipeline.swift:759-840): only for a quantised
+        transformer configuration, and not with a merged LoRA unless explicitly allowed."""
+        if self.quantization == "bf16":
+            raise Flux2Error(L.ERR_INVALID_ARG, "exportPrequantizedTransformer requires a quantized transformer configuration (current: bf16)")
+        if self.transformer is None:
+            raise Flux2Error(L.ERR_NOT_LOADED, "Transformer")
+        if self.hasLoRA and not allowLoRABaked:
+            raise Flux2Error(L.ERR_INVALID_ARG, "a LoRA is merged into the transformer; pass allowLoRABaked=True to export it baked in")
+        return self.transformer.export_prequantized(path, source_fingerprint)
+
     @property
     def hasLoRA(self) -> bool:
         return bool(getattr(self, "_lora", []))

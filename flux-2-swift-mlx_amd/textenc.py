@@ -25,6 +25,41 @@ def format_qwen3_chat_template(user_message: str, add_generation_prompt: bool = 
     return s
 
 
+# TekkenTokenizer's special token ranks (FluxTextEncoders/Tokenizer/TekkenTokenizer.swift:46-53; overridden from
+# tekken.json / generation_config.json when those are present)
+MISTRAL_SPECIAL_TOKENS = {"bos": 1, "eos": 2, "inst": 3, "end_inst": 4, "pad": 11, "system_prompt": 17, "end_system_prompt": 18}
+# FluxConfig.systemMessage (Embeddings/EmbeddingExtractor.swift:17-19): the fixed system turn of FLUX.2-dev prompts
+FLUX_SYSTEM_MESSAGE = ("You are an AI that reasons about image descriptions. You give structured responses focusing on object "
+                       "relationships, object attribution and actions without speculation.")
+
+
+def encode_mistral_chat_messages(messages, encode, special: Optional[Dict[str, int]] = None) -> List[int]:
+    """`TekkenTokenizer.encodeChatMessages(messages:addGenerationPrompt:)`, manual layout (:516-536):
+    <s> then per message  system: [SYSTEM_PROMPT] text [/SYSTEM_PROMPT];  user: [INST] text [/INST];
+    assistant: text </s>.  `encode(text) -> ids` must not add special tokens.  Unknown roles and messages without
+    role/content are skipped, like the reference."""
+    sp = dict(MISTRAL_SPECIAL_TOKENS, **(special or {}))
+    tokens = [sp["bos"]]
+    for m in messages:
+        role, content = m.get("role"), m.get("content")
+        if role is None or content is None:
+            continue
+        if role == "system":
+            tokens += [sp["system_prompt"], *encode(content), sp["end_system_prompt"]]
+        elif role == "user":
+            tokens += [sp["inst"], *encode(content), sp["end_inst"]]
+        elif role == "assistant":
+            tokens += [*encode(content), sp["eos"]]
+    return tokens
+
+
+def flux_prompt_token_ids(prompt: str, encode, special: Optional[Dict[str, int]] = None) -> List[int]:
+    """`getFluxTokenIds` before padding (EmbeddingExtractor.swift:206-218): "[IMG]" stripped from the prompt,
+    [system = FluxConfig.systemMessage, user = prompt], no generation prompt."""
+    return encode_mistral_chat_messages(
+        [{"role": "system", "content": FLUX_SYSTEM_MESSAGE}, {"role": "user", "content": prompt.replace("[IMG]", "")}], encode, special)
+
+
 def pad_klein_token_ids(token_ids: Sequence[int], max_length: int = KLEIN_MAX_SEQUENCE_LENGTH,
                         pad_id: int = QWEN3_PAD_TOKEN_ID) -> Tuple[List[int], int]:
     """Truncate to max_length, RIGHT-pad with pad_id (:70-90).  Returns (ids, number of real tokens)."""
@@ -111,11 +146,16 @@ class TextEncoder:
         return self.forward(t, n)
 
     # ---- EmbeddingExtractor.extractFluxEmbeddings(prompt:maxLength:) (Dev, Mistral) -------------------
-    def extract_flux_embeddings(self, token_ids: Sequence[int], max_length: int = KLEIN_MAX_SEQUENCE_LENGTH,
-                                pad_id: int = 11) -> torch.Tensor:
-        """`token_ids` = the chat-template encoding of [system message, user prompt] (tokenizer work stays
-        with the caller: EmbeddingExtractor.swift:206-218); truncated to max_length and LEFT-padded with the
-        tokenizer's pad token (:226-237).  -> [1, max_length, 3*hidden] bf16."""
+    def extract_flux_embeddings(self, token_ids: Optional[Sequence[int]] = None, max_length: int = KLEIN_MAX_SEQUENCE_LENGTH,
+                                pad_id: int = MISTRAL_SPECIAL_TOKENS["pad"], prompt: Optional[str] = None) -> torch.Tensor:
+        """`prompt` is encoded as [system message, user prompt] with the Mistral chat layout
+        (`encode_mistral_chat_messages`, EmbeddingExtractor.swift:206-218) through the loaded tokenizer, or
+        `token_ids` carries that encoding; then truncated to max_length and LEFT-padded with the tokenizer's pad
+        token (:226-237).  -> [1, max_length, 3*hidden] bf16."""
+        if token_ids is None:
+            if prompt is None or self.tokenizer is None:
+                raise Flux2Error(L.ERR_NOT_LOADED, "tokenizer (set_tokenizer(path to tokenizer.json) + prompt, or pass token_ids)")
+            token_ids = flux_prompt_token_ids(prompt, lambda t: self.tokenizer.encode(t, add_special_tokens=False).ids)
         ids = list(token_ids)[:max_length]
         n = len(ids)
         if n == 0:

@@ -89,6 +89,18 @@ int flux2mi_sched_step(flux2mi_ctx* ctx, float* x, const float* v, float dt, int
 /* FlowMatchEulerScheduler.scaleNoise (:195-204): out = (1-sigma)*sample + sigma*noise. */
 int flux2mi_scale_noise(flux2mi_ctx* ctx, float* out, const float* sample, const float* noise,
                         float sigma, int64_t n);
+/* ---- pre-quantized checkpoint: Flux2PrequantizedCheckpoint + Flux2Pipeline.exportPrequantizedTransformer
+ * (Loading/PrequantizedCheckpoint.swift, Pipeline/Flux2Pipeline.swift:759-840).  One safetensors file with the
+ * resident weights in the library's own layout and naming ("<buffer>.weight" F8_E4M3 + "<buffer>.scale" F32 per
+ * output row for the block GEMMs of a weight_format 1 model, BF16 otherwise) and string metadata {format,
+ * quantization, bits, component, config, lora_baked, source_fingerprint}.  export: the model must be finalized;
+ * written atomically (temp file + rename).  load: metadata (and the fingerprint when expected_fingerprint != NULL),
+ * payload size, key set, dtypes and shapes are validated BEFORE the model is touched — on an error the model is
+ * exactly as it was, so the standard load path can run; on success the model is finalized.  *lora_baked (optional)
+ * reports an export taken after flux2mi_dit_merge_lora. */
+int flux2mi_dit_export_prequantized(flux2mi_dit* dit, const char* path, const char* source_fingerprint);
+int flux2mi_dit_load_prequantized(flux2mi_dit* dit, const char* path, const char* expected_fingerprint, int* lora_baked);
+
 /* ---- pixel-space pre/post-processing of the inpainting / outpainting chains (device buffers, u8 interleaved
  * [H,W,C] images).  The reference resamples with CoreGraphics' closed `.high` filter; this library uses the
  * antialiased triangle filter in Pillow's 8-bit fixed-point form (bit-exact against Pillow's

@@ -212,3 +212,127 @@ def test_vae_safetensors(flux2mi, ctx, tmp_path):
     assert torch.equal(a.decode(z)[1], b.decode(z)[1])
     assert a.has_encoder
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("weights", ["fp8", "bf16"])
+def test_prequantized_checkpoint_round_trip(flux2mi, ctx, tmp_path, weights):
+    """Flux2PrequantizedCheckpoint: export the resident weights in the library's own layout, reload into a fresh
+    model -> bit-identical forward; the file is a valid safetensors file with the documented metadata and, for fp8,
+    about half the bytes of the bf16 one."""
+    import json, struct
+    from flux2mi.api import DiT
+    syn, cfg, P, inp, lat = _setup(seed=41)
+    a = DiT(ctx, cfg, weights=weights).load(P).finalize()
+    ref = _fwd(a, cfg, inp, lat, 64, 64, 16)
+    path = str(tmp_path / f"transformer_{weights}.safetensors")
+    a.export_prequantized(path, source_fingerprint="ckpt.safetensors:123:456")
+    a.close()
+    assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]            # temp file renamed away
+    raw = open(path, "rb").read()
+    hlen = struct.unpack("<Q", raw[:8])[0]
+    hdr = json.loads(raw[8:8 + hlen])
+    md = hdr.pop("__metadata__")
+    assert md["format"] == "flux2mi-prequantized-v1" and md["quantization"] == weights and md["lora_baked"] == "false"
+    assert md["source_fingerprint"] == "ckpt.safetensors:123:456" and f"dim={cfg['dim']}" in md["config"]
+    assert 8 + hlen + max(t["data_offsets"][1] for t in hdr.values()) == len(raw)
+    dtypes = {t["dtype"] for t in hdr.values()}
+    assert dtypes == ({"F8_E4M3", "F32", "BF16"} if weights == "fp8" else {"BF16"})
+    b = DiT(ctx, cfg, weights=weights)
+    assert b.load_prequantized(path, expected_fingerprint="ckpt.safetensors:123:456") is False
+    assert torch.equal(_fwd(b, cfg, inp, lat, 64, 64, 16), ref)              # finalized by the load, same bits
+    b.close()
+    if weights == "fp8":
+        other = str(tmp_path / "bf16.safetensors")
+        c = DiT(ctx, cfg, weights="bf16").load(P).finalize()
+        c.export_prequantized(other)
+        c.close()
+        assert os.path.getsize(path) < 0.75 * os.path.getsize(other)
+
+
+def test_prequantized_checkpoint_safety(flux2mi, ctx, tmp_path):
+    """The load validates before it mutates: wrong quantization / config / fingerprint, a truncated payload, a missing
+    or foreign tensor are all refused, and the refused model still takes the standard load path to the right answer."""
+    import json, struct
+    from flux2mi.api import DiT
+    from flux2mi.pipeline import Flux2Pipeline
+    syn, cfg, P, inp, lat = _setup(seed=43)
+    a = DiT(ctx, cfg, weights="fp8").load(P).finalize()
+    ref = _fwd(a, cfg, inp, lat, 64, 64, 16)
+    good = str(tmp_path / "good.safetensors")
+    a.export_prequantized(good, "fp-A")
+    with pytest.raises(flux2mi.Flux2Error):
+        DiT(ctx, cfg, weights="fp8").export_prequantized(str(tmp_path / "x.safetensors"))     # not finalized
+    a.close()
+    raw = open(good, "rb").read()
+    hlen = struct.unpack("<Q", raw[:8])[0]
+
+    def variant(name, mutate_header=None, cut=0):
+        hdr = json.loads(raw[8:8 + hlen])
+        if mutate_header:
+            mutate_header(hdr)
+        h = json.dumps(hdr, separators=(",", ":")).encode()
+        h += b" " * (-len(h) % 8)
+        body = raw[8 + hlen:]
+        p = str(tmp_path / name)
+        open(p, "wb").write(struct.pack("<Q", len(h)) + h + (body[:-cut] if cut else body))
+        return p
+
+    def drop_one(h):
+        h.pop(next(k for k in h if k.endswith(".scale")))
+
+    def add_one(h):
+        k = next(k for k in h if k.endswith(".scale"))
+        h["foreign.weight"] = dict(h[k])
+
+    def reshape_one(h):
+        k = next(k for k in h if k.endswith(".scale"))
+        h[k]["shape"] = [h[k]["shape"][0] // 2, 2]
+
+    bad = {
+        "truncated": variant("trunc.safetensors", cut=4096),
+        "format": variant("fmt.safetensors", lambda h: h["__metadata__"].update(format="something-else")),
+        "config": variant("cfg.safetensors", lambda h: h["__metadata__"].update(config="dim=1")),
+        "missing": variant("missing.safetensors", drop_one),
+        "foreign": variant("foreign.safetensors", add_one),
+        "shape": variant("shape.safetensors", reshape_one),
+    }
+    m = DiT(ctx, cfg, weights="fp8")
+    for why, p in bad.items():
+        with pytest.raises(flux2mi.Flux2Error):
+            m.load_prequantized(p)
+    with pytest.raises(flux2mi.Flux2Error):
+        m.load_prequantized(good, expected_fingerprint="fp-B")                 # exported from other source weights
+    with pytest.raises(flux2mi.Flux2Error):
+        DiT(ctx, cfg, weights="bf16").load_prequantized(good)                  # quantization mismatch
+    with pytest.raises(flux2mi.Flux2Error):
+        m.load_prequantized(str(tmp_path / "does_not_exist.safetensors"))
+    # the refused model is untouched: the standard path still gives the reference answer, and so does the good file
+    assert torch.equal(_fwd(m.load(P).finalize(), cfg, inp, lat, 64, 64, 16), ref)
+    m.close()
+    # pipeline-level rule (Flux2Pipeline.swift:763-766): bf16 configurations do not export
+    pipe = Flux2Pipeline(model=cfg, vae_variant=syn.VAE_PRESETS["tiny"]).load_models(P, syn.make_vae_weights(syn.VAE_PRESETS["tiny"]))
+    with pytest.raises(flux2mi.Flux2Error):
+        pipe.exportPrequantizedTransformer(str(tmp_path / "no.safetensors"))
+    pipe8 = Flux2Pipeline(model=cfg, vae_variant=syn.VAE_PRESETS["tiny"], quantization="fp8").load_models(
+        P, syn.make_vae_weights(syn.VAE_PRESETS["tiny"]))
+    out = pipe8.exportPrequantizedTransformer(str(tmp_path / "pipe.safetensors"), "fp-A")
+    assert os.path.getsize(out) == len(raw)
+
+
+def test_prequantized_checkpoint_lora_tag(flux2mi, ctx, tmp_path):
+    """An export taken after a LoRA merge is tagged and reported at load (PrequantizedCheckpoint.swift, LoRA-baked exports)."""
+    from flux2mi.api import DiT
+    syn, cfg, P, inp, lat = _setup(seed=47)
+    a = DiT(ctx, cfg).load(P)
+    name = "double_blocks.0.img_attn.proj.weight"
+    g = torch.Generator().manual_seed(1)
+    a.merge_lora(name, torch.randn((4, P[name].shape[1]), generator=g) * 0.05, torch.randn((P[name].shape[0], 4), generator=g) * 0.05, 0.8)
+    a.finalize()
+    ref = _fwd(a, cfg, inp, lat, 64, 64, 16)
+    path = str(tmp_path / "baked.safetensors")
+    a.export_prequantized(path)
+    a.close()
+    b = DiT(ctx, cfg)
+    assert b.load_prequantized(path) is True
+    assert torch.equal(_fwd(b, cfg, inp, lat, 64, 64, 16), ref)
+    b.close()

@@ -64,3 +64,19 @@ def test_mistral_left_padding_matches_hf_fixture_on_real_rows():
     ids2[pad:] = (ids2[pad:] + 17) % G.MISTRAL_TINY["vocab"]
     hs2 = R.qwen3_hidden_states(P, G.MISTRAL_TINY, ids2, v, (3,), pad_left=pad)
     np.testing.assert_allclose(hs[3][0, :pad].numpy(), hs2[3][0, :pad].numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_mistral_chat_message_layout():
+    """TekkenTokenizer.encodeChatMessages manual layout (FluxTextEncoders/Tokenizer/TekkenTokenizer.swift:516-536) and
+    the FLUX.2-dev prompt of EmbeddingExtractor.extractFluxEmbeddings (:206-218): host string/id logic, no GPU."""
+    from flux2mi.textenc import FLUX_SYSTEM_MESSAGE, encode_mistral_chat_messages, flux_prompt_token_ids
+    enc = lambda text: [1000 + b for b in text.encode("utf-8")]
+    ids = encode_mistral_chat_messages([{"role": "system", "content": "S"}, {"role": "user", "content": "hi"},
+                                        {"role": "assistant", "content": "ok"}, {"role": "tool", "content": "x"}, {"role": "user"}], enc)
+    assert ids == [1, 17, 1000 + ord("S"), 18, 3, 1000 + ord("h"), 1000 + ord("i"), 4, 1000 + ord("o"), 1000 + ord("k"), 2]
+    ids = flux_prompt_token_ids("a cat[IMG] on a mat", enc)
+    sys_ids, user_ids = enc(FLUX_SYSTEM_MESSAGE), enc("a cat on a mat")
+    assert ids == [1, 17, *sys_ids, 18, 3, *user_ids, 4]                 # no generation prompt, [IMG] stripped
+    assert FLUX_SYSTEM_MESSAGE.startswith("You are an AI that reasons about image descriptions.")
+    # special token ranks can come from the tokenizer files
+    assert encode_mistral_chat_messages([{"role": "user", "content": ""}], enc, {"bos": 7, "inst": 8, "end_inst": 9}) == [7, 8, 9]
