@@ -85,7 +85,8 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 // in (0, 1] for every key, the row maximum, its cross-lane exchange, the rescale branch and their
 // serial dependency in front of the first exp2 all disappear (same softmax: any offset cancels in
 // O / l).  The caller only asks for it when fixed_m is small enough that p cannot underflow.
-template <bool CAUSAL, int NW, bool FIXM = false>
+// FIXM == 2: Q arrives pre-multiplied by scale * log2(e) and the offset is zero: p = exp2(s), no fma.
+template <bool CAUSAL, int NW, int FIXM = 0>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(const uint16_t* __restrict__ q,
                                                           const uint16_t* __restrict__ k, int ldqk,
                                                           const uint16_t* __restrict__ vt, int s_pad,
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     // CAUSAL: a finite start value, so that a tile whose keys are all masked for a row (left padding
     // inside a straddling workgroup) gives exp2(-inf) = 0 and not exp2(-inf + inf)
-    float m_run = FIXM ? fixed_m : (CAUSAL ? -1.0e30f : -INFINITY), l_run = 0.f;
+    float m_run = FIXM == 2 ? 0.f : FIXM ? fixed_m : (CAUSAL ? -1.0e30f : -INFINITY), l_run = 0.f;
 
     // keys this block can see at all, and the per-lane limit of the causal form
     const int key_lim_blk = CAUSAL ? min(min(valid_len, S), q0 + BQ) : S;
@@ -277,7 +278,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[kb][s2 * 8 + j], scale_log2e, neg_m));
+                    const float pv = FIXM == 2 ? __builtin_amdgcn_exp2f(sa[kb][s2 * 8 + j])
+                                               : __builtin_amdgcn_exp2f(__builtin_fmaf(sa[kb][s2 * 8 + j], scale_log2e, neg_m));
                     rs += pv;
                     pf8[kb][s2][j] = (__bf16)pv;
                 }
@@ -348,9 +350,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
 }  // namespace
 
 int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
-                     int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads, float score_bound_log2) {
+                     int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads, float score_bound_log2, bool q_prescaled) {
     if (Sq <= 0 || S <= 0 || heads <= 0 || (ldqk & 7) || (ldo & 3) || s_pad < attn_s_pad(S) || (s_pad & 7)) return 1;
-    const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
+    const float scale_log2e = q_prescaled ? 1.0f : 1.4426950408889634f / sqrtf((float)HD);
     static const int nw_env = [] {   // FLUX2MI_ATTN_NW=4|8 forces a workgroup size (A/B runs)
         const char* e = getenv("FLUX2MI_ATTN_NW");
         return e ? atoi(e) : 0;
@@ -366,8 +368,9 @@ int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, i
     const bool fixm = fixm_on && score_bound_log2 > 0.f && score_bound_log2 <= 40.f;
     const dim3 grid((Sq + nw * 32 - 1) / (nw * 32), heads), block(nw * 64);
 #define ATTN_GO(NW_, FX_) hipLaunchKernelGGL((attn_fwd_kernel<false, NW_, FX_>), grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, scale_log2e, S, 1, score_bound_log2, 0)
-    if (nw == 8) { if (fixm) ATTN_GO(8, true); else ATTN_GO(8, false); }
-    else { if (fixm) ATTN_GO(4, true); else ATTN_GO(4, false); }
+    const int fx = fixm ? (q_prescaled ? 2 : 1) : 0;
+    if (nw == 8) { if (fx == 2) ATTN_GO(8, 2); else if (fx) ATTN_GO(8, 1); else ATTN_GO(8, 0); }
+    else { if (fx == 2) ATTN_GO(4, 2); else if (fx) ATTN_GO(4, 1); else ATTN_GO(4, 0); }
 #undef ATTN_GO
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

@@ -850,6 +850,13 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     };
     // joint attention per query range; keys = all S rows except for the reference queries of the
     // extraction pass, which see [txt | ref] only.  Also moves the reference K / V^T to / from the cache.
+    // the score scale log2(e)/sqrt(128) rides on Q from the norm+RoPE kernel (one rounding, as before), so the
+    // attention's softmax needs no multiply (FLUX2MI_ATTN_PRESCALE=0: scale inside the attention, for A/B runs)
+    static const bool q_pre = [] {
+        const char* e = getenv("FLUX2MI_ATTN_PRESCALE");
+        return e ? atoi(e) != 0 : true;
+    }();
+    const float q_mul = q_pre ? 1.4426950408889634f / sqrtf(128.0f) : 1.0f;
     auto attend = [&](int layer, uint16_t* o_buf, int ldo, float score_bound) -> int {
         if (mode == FWD_KV_EXTRACT) {
             F2_CHECK_HIP(hipMemcpy2DAsync(cache->k(layer), (size_t)d * 2, qkv + (size_t)s_txt * 3 * d + d, (size_t)3 * d * 2,
@@ -871,7 +878,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         for (int i = 0; i < nr; ++i) {
             prof_before(m->ctx, PROF_ATTENTION);
             const int ar = launch_attention(st, qkv + (size_t)rg[i].q0 * 3 * d, qkv + d, 3 * d, vt, s_pad,
-                                            o_buf + (size_t)rg[i].q0 * ldo, ldo, rg[i].nq, rg[i].nk, H, score_bound);
+                                            o_buf + (size_t)rg[i].q0 * ldo, ldo, rg[i].nq, rg[i].nk, H, score_bound, q_pre);
             prof_after(m->ctx, PROF_ATTENTION, 4.0 * (double)rg[i].nq * rg[i].nk * d);
             F2_LAUNCH(ar, "attention");
         }
@@ -890,7 +897,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
             F2_TRY(run_gemm(m, p, 2, 0, "dbl.qkv"));
         }
         F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, s_txt, w.qn[0], w.kn[0], w.qn[1], w.kn[1], cos_tab, sin_tab,
-                                         vt, s_pad), "qk_norm_rope");
+                                         vt, s_pad, q_mul), "qk_norm_rope");
         F2_TRY(attend(i, comb, d, w.score_bound));
         F2_LAUNCH(quant(comb, d, d), "quantize(attn out)");
         {
@@ -940,7 +947,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
             }
             F2_TRY(run_gemm(m, p, n_rng, PROF_LINEAR1, "single.linear1"));
         }
-        F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, 0, w.qn, w.kn, w.qn, w.kn, cos_tab, sin_tab, vt, s_pad),
+        F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, 0, w.qn, w.kn, w.qn, w.kn, cos_tab, sin_tab, vt, s_pad, q_mul),
                   "qk_norm_rope");
         F2_TRY(attend(m->cfg.n_double + i, comb, 4 * d, w.score_bound));
         F2_LAUNCH(quant(comb, 4 * d, 4 * d), "quantize(attn | ff hidden)");

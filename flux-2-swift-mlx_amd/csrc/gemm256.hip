@@ -43,6 +43,13 @@ typedef __attribute__((ext_vector_type(2))) long i64x2;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// v_permlane16_swap_b32 a, b: rows (16 lanes) 1 and 3 of a <-> rows 0 and 2 of b.  With a = X, b = Y of lane
+// (frow, fq) afterwards {a, b} = {X of fq&~1, X of fq|1} on even fq and {Y of fq&~1, Y of fq|1} on odd fq:
+// two 8-byte column groups that were split over two lanes become one 16-byte run per lane (guide T21).
+__device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+
 __device__ __forceinline__ void tile_coords256(int local, int ntiles, int tiles_m, int tiles_n, int& tm, int& tn) {
     const int q = ntiles >> 3, r = ntiles & 7;
     const int xcd = local & 7, within = local >> 3;
@@ -63,7 +70,8 @@ __device__ __forceinline__ void tile_coords256(int local, int ntiles, int tiles_
 // on each SIMD instead of both reading, then both computing (MI355X guide, "Two waves per
 // SIMD" item 9).  Data published by LDS-DMA is then only guaranteed one phase later for the
 // leading group, hence vmcnt(8) instead of vmcnt(10).
-// ABL bits (timing only): 1 no fragment reads, 2 no DMA, 4 DMA from an L2-resident source, 8 no vmcnt waits, 16 no MFMA
+// ABL bits (timing only): 1 no fragment reads, 2 no DMA, 4 DMA from an L2-resident source, 8 no vmcnt waits, 16 no MFMA,
+// 32 no epilogue (the accumulators are dropped after the K loop)
 // FP8: operands are OCP e4m3 bytes.  The byte geometry of the tile is unchanged (128-B rows, so a
 // K-tile holds 128 k instead of 64); a lane's two 16-B fragment reads are the 32-byte operand of
 // ONE block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3, unit block scales), the form that
@@ -329,6 +337,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     // memory instructions (the scalar form spent ~17k cycles per tile in the store queue).
     const int row_base = m0 + wm * 128 + frow;
     const int col_base = n0 + wn * 64 + fq * 4;
+    if ((ABL & 32) && p.alpha != 12345.f) return;   // timing only: the K loop without its epilogue
     int epi = p.epi;
     if (epi == EPI_QKV_MLP) epi = (n0 >= p.n_split) ? EPI_SWIGLU : EPI_BF16;
     if (FP8) {  // de-quantise: per-row activation scale x per-column weight scale
@@ -371,6 +380,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     } else if (epi == EPI_BF16) {
         uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
         const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 7) == 0;
+        if ((batch.flags & 1) && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && n0 + BN2 <= p.N) {
+            // 16-byte stores: half the store instructions of the 8-byte form below
+            const int wcol = n0 + wn * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = row_base + i * 16;
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const f32x4 vx = acc[i][2 * jp] * p.alpha, vy = acc[i][2 * jp + 1] * p.alpha;
+                    uint32_t x0 = pack_bf16x2(vx[0], vx[1]), x1 = pack_bf16x2(vx[2], vx[3]);
+                    uint32_t y0 = pack_bf16x2(vy[0], vy[1]), y1 = pack_bf16x2(vy[2], vy[3]);
+                    swap16(x0, y0);
+                    swap16(x1, y1);
+                    if (row < p.M)
+                        *reinterpret_cast<uint4*>(C + (size_t)row * p.ldc + wcol + jp * 32) = make_uint4(x0, x1, y0, y1);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = row_base + i * 16;
@@ -428,6 +456,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         const int hbase = ((n0 + wn * 64 - start) >> 1) + fq * 4;
         const int hidden = (p.N - start) >> 1;
         const bool vec_ok = (p.ldc2 & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 7) == 0;
+        if ((batch.flags & 1) && (p.ldc2 & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && n0 + BN2 <= p.N) {
+            const int wh = ((n0 + wn * 64 - start) >> 1) + (fq & 1) * 16 + (fq >> 1) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = row_base + i * 16;
+                float ox[4], oy[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ox[r] = silu_f(acc[i][0][r]) * acc[i][2][r];
+                    oy[r] = silu_f(acc[i][1][r]) * acc[i][3][r];
+                }
+                uint32_t x0 = pack_bf16x2(ox[0], ox[1]), x1 = pack_bf16x2(ox[2], ox[3]);
+                uint32_t y0 = pack_bf16x2(oy[0], oy[1]), y1 = pack_bf16x2(oy[2], oy[3]);
+                swap16(x0, y0);
+                swap16(x1, y1);
+                if (row < p.M) *reinterpret_cast<uint4*>(C + (size_t)row * p.ldc2 + wh) = make_uint4(x0, x1, y0, y1);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = row_base + i * 16;
@@ -505,6 +552,12 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
     }
     if (nprob == 1) b.p[1] = probs[0];
     b.tile_start1 = tiles[0];
+    // bit 0: 16-byte bf16 / SwiGLU epilogue stores (FLUX2MI_GEMM_FLAGS=0 for A/B runs: linear1 0.617 -> 0.604 ms)
+    static const int flags = [] {
+        const char* e = getenv("FLUX2MI_GEMM_FLAGS");
+        return e ? atoi(e) : 1;
+    }();
+    b.flags = flags;
 
     const bool fp8 = probs[0].fp8 != 0;
     if (fp8) {
@@ -527,6 +580,10 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
         const char* e = getenv("FLUX2MI_GEMM_VAR");
         return e ? atoi(e) : 3;
     }();
+    if (abl == 32) {
+        hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 32, false, false, false, 3>), grid, block, 0, stream, b);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
     if (var == 2 && abl == 0 && stagger == 0) {   // lockstep waves, one wait per K-tile (A/B only)
         hipLaunchKernelGGL((gemm_bf16_256x256_kernel<false, 0, false, false, false, 2>), grid, block, 0, stream, b);
         return hipGetLastError() == hipSuccess ? 0 : 2;

@@ -36,6 +36,7 @@ struct GemmBatch {
     GemmProblem p[2];
     int nprob;
     int tile_start1;
+    int flags;    // gemm256: bit 0 = 16-byte bf16 epilogue stores
 };
 int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob);
 
@@ -48,8 +49,12 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob);
 // score_bound_log2 > 0: the caller guarantees |q.k| / sqrt(128) * log2(e) <= score_bound_log2 for every
 // query/key pair (q, k out of the per-head RMSNorm); the softmax then uses it as a fixed offset instead
 // of tracking row maxima (used when <= 40).  0 = no bound known.
+// q_prescaled: Q already carries the factor log2(e)/sqrt(128) (launch_qk_norm_rope_vt's q_mul), so the scores
+// come out of the MFMA in the log2 domain; with a bound the offset is then taken as ZERO and p = exp2(s)
+// needs no multiply-add at all (p in [2^-40, 2^40]: far inside f32 / bf16 range, any offset cancels in O / l).
 int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
-                     int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads, float score_bound_log2 = 0.f);
+                     int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads, float score_bound_log2 = 0.f,
+                     bool q_prescaled = false);
 static inline int attn_s_pad(int S) { return ((S + 63) / 64) * 64; }
 
 // ---------------------------------------------------------------- norms / rope (norm.hip)
@@ -68,11 +73,12 @@ int launch_quantize_rows_fp8(hipStream_t stream, const uint16_t* x, int ld, uint
 // In place on qkv bf16 [S, 3*dim] (q | k | v): per-head RMSNorm (eps 1e-6, learned scale)
 // then RoPE on q and k; V is written transposed + key-permuted into vt [heads][128][s_pad].
 // Rows < split use (qscale0, kscale0) — the text stream of a double block — rows >= split
-// use (qscale1, kscale1).
+// use (qscale1, kscale1).  q_mul multiplies Q (not K) before its rounding to bf16: the DiT folds the
+// attention's score scale log2(e)/sqrt(128) in here and calls launch_attention with q_prescaled.
 int launch_qk_norm_rope_vt(hipStream_t stream, uint16_t* qkv, int ldqkv, int S, int heads, int split,
                            const uint16_t* qscale0, const uint16_t* kscale0, const uint16_t* qscale1,
                            const uint16_t* kscale1, const float* cos_tab, const float* sin_tab,
-                           uint16_t* vt, int s_pad);
+                           uint16_t* vt, int s_pad, float q_mul = 1.0f);
 // V half of the above only (standalone attention op).
 int launch_v_transpose_only(hipStream_t stream, const uint16_t* qkv, int ldqkv, int S, int heads, uint16_t* vt,
                             int s_pad);

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(uint16_t* __restrict_
                                                            const uint16_t* __restrict__ qs1,
                                                            const uint16_t* __restrict__ ks1,
                                                            const float* __restrict__ cos_tab,
-                                                           const float* __restrict__ sin_tab) {
+                                                           const float* __restrict__ sin_tab, float q_mul) {
     const int sub = threadIdx.x & 15;
     const long vec = (long)blockIdx.x * 16 + (threadIdx.x >> 4);  // ((row*2 + which)*heads + head)
     const long total = (long)S * 2 * heads;
@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(uint16_t* __restrict_
     for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-    const float r = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+    // q_mul: the attention's score scale folded into Q before its one bf16 rounding (see launch_attention)
+    const float r = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f) * (which ? 1.0f : q_mul);
     const uint16_t* sc = (row < split) ? (which ? ks0 : qs0) : (which ? ks1 : qs1);
     const uint4 su = *reinterpret_cast<const uint4*>(sc + sub * 8);
     const float w[8] = {lo_bf16(su.x), hi_bf16(su.x), lo_bf16(su.y), hi_bf16(su.y),
@@ -402,11 +403,11 @@ int launch_quantize_rows_fp8(hipStream_t stream, const uint16_t* x, int ld, uint
 int launch_qk_norm_rope_vt(hipStream_t stream, uint16_t* qkv, int ldqkv, int S, int heads, int split,
                            const uint16_t* qscale0, const uint16_t* kscale0, const uint16_t* qscale1,
                            const uint16_t* kscale1, const float* cos_tab, const float* sin_tab,
-                           uint16_t* vt, int s_pad) {
+                           uint16_t* vt, int s_pad, float q_mul) {
     if (S <= 0 || heads <= 0 || (ldqkv & 7) || s_pad < attn_s_pad(S)) return 1;
     const long total = (long)S * 2 * heads;
     hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, qkv, ldqkv, S,
-                       heads, split, qscale0, kscale0, qscale1, kscale1, cos_tab, sin_tab);
+                       heads, split, qscale0, kscale0, qscale1, kscale1, cos_tab, sin_tab, q_mul);
     hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, heads), dim3(256), 0, stream, qkv, ldqkv, S,
                        2 * heads * 128, vt, s_pad);
     return hipGetLastError() == hipSuccess ? 0 : 2;

@@ -24,6 +24,16 @@ SHAPES = [  # (M, N, K, name)
 ]
 
 
+SHAPES_9B = [  # Klein-9B (d 4096) and Dev (d 6144): N = d GEMMs are 288 / 432 tiles of 256^2
+    (4608, 36864, 4096, "9b.linear1"),
+    (4608, 4096, 16384, "9b.linear2"),
+    (4608, 4096, 4096, "9b.proj"),
+    (4608, 4096, 12288, "9b.mlp_out"),
+    (4608, 6144, 24576, "dev.linear2"),
+    (4608, 6144, 6144, "dev.proj"),
+]
+
+
 def time_fn(fn, iters=10):
     for _ in range(3):
         fn()
@@ -41,7 +51,7 @@ def main():
     ctx = Context(0)
     check = "--check" in sys.argv
     print(f"FLUX2MI_GEMM={os.environ.get('FLUX2MI_GEMM', '(auto)')}")
-    for M, N, K, name in SHAPES:
+    for M, N, K, name in (SHAPES_9B if "--9b" in sys.argv else SHAPES):
         a = torch.randn((M, K), device="cuda").to(torch.bfloat16)
         w = (torch.randn((N, K), device="cuda") * 0.05).to(torch.bfloat16)
         with torch.cuda.stream(ctx.stream):
