@@ -71,7 +71,7 @@ __device__ __forceinline__ void tile_coords256(int local, int ntiles, int tiles_
 // SIMD" item 9).  Data published by LDS-DMA is then only guaranteed one phase later for the
 // leading group, hence vmcnt(8) instead of vmcnt(10).
 // ABL bits (timing only): 1 no fragment reads, 2 no DMA, 4 DMA from an L2-resident source, 8 no vmcnt waits, 16 no MFMA,
-// 32 no epilogue (the accumulators are dropped after the K loop)
+// 32 no epilogue (the accumulators are dropped after the K loop), 64 bf16 / SwiGLU stores as whole rows (wrong places)
 // FP8: operands are OCP e4m3 bytes.  The byte geometry of the tile is unchanged (128-B rows, so a
 // K-tile holds 128 k instead of 64); a lane's two 16-B fragment reads are the 32-byte operand of
 // ONE block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3, unit block scales), the form that
@@ -96,6 +96,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     const int t = threadIdx.x;
     const int lane = t & 63, wid = t >> 6;
     const int wm = wid >> 2, wn = wid & 3;
+    // FLUX2MI_GEMM_TRACE (tools/gemm_trace.py): per-workgroup s_memtime stamps of the production kernel —
+    // entry, first K-tile ready, K loop done, epilogue stores issued, stores retired — plus the hardware id
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0;
+#define G2_TR(v_) if (batch.trace) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v_)::"memory"); }
+    G2_TR(tr0)
 
     // ---- LDS-DMA source addresses: per kind, 2 instructions per thread.
     // instruction j of wave w fills slot bytes [(j*8+w)*1024, +1024): rows (j*8+w)*8 .. +8,
@@ -275,6 +280,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         G2_PHASE_END()
     }
     if (STAGGER && wm_u == 1) { G2_SYNC() }
+    G2_TR(tr1)
 
     if (ABL & 1) {  // operands read once; wrong results by design
         const uint8_t* st = smem;
@@ -316,6 +322,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     }
     }
     if (STAGGER && wm_u == 0) { G2_SYNC() }
+    G2_TR(tr2)
     if (DIAG && p.C2 != nullptr && lane == 0) {
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.C2) + ((size_t)blockIdx.x * 8 + wid) * 4;
         dbg[0] = dg_r; dbg[1] = dg_w1; dbg[2] = dg_m; dbg[3] = dg_w2 + (dg_dma << 32);
@@ -393,12 +400,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
                     uint32_t y0 = pack_bf16x2(vy[0], vy[1]), y1 = pack_bf16x2(vy[2], vy[3]);
                     swap16(x0, y0);
                     swap16(x1, y1);
+                    if (ABL & 64) {   // timing only: the same bytes as whole 128-B rows (8 full lines per instruction)
+                        const int fr = m0 + wm * 128 + i * 16 + jp * 8 + (lane >> 3);
+                        if (fr < p.M) *reinterpret_cast<uint4*>(C + (size_t)fr * p.ldc + n0 + wn * 64 + (lane & 7) * 8) = make_uint4(x0, x1, y0, y1);
+                    } else
                     if (row < p.M)
                         *reinterpret_cast<uint4*>(C + (size_t)row * p.ldc + wcol + jp * 32) = make_uint4(x0, x1, y0, y1);
                 }
             }
-            return;
-        }
+        } else
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = row_base + i * 16;
@@ -471,10 +481,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
                 uint32_t y0 = pack_bf16x2(oy[0], oy[1]), y1 = pack_bf16x2(oy[2], oy[3]);
                 swap16(x0, y0);
                 swap16(x1, y1);
+                if (ABL & 64) {
+                    const int fr = m0 + wm * 128 + (wn & 1) * 64 + i * 8 + (lane >> 3);
+                    const int fh = ((n0 - start) >> 1) + (wn >> 1) * 64 + (lane & 7) * 8;
+                    if (fr < p.M) *reinterpret_cast<uint4*>(C + (size_t)fr * p.ldc2 + fh) = make_uint4(x0, x1, y0, y1);
+                } else
                 if (row < p.M) *reinterpret_cast<uint4*>(C + (size_t)row * p.ldc2 + wh) = make_uint4(x0, x1, y0, y1);
             }
-            return;
-        }
+        } else
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = row_base + i * 16;
@@ -537,6 +551,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
             }
         }
     }
+    if (batch.trace) {
+        G2_TR(tr3)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        G2_TR(tr4)
+        if (lane == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* o = batch.trace + ((size_t)bid * 8 + wid) * 8;
+            o[0] = tr0; o[1] = tr1; o[2] = tr2; o[3] = tr3; o[4] = tr4;
+            o[5] = (unsigned long long)hw | ((unsigned long long)xcc << 32); o[6] = (unsigned long long)bid; o[7] = (unsigned long long)p.epi;
+        }
+    }
+#undef G2_TR
 }
 
 }  // namespace
@@ -558,6 +586,12 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
         return e ? atoi(e) : 1;
     }();
     b.flags = flags;
+    b.trace = nullptr;
+    static const char* trace_path = getenv("FLUX2MI_GEMM_TRACE");
+    static int trace_seen = 0;
+    const bool trace_now = trace_path && probs[0].epi == EPI_QKV_MLP && !probs[0].fp8 && ++trace_seen == 30;   // a warm linear1
+    const size_t trace_n = (size_t)(tiles[0] + tiles[1]) * 8 * 8;
+    if (trace_now && hipMalloc((void**)&b.trace, trace_n * 8) != hipSuccess) b.trace = nullptr;
 
     const bool fp8 = probs[0].fp8 != 0;
     if (fp8) {
@@ -580,8 +614,9 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
         const char* e = getenv("FLUX2MI_GEMM_VAR");
         return e ? atoi(e) : 3;
     }();
-    if (abl == 32) {
-        hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 32, false, false, false, 3>), grid, block, 0, stream, b);
+    if (abl == 32 || abl == 64) {
+        if (abl == 32) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 32, false, false, false, 3>), grid, block, 0, stream, b);
+        else hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 64, false, false, false, 3>), grid, block, 0, stream, b);
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
     if (var == 2 && abl == 0 && stagger == 0) {   // lockstep waves, one wait per K-tile (A/B only)
@@ -592,6 +627,13 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
         if (var == 1) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 1>), grid, block, 0, stream, b);
         else if (var == 2) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 2>), grid, block, 0, stream, b);
         else hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 3>), grid, block, 0, stream, b);
+        if (b.trace) {
+            std::vector<unsigned long long> h(trace_n);
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(h.data(), b.trace, trace_n * 8, hipMemcpyDeviceToHost);
+            (void)hipFree(b.trace);
+            if (FILE* f = fopen(trace_path, "wb")) { fwrite(h.data(), 8, trace_n, f); fclose(f); }
+        }
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
     static const int diag = [] {

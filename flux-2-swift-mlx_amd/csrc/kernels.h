@@ -37,6 +37,7 @@ struct GemmBatch {
     int nprob;
     int tile_start1;
     int flags;    // gemm256: bit 0 = 16-byte bf16 epilogue stores
+    unsigned long long* trace;   // gemm256: per-wave time stamps (dev tool), nullptr normally
 };
 int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob);
 
