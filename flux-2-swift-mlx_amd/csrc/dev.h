@@ -31,7 +31,13 @@ __device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float 
     return (uint32_t)w;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp each; every use rounds the result to bf16 or feeds a
+// bf16 GEMM).  The IEEE division `x / (1 + expf(-x))` costs ~12 VALU instructions per element
+// (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup): in the SwiGLU epilogue of a 256x256 GEMM tile that
+// was ~800 instructions per lane.
+__device__ __forceinline__ float silu_f(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

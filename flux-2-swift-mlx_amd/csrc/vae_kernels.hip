@@ -235,17 +235,25 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
+// The grid is sized so that (total threads) % cpb == 0: a thread then sees the same 8 channels in every
+// iteration, its 16 affine coefficients stay in registers and no per-chunk modulo is needed (the 64-bit
+// `i % cpb` + 16 dependent loads of the first form ran at a quarter of the HBM rate).
 __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
                                                        int64_t nchunks, int cpb, const float* __restrict__ ab, int C,
                                                        int silu) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cpb) * 8;
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    const int c0 = (int)(tid % (uint32_t)cpb) * 8;
+    float ca[8], cb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ca[j] = ab[c0 + j]; cb[j] = ab[C + c0 + j]; }
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = tid; i < nchunks; i += stride) {
         const uint4 v = reinterpret_cast<const uint4*>(x)[i];
         float f[8] = {lo_bf16(v.x), hi_bf16(v.x), lo_bf16(v.y), hi_bf16(v.y),
                       lo_bf16(v.z), hi_bf16(v.z), lo_bf16(v.w), hi_bf16(v.w)};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float o = ab[c0 + j] * f[j] + ab[C + c0 + j];
+            float o = ca[j] * f[j] + cb[j];
             if (silu) o = silu_f(o);
             f[j] = o;
         }
@@ -383,6 +391,13 @@ int launch_groupnorm_apply(hipStream_t stream, const uint16_t* x, uint16_t* y, i
     const int64_t nchunks = pixels * (C >> 3);
     int64_t blocks = (nchunks + 255) / 256;
     if (blocks > 8192) blocks = 8192;
+    // blocks * 256 must be a multiple of cpb = C/8 (see the kernel): round up to a multiple of cpb / gcd(cpb, 256)
+    {
+        int cpb = C >> 3, g = cpb, r = 256;
+        while (r) { const int tmp = g % r; g = r; r = tmp; }
+        const int64_t unit = cpb / g;
+        blocks = (blocks + unit - 1) / unit * unit;
+    }
     hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y, nchunks, C >> 3, ab, C,
                        silu);
     VK_DONE();
