@@ -11,6 +11,7 @@
 //     per-channel affine (a_c, b_c); apply (+SiLU) is one bf16 pass.
 #include "dev.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -154,6 +155,136 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a, int Ho, int Wo,
     }
 }
 
+// ---------------------------------------------------------------- conv2d, 128x128x64 tile
+// The decoder's heavy convolutions (Cin % 64 == 0, bf16 NHWC output): implicit GEMM with a 128-pixel x
+// 128-channel tile and a K-step of one tap x 64 input channels.  4 waves as 2 x 2, wave tile 64 x 64 =
+// 4 x 4 MFMA 16x16x32 per 32 k (the 32-pixel x 128-channel wave tile of conv2d_kernel reads 160 B of LDS per
+// CU-clock at full MFMA rate; this shape 128), LDS 2 x [A 128x64 | W 128x64] bf16 = 64 KB XOR-swizzled, two
+// workgroups per CU, operands staged through registers (issued before the MFMAs of a K-step, written to
+// LDS after them), one barrier per K-step.  The weight fragment is the MFMA's A operand, so a lane holds 4
+// CONSECUTIVE output channels of one pixel: bias, residual and the store are 16 / 8 / 8-byte accesses.
+__global__ __launch_bounds__(256, 2) void conv2d_g128_kernel(ConvArgs a, int Ho, int Wo, int cout_pad) {
+    constexpr int TM = 128, TN = 128, TK = 64;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * 2 * TM * TK * 2];   // 64 KB
+
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int P = Ho * Wo;
+    const int tiles_m = (P + TM - 1) / TM, tiles_n = (a.Cout + TN - 1) / TN;
+    // XCD remap: workgroups with equal (blockIdx % 8) share an XCD; give each a contiguous run of tiles, the
+    // N-tiles of one pixel block adjacent (they re-read the same activation rows from that XCD's L2)
+    int tm, tn;
+    {
+        const int ntiles = tiles_m * tiles_n, q = ntiles >> 3, r = ntiles & 7;
+        const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+        const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+        tm = idx / tiles_n;
+        tn = idx - tm * tiles_n;
+    }
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int taps = a.ks * a.ks, pad = a.ks >> 1;
+    const int cblocks = a.Cin / TK;
+    const int nk = taps * cblocks;
+    const int up = a.upsample;
+    const int stride = a.downsample ? 2 : 1;
+    const int pad_tl = a.downsample ? 0 : pad;
+    const int Hv = a.Hin << up, Wv = a.Win << up;
+
+    // ---- staging: 4 x 16 B per operand per thread: rows (t >> 3) + 32 i, chunk t & 7
+    const int chunk = t & 7;
+    int a_y[4], a_x[4], lds_off[4];
+    const uint16_t* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (t >> 3) + 32 * i;
+        const int p = m0 + row;
+        const bool ok = p < P;
+        const int pp = ok ? p : 0;
+        a_y[i] = ok ? (pp / Wo) * stride - pad_tl : -100000;   // a dead row is out of bounds for every tap
+        a_x[i] = (pp % Wo) * stride - pad_tl;
+        w_src[i] = a.w + (size_t)min(n0 + row, cout_pad - 1) * taps * a.Cin + chunk * 8;
+        lds_off[i] = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    }
+    u32x4 a_reg[4], w_reg[4];
+#define CG_LOAD(kt_)                                                                                           \
+    {                                                                                                          \
+        const int tap_ = (kt_) / cblocks, cb_ = (kt_) - tap_ * cblocks;                                        \
+        const int ky_ = tap_ / a.ks, kx_ = tap_ - ky_ * a.ks;                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                     \
+            const int iy_ = a_y[i_] + ky_, ix_ = a_x[i_] + kx_;                                                \
+            u32x4 v_ = {0u, 0u, 0u, 0u};                                                                       \
+            if (iy_ >= 0 && iy_ < Hv && ix_ >= 0 && ix_ < Wv)                                                  \
+                v_ = *reinterpret_cast<const u32x4*>(a.x + ((size_t)(iy_ >> up) * a.Win + (ix_ >> up)) * a.Cin + cb_ * TK + chunk * 8); \
+            a_reg[i_] = v_;                                                                                    \
+            w_reg[i_] = *reinterpret_cast<const u32x4*>(w_src[i_] + (size_t)(kt_) * TK);                       \
+        }                                                                                                      \
+    }
+#define CG_STORE(buf_)                                                                                         \
+    {                                                                                                          \
+        uint8_t* base_ = smem + (buf_) * (2 * TM * TK * 2);                                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                     \
+            *reinterpret_cast<u32x4*>(base_ + lds_off[i_]) = a_reg[i_];                                        \
+            *reinterpret_cast<u32x4*>(base_ + TM * TK * 2 + lds_off[i_]) = w_reg[i_];                          \
+        }                                                                                                      \
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    const int sw = (frow >> 1) & 7;
+    CG_LOAD(0)
+    CG_STORE(0)
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) CG_LOAD(kt + 1)
+        const uint8_t* sa = smem + buf * (2 * TM * TK * 2);
+        const uint8_t* sb = sa + TM * TK * 2;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int coff = (((kk * 4 + fq) ^ sw) << 4);
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + (wm * 64 + i * 16 + frow) * 128 + coff);
+                bf[i] = *reinterpret_cast<const bf16x8*>(sb + (wn * 64 + i * 16 + frow) * 128 + coff);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) CG_STORE(buf ^ 1)
+        __syncthreads();
+    }
+#undef CG_LOAD
+#undef CG_STORE
+
+    // ---- epilogue: acc[i][j][r] = pixel m0 + wm*64 + i*16 + frow, channel n0 + wn*64 + j*16 + fq*4 + r
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + fq * 4;
+        if (col >= a.Cout) continue;                      // Cout % 4 == 0 (launcher)
+        const float4 bs = a.bias ? *reinterpret_cast<const float4*>(a.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = m0 + wm * 64 + i * 16 + frow;
+            if (p >= P) continue;
+            float v0 = acc[i][j][0] + bs.x, v1 = acc[i][j][1] + bs.y, v2 = acc[i][j][2] + bs.z, v3 = acc[i][j][3] + bs.w;
+            if (a.resid) {
+                const uint2 rv = *reinterpret_cast<const uint2*>(a.resid + (size_t)p * a.Cout + col);
+                v0 += lo_bf16(rv.x); v1 += hi_bf16(rv.x); v2 += lo_bf16(rv.y); v3 += hi_bf16(rv.y);
+            }
+            *reinterpret_cast<uint2*>(a.y + (size_t)p * a.Cout + col) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        }
+    }
+}
+
 // ---------------------------------------------------------------- GroupNorm
 // stage 1: per-workgroup partial (sum, sumsq) per group.  Thread owns a fixed 8-channel
 // chunk and strides over pixels.  The per-thread sums are combined per group in a FIXED order (no
@@ -203,19 +334,36 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
                                                           float* __restrict__ ab) {
     __shared__ double dsum[64], dsq[64];
     __shared__ float gmean[64], grstd[64];
+    __shared__ double ps[256], pq[256];
     const int t = threadIdx.x;
-    // 4 threads per group (groups <= 64)
-    const int g = t >> 2, part = t & 3;
+    // thread = (block lane bl, group g): consecutive threads read consecutive float2 of one block's row of
+    // partials; 8 independent loads in flight per thread (the first form's one dependent load per iteration
+    // made this single-workgroup kernel 50 us long), lanes combined in a fixed order through LDS
+    const int nbl = 256 / groups;          // groups <= 64 (launcher)
+    const int g = t % groups, bl = t / groups;
     double s = 0.0, q = 0.0;
-    if (g < groups) {
-        for (int b = part; b < nblocks; b += 4) {
-            s += (double)partial[((size_t)b * groups + g) * 2 + 0];
-            q += (double)partial[((size_t)b * groups + g) * 2 + 1];
+    if (bl < nbl) {
+        const float2* pp = reinterpret_cast<const float2*>(partial);
+        int b = bl;
+        for (; b + 7 * nbl < nblocks; b += 8 * nbl) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(b + u * nbl) * groups + g];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s += (double)v[u].x; q += (double)v[u].y; }
+        }
+        for (; b < nblocks; b += nbl) {
+            const float2 v = pp[(size_t)b * groups + g];
+            s += (double)v.x; q += (double)v.y;
         }
     }
-    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
-    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2);
-    if (g < groups && part == 0) { dsum[g] = s; dsq[g] = q; }
+    ps[t] = s; pq[t] = q;
+    __syncthreads();
+    if (t < groups) {
+        double ss = 0.0, qq = 0.0;
+        for (int l = 0; l < nbl; ++l) { ss += ps[l * groups + t]; qq += pq[l * groups + t]; }
+        dsum[t] = ss; dsq[t] = qq;
+    }
     __syncthreads();
     if (t < groups) {
         const double n = (double)pixels * (double)(C / groups);
@@ -350,6 +498,18 @@ int launch_conv2d(hipStream_t stream, const ConvArgs& a) {
     const int P = Ho * Wo;
     const int tiles_m = (P + CBM - 1) / CBM;
     const int cout_pad = ((a.Cout + 31) / 32) * 32;
+    // the heavy decoder / encoder convolutions: 128x128x64 tiles (FLUX2MI_CONV=32 keeps the first kernel, A/B runs)
+    static const int conv_force = [] {
+        const char* e = getenv("FLUX2MI_CONV");
+        return e ? atoi(e) : 0;
+    }();
+    if (conv_force != 32 && a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.Cout >= 128 && a.y && !a.y_f32_nchw && !a.y_u8_hwc &&
+        (reinterpret_cast<uintptr_t>(a.y) & 7) == 0 && (!a.resid || (reinterpret_cast<uintptr_t>(a.resid) & 7) == 0) &&
+        (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0)) {
+        const int tm128 = (P + 127) / 128, tn128 = (a.Cout + 127) / 128;
+        hipLaunchKernelGGL(conv2d_g128_kernel, dim3(tm128 * tn128), dim3(256), 0, stream, a, Ho, Wo, cout_pad);
+        VK_DONE();
+    }
     int bn;
     if (a.Cout % 128 == 0) bn = 128;
     else if (a.Cout % 96 == 0) bn = 96;
