@@ -80,7 +80,11 @@ __device__ __forceinline__ void tile_coords256(int local, int ntiles, int tiles_
 // does not see.  The epilogue multiplies by a_scale[row] * w_scale[col].
 // VAR (schedule experiments, FLUX2MI_GEMM_VAR): bit 0 = wait for the fragment reads AFTER the phase's first
 // barrier; bit 1 = one counted vmcnt per K-tile (before the first barrier of phase 3) instead of one per phase.
-template <bool STAGGER, int ABL, bool HALFBAR = false, bool DIAG = false, bool FP8 = false, int VAR = 0>
+// NI: MFMA row blocks per wave (8 = the 256-row tile; 7, 6, 5 = 224, 192, 160 rows).  The shorter tiles exist for
+// wave quantisation only: M = 4608 x N = 3072 is 216 tiles of 256^2 on 256 CUs but 252 tiles of 224 x 256, one round
+// either way, so the launch takes 7/8 of the time.  A wave-row keeps its first 64 rows as half-tile A0 and the
+// remaining NI*16 - 64 as A1 (the A1 slot is still filled with 64 rows per wave-row: the surplus is never read).
+template <bool STAGGER, int ABL, bool HALFBAR = false, bool DIAG = false, bool FP8 = false, int VAR = 0, int NI = 8>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch batch) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE2_BYTES];  // 128 KB, the ONLY LDS object
 
@@ -88,10 +92,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     const int pi = (batch.nprob > 1 && bid >= batch.tile_start1) ? 1 : 0;
     const GemmProblem& p = batch.p[pi];
     const int local = bid - (pi ? batch.tile_start1 : 0);
-    const int tiles_m = (p.M + BM2 - 1) / BM2, tiles_n = (p.N + BN2 - 1) / BN2;
+    constexpr int BMT = 32 * NI;     // tile rows
+    constexpr int WROWS = 16 * NI;   // rows of one wave-row
+    constexpr int NI1 = NI - 4;      // row blocks of the second half-tile
+    const int tiles_m = (p.M + BMT - 1) / BMT, tiles_n = (p.N + BN2 - 1) / BN2;
     int tm, tn;
     tile_coords256(local, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * BM2, n0 = tn * BN2;
+    const int m0 = tm * BMT, n0 = tn * BN2;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wid = t >> 6;
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     for (int j = 0; j < 2; ++j) {
         const int rho = (j * 8 + wid) * 8 + (lane >> 3);             // slot row 0..127
         const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
-        const int a_row0 = (rho >> 6) * 128 + (rho & 63);            // A0: wave-row's first 64 rows
+        const int a_row0 = (rho >> 6) * WROWS + (rho & 63);          // A0: wave-row's first 64 rows
         const int b_row0 = (rho >> 5) * 64 + (rho & 31);             // B0: wave-col's first 32 rows
         src[KIND_A0][j] = gA + (size_t)min(m0 + a_row0, p.M - 1) * p.lda * ES + chunk * 16;
         src[KIND_A1][j] = gA + (size_t)min(m0 + a_row0 + 64, p.M - 1) * p.lda * ES + chunk * 16;
@@ -135,9 +142,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         }                                                                                                     \
     }
 
-    f32x4 acc[8][4];
+    f32x4 acc[NI][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     bf16x8 a[4][2], b0[2][2], b1[2][2];
 
 #define G2_READ_A(slot_)                                                                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < ((slot_) == KIND_A1 ? NI1 : 4); ++i_) {        \
         const uint8_t* r__ = st + (slot_) * SLOT_BYTES + a_frag + i_ * 2048;               \
         a[i_][0] = *reinterpret_cast<const bf16x8*>(r__ + c0);                             \
         a[i_][1] = *reinterpret_cast<const bf16x8*>(r__ + c1);                             \
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         if (FP8) {                                                                                       \
             /* one block-scaled 16x16x128 per (i, j): the lane's 32 bytes are its two 16-B chunks;  */   \
             /* scales are e8m0 127 = 1.0 (the real scales are per row/column, applied in the epilogue) */ \
-            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                           \
+            _Pragma("unroll") for (int i_ = 0; i_ < ((mh_) ? NI1 : 4); ++i_) {                                           \
                 const i32x8 a8__ = __builtin_shufflevector(__builtin_bit_cast(i32x4, a[i_][0]),          \
                                                            __builtin_bit_cast(i32x4, a[i_][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
                 _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                       \
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
             }                                                                                            \
         } else {                                                                                         \
             _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                          \
-                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
+                _Pragma("unroll") for (int i_ = 0; i_ < ((mh_) ? NI1 : 4); ++i_)                                         \
                     _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                     \
                         acc[(mh_) * 4 + i_][(nh_) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(  \
                             bsrc_[j_][kk_], a[i_][kk_], acc[(mh_) * 4 + i_][(nh_) * 2 + j_], 0, 0, 0);   \
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     // output row m0 + wm*128 + i*16 + frow, the FOUR CONSECUTIVE columns n0 + wn*64 + j*16 + fq*4 + r.
     // Every store is then 16 B (f32) or 8 B (bf16) per lane instead of 4 / 2 B: a quarter of the
     // memory instructions (the scalar form spent ~17k cycles per tile in the store queue).
-    const int row_base = m0 + wm * 128 + frow;
+    const int row_base = m0 + wm * WROWS + frow;
     const int col_base = n0 + wn * 64 + fq * 4;
     if ((ABL & 32) && p.alpha != 12345.f) return;   // timing only: the K loop without its epilogue
     int epi = p.epi;
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
 #pragma unroll
             for (int r = 0; r < 4; ++r) ws[j][r] = p.w_scale[min(col_base + j * 16 + r, p.N - 1)];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const float as = p.a_scale[min(row_base + i * 16, p.M - 1)];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         float* C = reinterpret_cast<float*>(p.C);
         const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int row = row_base + i * 16;
             if (row < p.M) {
 #pragma unroll
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
             // 16-byte stores: half the store instructions of the 8-byte form below
             const int wcol = n0 + wn * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 const int row = row_base + i * 16;
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
                     swap16(x0, y0);
                     swap16(x1, y1);
                     if (ABL & 64) {   // timing only: the same bytes as whole 128-B rows (8 full lines per instruction)
-                        const int fr = m0 + wm * 128 + i * 16 + jp * 8 + (lane >> 3);
+                        const int fr = m0 + wm * WROWS + i * 16 + jp * 8 + (lane >> 3);
                         if (fr < p.M) *reinterpret_cast<uint4*>(C + (size_t)fr * p.ldc + n0 + wn * 64 + (lane & 7) * 8) = make_uint4(x0, x1, y0, y1);
                     } else
                     if (row < p.M)
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
             }
         } else
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int row = row_base + i * 16;
             if (row < p.M) {
 #pragma unroll
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
                 g[j][r] = (col < p.N) ? p.vec[col] : 0.f;
             }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int row = row_base + i * 16;
             if (row < p.M) {
 #pragma unroll
@@ -469,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         if ((batch.flags & 1) && (p.ldc2 & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && n0 + BN2 <= p.N) {
             const int wh = ((n0 + wn * 64 - start) >> 1) + (fq & 1) * 16 + (fq >> 1) * 8;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 const int row = row_base + i * 16;
                 float ox[4], oy[4];
 #pragma unroll
@@ -482,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
                 swap16(x0, y0);
                 swap16(x1, y1);
                 if (ABL & 64) {
-                    const int fr = m0 + wm * 128 + (wn & 1) * 64 + i * 8 + (lane >> 3);
+                    const int fr = m0 + wm * WROWS + (wn & 1) * 64 + i * 8 + (lane >> 3);
                     const int fh = ((n0 - start) >> 1) + (wn >> 1) * 64 + (lane & 7) * 8;
                     if (fr < p.M) *reinterpret_cast<uint4*>(C + (size_t)fr * p.ldc2 + fh) = make_uint4(x0, x1, y0, y1);
                 } else
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
             }
         } else
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int row = row_base + i * 16;
             if (row < p.M) {
 #pragma unroll
@@ -523,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
                 bsv[j][r] = (p.vec != nullptr && col < p.N) ? p.vec[col] : 0.f;
             }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int row = row_base + i * 16;
             if (row < p.M) {
 #pragma unroll
@@ -573,11 +580,38 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
 int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
     GemmBatch b;
     b.nprob = nprob;
-    int tiles[2] = {0, 0};
-    for (int i = 0; i < nprob; ++i) {
-        b.p[i] = probs[i];
-        tiles[i] = ((probs[i].M + BM2 - 1) / BM2) * ((probs[i].N + BN2 - 1) / BN2);
+    // Tile height by wave quantisation: rounds of 256 workgroups x relative tile cost (+2 % per row block dropped for
+    // the lower arithmetic intensity); ties keep the taller tile.  FLUX2MI_GEMM_NI=8 forces 256 rows (A/B runs).
+    static const int ni_force = [] {
+        const char* e = getenv("FLUX2MI_GEMM_NI");
+        return e ? atoi(e) : 0;
+    }();
+    auto count_tiles = [&](int ni, int* per) {
+        int tot = 0;
+        for (int i = 0; i < nprob; ++i) {
+            const int n = ((probs[i].M + 32 * ni - 1) / (32 * ni)) * ((probs[i].N + BN2 - 1) / BN2);
+            if (per) per[i] = n;
+            tot += n;
+        }
+        return tot;
+    };
+    // the ablation / diagnostic / schedule-variant instantiations only exist for the 256-row tile
+    static const bool dev_env = getenv("FLUX2MI_GEMM_ABLATE") || getenv("FLUX2MI_GEMM_VAR") || getenv("FLUX2MI_GEMM_STAGGER") ||
+                                getenv("FLUX2MI_GEMM_DIAG");
+    int ni = 8;
+    if (dev_env) ni = 8;
+    else if (ni_force >= 5 && ni_force <= 8) ni = ni_force;
+    else {
+        double best = 1e30;
+        for (int c = 8; c >= 5; --c) {
+            const int tot = count_tiles(c, nullptr);
+            const double cost = (double)((tot + 255) / 256) * (c / 8.0) * (1.0 + 0.02 * (8 - c));
+            if (cost < best * 0.97) { best = cost; ni = c; }   // a shorter tile must win by 3 %
+        }
     }
+    int tiles[2] = {0, 0};
+    for (int i = 0; i < nprob; ++i) b.p[i] = probs[i];
+    count_tiles(ni, tiles);
     if (nprob == 1) b.p[1] = probs[0];
     b.tile_start1 = tiles[0];
     // bit 0: 16-byte bf16 / SwiGLU epilogue stores (FLUX2MI_GEMM_FLAGS=0 for A/B runs: linear1 0.617 -> 0.604 ms)
@@ -594,8 +628,15 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
     if (trace_now && hipMalloc((void**)&b.trace, trace_n * 8) != hipSuccess) b.trace = nullptr;
 
     const bool fp8 = probs[0].fp8 != 0;
+#define G2_GO_NI(FP8_)                                                                                                  \
+    switch (ni) {                                                                                                       \
+        case 7: hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, FP8_, 3, 7>), dim3(tiles[0] + tiles[1]), dim3(512), 0, stream, b); break; \
+        case 6: hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, FP8_, 3, 6>), dim3(tiles[0] + tiles[1]), dim3(512), 0, stream, b); break; \
+        case 5: hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, FP8_, 3, 5>), dim3(tiles[0] + tiles[1]), dim3(512), 0, stream, b); break; \
+        default: hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, FP8_, 3, 8>), dim3(tiles[0] + tiles[1]), dim3(512), 0, stream, b); break; \
+    }
     if (fp8) {
-        hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, true, 3>), dim3(tiles[0] + tiles[1]), dim3(512), 0, stream, b);
+        G2_GO_NI(true)
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
     static const int abl = [] {
@@ -626,7 +667,7 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
     if (var >= 1 && var <= 3 && abl == 0 && stagger == 1) {
         if (var == 1) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 1>), grid, block, 0, stream, b);
         else if (var == 2) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 2>), grid, block, 0, stream, b);
-        else hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 3>), grid, block, 0, stream, b);
+        else { G2_GO_NI(false) }
         if (b.trace) {
             std::vector<unsigned long long> h(trace_n);
             (void)hipStreamSynchronize(stream);

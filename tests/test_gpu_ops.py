@@ -184,6 +184,10 @@ def test_gemm_fp8_rejects_bad_k(ctx):
     (4500, 3000, 2048),    # ragged edges
     (4608, 3072, 64),      # a single K-tile
     (2304, 27648, 512),    # wide N
+    (1536, 8192, 512),     # tile height 192 (256 workgroups instead of 192 of 256x256)
+    (4608, 4096, 1024),    # Klein-9B width: tile height 160 (464 workgroups, 2 rounds of 5/8 tiles)
+    (4500, 4096, 512),     # the same with a ragged last row block
+    (4608, 6144, 512),     # Dev width: tile height 224
 ])
 def test_gemm_production_shapes_exact(ctx, M, N, K):
     """Integer-valued operands: every partial sum is exact in f32, so the result must equal the
@@ -228,6 +232,7 @@ def test_gemm_race_screen(ctx):
     (4500, 3000, 6144),    # ragged edges
     (4608, 3072, 3072),    # attention projection
     (2304, 3072, 12288),   # 512x512 image
+    (4608, 4096, 4096),    # Klein-9B width (tile height 160)
 ])
 def test_gemm_gate_resid_exact(ctx, M, N, K):
     """x += gate * (A W^T) on integer-valued data (every partial sum exact in f32): bit-exact against
