@@ -684,7 +684,7 @@ int ensure_workspace(flux2mi_dit* m, int S, int s_img) {
     }
     F2_TRY(m->comb.reserve(Sz * 4 * d * 2));
     F2_TRY(m->mods.reserve((size_t)(256 + 2 * d + 6 * d + 6 * d + 3 * d + 2 * d) * 4));
-    F2_TRY(m->rope.reserve(Sz * 128 * 4 * 2));
+    F2_TRY(m->rope.reserve(Sz * 128 * 4 * 2 + Sz * 4 * 4));   // cos, sin f32 [S,128] + positions f32 [S,4]
     F2_TRY(m->lat_bf16.reserve((size_t)s_img * 128 * 2));
     if (m->cfg.weight_format == 1) {
         F2_TRY(m->xq.reserve(Sz * 4 * d));
@@ -759,6 +759,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     uint16_t* comb = m->comb.as<uint16_t>();
     float* cos_tab = m->rope.as<float>();
     float* sin_tab = cos_tab + (size_t)S * 128;
+    float* pos_tab = sin_tab + (size_t)S * 128;
     // mods layout
     float* emb = m->mods.as<float>();          // [256]
     float* tmp = emb + 256;                    // [d]
@@ -785,15 +786,16 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     F2_LAUNCH(launch_gemv(st, m->final_mod, temb, mod_fin, 2 * d, d, 1, 0), "final_mod");
     // ---- RoPE tables from the ids of this call (Flux2Transformer.swift:153-154, :370-371)
     if (mode == FWD_PLAIN) {
-        F2_LAUNCH(launch_rope_tables(st, txt_ids, s_txt, img_ids, s_lat, cos_tab, sin_tab), "rope_tables");
+        F2_LAUNCH(launch_rope_tables(st, txt_ids, s_txt, img_ids, s_lat, cos_tab, sin_tab, pos_tab), "rope_tables");
     } else {
         // [txt | ref] rows (the gap rows of a cached pass get their ids too when given; unused otherwise)
         if (mode == FWD_KV_EXTRACT) {
-            F2_LAUNCH(launch_rope_tables(st, txt_ids, s_txt, ref_ids, s_ref, cos_tab, sin_tab), "rope_tables(txt,ref)");
+            F2_LAUNCH(launch_rope_tables(st, txt_ids, s_txt, ref_ids, s_ref, cos_tab, sin_tab, pos_tab), "rope_tables(txt,ref)");
         } else {
-            F2_LAUNCH(launch_rope_tables(st, txt_ids, s_txt, img_ids, 0, cos_tab, sin_tab), "rope_tables(txt)");
+            F2_LAUNCH(launch_rope_tables(st, txt_ids, s_txt, img_ids, 0, cos_tab, sin_tab, pos_tab), "rope_tables(txt)");
         }
-        F2_LAUNCH(launch_rope_tables(st, txt_ids, 0, img_ids, s_lat, cos_tab + (size_t)out0 * 128, sin_tab + (size_t)out0 * 128),
+        F2_LAUNCH(launch_rope_tables(st, txt_ids, 0, img_ids, s_lat, cos_tab + (size_t)out0 * 128, sin_tab + (size_t)out0 * 128,
+                                     pos_tab + (size_t)out0 * 4),
                   "rope_tables(out)");
     }
 
@@ -885,6 +887,14 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         return FLUX2MI_OK;
     };
 
+    // FLUX2MI_QK_FUSE=0: QK norm + RoPE as a separate kernel after the qkv projection (A/B runs).  The fused form needs
+    // whole heads inside a 256-column tile and the 256x256 bf16 kernel (>= 100 tiles, see launch_gemm).
+    static const bool qk_fuse_on = [] {
+        const char* e = getenv("FLUX2MI_QK_FUSE");
+        return e ? atoi(e) != 0 : true;
+    }();
+    const bool qk_fuse_ok = qk_fuse_on && !f8 && d % 256 == 0 && !getenv("FLUX2MI_GEMM") && !getenv("FLUX2MI_GEMM_V");
+    const bool qk_fuse_dbl = qk_fuse_ok && (long)((s_txt + 255) / 256 + (n_img + 255) / 256) * ((3 * d + 255) / 256) >= 100;
     // ---- double-stream blocks (Flux2TransformerBlock.swift:80-168)
     for (int i = 0; i < m->cfg.n_double; ++i) {
         const flux2mi_dit::Dbl& w = m->dbl[i];
@@ -894,8 +904,18 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
             GemmProblem p[2];
             p[0] = blk(xn, d, 0, w.qkv[0], qkv, 3 * d, s_txt, 3 * d, d, EPI_BF16);
             p[1] = blk(xn, d, img0, w.qkv[1], qkv + (size_t)img0 * 3 * d, 3 * d, n_img, 3 * d, d, EPI_BF16);
+            if (qk_fuse_dbl) {   // per-stream norm weights: one set per problem
+                for (int r = 0; r < 2; ++r) {
+                    p[r].qk_qw = w.qn[r]; p[r].qk_kw = w.kn[r]; p[r].qk_pos = pos_tab;
+                    p[r].qk_cols = 2 * d; p[r].qk_row0 = r ? img0 : 0; p[r].qk_qmul = q_mul;
+                    p[r].qk_l2t16 = log2f(2000.0f) / 16.0f;
+                }
+            }
             F2_TRY(run_gemm(m, p, 2, 0, "dbl.qkv"));
         }
+        if (qk_fuse_dbl) {
+            F2_LAUNCH(launch_v_transpose_only(st, qkv, 3 * d, S, H, vt, s_pad), "v_transpose");
+        } else
         F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, s_txt, w.qn[0], w.kn[0], w.qn[1], w.kn[1], cos_tab, sin_tab,
                                          vt, s_pad, q_mul), "qk_norm_rope");
         F2_TRY(attend(i, comb, d, w.score_bound));
@@ -934,6 +954,9 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     // on the same weights
     const int n_rng = img0 == s_txt ? 1 : 2;
     const int rng0[2] = {0, img0}, rngn[2] = {img0 == s_txt ? S : s_txt, n_img};
+    long lin1_tiles = 0;
+    for (int r = 0; r < n_rng; ++r) lin1_tiles += (long)((rngn[r] + 255) / 256) * ((9 * d + 255) / 256);
+    const bool qk_fuse = qk_fuse_ok && lin1_tiles >= 100;
     for (int i = 0; i < m->cfg.n_single; ++i) {
         const flux2mi_dit::Sgl& w = m->sgl[i];
         F2_LAUNCH(ln_mod(mod_sgl, mod_sgl + d, mod_sgl, mod_sgl + d), "ln_mod(single)");
@@ -944,9 +967,17 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
                 p[r].n_split = 3 * d;
                 p[r].C2 = comb + (size_t)rng0[r] * 4 * d + d;  // SwiGLU hidden goes to columns d..4d of comb
                 p[r].ldc2 = 4 * d;
+                if (qk_fuse) {   // per-head RMSNorm + RoPE of q | k in the GEMM epilogue (no separate pass over qkv)
+                    p[r].qk_qw = w.qn; p[r].qk_kw = w.kn; p[r].qk_pos = pos_tab;
+                    p[r].qk_cols = 2 * d; p[r].qk_row0 = rng0[r]; p[r].qk_qmul = q_mul;
+                    p[r].qk_l2t16 = log2f(2000.0f) / 16.0f;   // theta 2000, 16 frequencies per axis (Flux2RoPE.swift:129-169)
+                }
             }
             F2_TRY(run_gemm(m, p, n_rng, PROF_LINEAR1, "single.linear1"));
         }
+        if (qk_fuse) {
+            F2_LAUNCH(launch_v_transpose_only(st, qkv, 3 * d, S, H, vt, s_pad), "v_transpose");
+        } else
         F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, 0, w.qn, w.kn, w.qn, w.kn, cos_tab, sin_tab, vt, s_pad, q_mul),
                   "qk_norm_rope");
         F2_TRY(attend(m->cfg.n_double + i, comb, 4 * d, w.score_bound));

@@ -326,6 +326,9 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
             const char* e = getenv("FLUX2MI_GEMM_V");
             return e ? atoi(e) : 2;
         }();
+        bool fused_qk = false;   // only the 256x256 kernel (gemm256.hip) applies GemmProblem::qk_*
+        for (int i = 0; i < nprob; ++i) fused_qk |= probs[i].qk_qw != nullptr;
+        if (fused_qk && !((force == 256 || (force != 128 && big)) && ver == 2)) return 1;
         if (force == 256 || (force != 128 && big))
             return ver == 5 ? launch_gemm_ws(stream, probs, nprob)
                  : ver == 4 ? launch_gemm256_r4(stream, probs, nprob)

@@ -370,6 +370,79 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         }
     }
 
+    if (!FP8 && p.qk_qw != nullptr && epi == EPI_BF16 && n0 < p.qk_cols) {   // (bf16 only: the e4m3 epilogue has no registers left for it)
+        // ---- fused QK RMSNorm + RoPE (Flux2Attention.swift:137-157).  A 256-column tile is two heads: waves wn 0,1
+        // hold head A's 128 columns, wn 2,3 head B's.  Sum of squares: 16 values in the lane, the 4 fq lanes of a row
+        // by two lane exchanges, the partner wave through LDS (free now; one barrier on each side).
+        float2 ps[NI];                                  // positions of the wave's two RoPE axes, per row block
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            ps[i] = *reinterpret_cast<const float2*>(p.qk_pos + (size_t)(p.qk_row0 + min(row_base + i * 16, p.M - 1)) * 4 + (wn & 1) * 2);
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);   // [8 waves][128 rows]
+        float ss[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float t2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t2 += acc[i][j][r] * acc[i][j][r];
+            t2 += __shfl_xor(t2, 16);
+            t2 += __shfl_xor(t2, 32);
+            ss[i] = t2;
+        }
+        if (fq == 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) red[wid * 128 + i * 16 + frow] = ss[i];
+        }
+        __syncthreads();
+        const bool is_k = n0 >= (p.qk_cols >> 1);
+        const uint16_t* wv = (is_k ? p.qk_kw : p.qk_qw) + (wn & 1) * 64 + fq * 4;
+        const float qm = is_k ? 1.0f : p.qk_qmul;
+        float wj[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint2 u = *reinterpret_cast<const uint2*>(wv + j * 16);
+            wj[j][0] = lo_bf16(u.x) * qm; wj[j][1] = hi_bf16(u.x) * qm; wj[j][2] = lo_bf16(u.y) * qm; wj[j][3] = hi_bf16(u.y) * qm;
+        }
+        // the lane's columns inside the head: (wn&1)*64 + j*16 + fq*4 + r = axis (wn&1)*2 + (j>>1), pair (j&1)*8 + fq*2 + (r>>1)
+        // of that axis: four frequencies per lane, in revolutions (v_sin_f32 / v_cos_f32 take x / 2pi)
+        float wrev[2][2];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+                wrev[jb][pr] = __builtin_amdgcn_exp2f(-(float)(jb * 8 + fq * 2 + pr) * p.qk_l2t16) * 0.15915494309189535f;
+        uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+        const int wcol = n0 + wn * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float tot = ss[i] + red[(wid ^ 1) * 128 + i * 16 + frow];
+            const float rinv = rsqrtf(tot * (1.0f / 128.0f) + 1e-6f);
+            const int row = row_base + i * 16;
+            uint32_t pk[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pos = (j >> 1) ? ps[i].y : ps[i].x;
+                const float f0 = __builtin_amdgcn_fractf(pos * wrev[j & 1][0]), f1 = __builtin_amdgcn_fractf(pos * wrev[j & 1][1]);
+                const float c0 = __builtin_amdgcn_cosf(f0), s0 = __builtin_amdgcn_sinf(f0);
+                const float c1 = __builtin_amdgcn_cosf(f1), s1 = __builtin_amdgcn_sinf(f1);
+                const float a0 = acc[i][j][0] * rinv * wj[j][0], a1 = acc[i][j][1] * rinv * wj[j][1];
+                const float a2 = acc[i][j][2] * rinv * wj[j][2], a3 = acc[i][j][3] * rinv * wj[j][3];
+                pk[j][0] = pack_bf16x2(a0 * c0 - a1 * s0, a1 * c0 + a0 * s0);
+                pk[j][1] = pack_bf16x2(a2 * c1 - a3 * s1, a3 * c1 + a2 * s1);
+            }
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                swap16(pk[2 * jp][0], pk[2 * jp + 1][0]);
+                swap16(pk[2 * jp][1], pk[2 * jp + 1][1]);
+                if (row < p.M)
+                    *reinterpret_cast<uint4*>(C + (size_t)row * p.ldc + wcol + jp * 32) =
+                        make_uint4(pk[2 * jp][0], pk[2 * jp][1], pk[2 * jp + 1][0], pk[2 * jp + 1][1]);
+            }
+        }
+    } else
     if (epi == EPI_F32) {
         float* C = reinterpret_cast<float*>(p.C);
         const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
@@ -610,7 +683,14 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
         }
     }
     int tiles[2] = {0, 0};
-    for (int i = 0; i < nprob; ++i) b.p[i] = probs[i];
+    for (int i = 0; i < nprob; ++i) {
+        b.p[i] = probs[i];
+        const GemmProblem& q = probs[i];   // fused QK norm + RoPE: whole heads per tile, 16-byte row stores
+        if (q.qk_qw && (!q.qk_kw || !q.qk_pos || q.qk_cols % 512 != 0 || q.qk_cols > q.N || (q.N & 255) || (q.ldc & 7) ||
+                        (reinterpret_cast<uintptr_t>(q.C) & 15) || (q.epi != EPI_BF16 && q.epi != EPI_QKV_MLP) ||
+                        (q.epi == EPI_QKV_MLP && q.qk_cols > q.n_split) || dev_env || q.fp8))
+            return 1;
+    }
     count_tiles(ni, tiles);
     if (nprob == 1) b.p[1] = probs[0];
     b.tile_start1 = tiles[0];

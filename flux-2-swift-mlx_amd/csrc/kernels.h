@@ -31,6 +31,17 @@ struct GemmProblem {
     const float* a_scale;
     const float* w_scale;
     int fp8;
+    // 256x256 kernel, EPI_BF16 columns [0, qk_cols) (= q | k of a fused qkv projection, qk_cols = 2*dim, dim % 256 == 0):
+    // per-head RMSNorm (eps 1e-6, weights qk_qw / qk_kw bf16 [128]) + RoPE applied to the f32 accumulators before
+    // the store — what launch_qk_norm_rope_vt does in a separate pass over the stored bf16 values; q additionally
+    // times qk_qmul.  The rotation angles are computed in the epilogue from the positions qk_pos f32 [rows, 4]
+    // (launch_rope_tables' third output; table row = qk_row0 + row) and qk_l2t16 = log2(theta) / 16: v_sin / v_cos
+    // on pos * theta^(-k/16) / 2pi, no table traffic.  nullptr = off.
+    const uint16_t* qk_qw;
+    const uint16_t* qk_kw;
+    const float* qk_pos;
+    int qk_cols, qk_row0;
+    float qk_qmul, qk_l2t16;
 };
 struct GemmBatch {
     GemmProblem p[2];
@@ -109,8 +120,9 @@ int launch_f32_rows_to_bf16_cols(hipStream_t stream, const float* hs, uint16_t* 
 // padding) attend uniformly to keys 0..i (see attention.hip).  Operand layouts as launch_attention.
 int launch_attention_causal(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
                             int s_pad, uint16_t* out, int ldo, int S, int pad_lo, int valid_len, int heads, int kv_heads);
+// pos_tab (optional): f32 [S, 4], the ids as floats (the fused GEMM epilogue's input)
 int launch_rope_tables(hipStream_t stream, const int32_t* txt_ids, int s_txt, const int32_t* img_ids, int s_img,
-                       float* cos_tab, float* sin_tab);
+                       float* cos_tab, float* sin_tab, float* pos_tab = nullptr);
 
 // ---------------------------------------------------------------- small ops (elementwise.hip)
 // out f32[n] (+)= sum_k W[n,k] * f(x[k]); f = silu when silu_in; one wave per output row.

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_llm_kernel(uint16_t* __restr
 // omega = theta^(-2j/32), theta = 2000, value repeated for columns 2j, 2j+1.
 __global__ void rope_tables_kernel(const int32_t* __restrict__ txt_ids, int s_txt,
                                    const int32_t* __restrict__ img_ids, int s_img, float* __restrict__ cos_tab,
-                                   float* __restrict__ sin_tab) {
+                                   float* __restrict__ sin_tab, float* __restrict__ pos_tab) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (row, axis, j)
     const int S = s_txt + s_img;
     if (idx >= S * 64) return;
@@ -371,6 +371,7 @@ __global__ void rope_tables_kernel(const int32_t* __restrict__ txt_ids, int s_tx
     const size_t o = (size_t)row * 128 + axis * 32 + j * 2;
     cos_tab[o] = c; cos_tab[o + 1] = c;
     sin_tab[o] = s; sin_tab[o + 1] = s;
+    if (pos_tab != nullptr && j == 0) pos_tab[(size_t)row * 4 + axis] = pos;
 }
 
 }  // namespace
@@ -450,10 +451,10 @@ int launch_qk_norm_rope_llm_vt(hipStream_t stream, uint16_t* qkv, int S, int hq,
 }
 
 int launch_rope_tables(hipStream_t stream, const int32_t* txt_ids, int s_txt, const int32_t* img_ids, int s_img,
-                       float* cos_tab, float* sin_tab) {
+                       float* cos_tab, float* sin_tab, float* pos_tab) {
     const int total = (s_txt + s_img) * 64;
     if (total <= 0) return 1;
     hipLaunchKernelGGL(rope_tables_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, txt_ids, s_txt, img_ids,
-                       s_img, cos_tab, sin_tab);
+                       s_img, cos_tab, sin_tab, pos_tab);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
