@@ -144,6 +144,16 @@ def test_production_width_blocks(flux2mi, ctx):
     assert rel_l2(out, ref) < 2e-2
 
 
+def test_production_width_blocks_ragged(flux2mi, ctx):
+    """The same width with nothing aligned to the 256-row GEMM tiles (s_txt 77, 272x256 -> 272 image tokens, S 349):
+    the QK RMSNorm + RoPE runs in the qkv / linear1 GEMM epilogue here (>= 100 tiles), on partial row blocks, with
+    non-trivial H / W / L positions feeding the in-kernel rotation angles."""
+    cfg = dict(dim=3072, heads=24, n_double=1, n_single=1, joint_dim=7680, guidance=False)
+    out, ref = _forward_both(flux2mi, ctx, cfg, s_txt=77, h=272, w=256)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 2e-2
+
+
 # ---- weight_format 1: e4m3 block GEMMs ----------------------------------------------------------
 def _fp8_case(ctx, cfg, s_txt, h, w, std=0.05):
     from flux2mi import synthetic as syn
@@ -240,6 +250,17 @@ def test_kv_extract_and_cached_vs_oracle(flux2mi, ctx, preset, s_txt, h, w, ref_
     inputs reproduces its output (same keys, same values: <= 2e-3, bf16 rounding of split launches)."""
     from flux2mi import synthetic as syn
     (o0, o1), (h0, h1, h0_again) = _kv_case(ctx, syn.DIT_PRESETS[preset], s_txt, h, w, ref_hw)
+    assert torch.isfinite(h0).all() and torch.isfinite(h1).all()
+    assert rel_l2(h0, o0) < 2e-2
+    assert rel_l2(h1, o1) < 2e-2
+    assert rel_l2(h0_again, h0) < 2e-3
+
+
+def test_kv_extract_and_cached_production_width(flux2mi, ctx):
+    """KV extraction / cached passes at Klein-4B width: the fused QK norm + RoPE epilogue on the two live row ranges
+    of a cached pass ([txt] and [out] with the reference gap between them: table rows offset per range)."""
+    cfg = dict(dim=3072, heads=24, n_double=1, n_single=1, joint_dim=7680, guidance=False)
+    (o0, o1), (h0, h1, h0_again) = _kv_case(ctx, cfg, 64, 256, 256, (16, 16))
     assert torch.isfinite(h0).all() and torch.isfinite(h1).all()
     assert rel_l2(h0, o0) < 2e-2
     assert rel_l2(h1, o1) < 2e-2
