@@ -135,7 +135,7 @@ def main():
     if args.model == "klein-4b" and (H, W) == (1024, 1024) and args.weights == "bf16" and os.path.exists(tpath):
         with open(tpath) as f:
             traffic = json.load(f)["traffic_bytes_per_launch"]
-    roofline = {"bound": "mfma", "kernel": "gemm_bf16_256x256_kernel (single_blocks.linear1: [S,d] x [9d,d]^T, fused qkv store + SwiGLU)",
+    roofline = {"bound": "mfma", "kernel": "gemm_bf16_256x256_kernel (single_blocks.linear1: [S,d] x [9d,d]^T as two launches: [q|k] with fused RMSNorm+RoPE + SwiGLU rows, and V^T = W_v x^T)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),

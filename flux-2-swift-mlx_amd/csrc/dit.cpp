@@ -678,7 +678,9 @@ int ensure_workspace(flux2mi_dit* m, int S, int s_img) {
     F2_TRY(m->xn.reserve(Sz * d * 2));
     F2_TRY(m->qkv.reserve(Sz * 3 * d * 2));
     const size_t vt_bytes = (size_t)H * 128 * attn_s_pad(S) * 2;
-    if (m->vt.bytes < vt_bytes) {
+    // the columns of the padded keys must read as finite numbers (their probabilities are exactly 0).  The V^T
+    // GEMM only writes the valid keys, so the image is cleared whenever the sequence length (= the padding) changes.
+    if (m->vt.bytes < vt_bytes || m->ws_S != S) {
         F2_TRY(m->vt.reserve(vt_bytes));
         F2_CHECK_HIP(hipMemsetAsync(m->vt.ptr, 0, m->vt.bytes, m->ctx->stream));
     }
@@ -894,7 +896,17 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         return e ? atoi(e) != 0 : true;
     }();
     const bool qk_fuse_ok = qk_fuse_on && !f8 && d % 256 == 0 && !getenv("FLUX2MI_GEMM") && !getenv("FLUX2MI_GEMM_V");
-    const bool qk_fuse_dbl = qk_fuse_ok && (long)((s_txt + 255) / 256 + (n_img + 255) / 256) * ((3 * d + 255) / 256) >= 100;
+    // decided on the whole sequence S, not on the live rows of this pass: a KV-cached pass (fewer live rows) must
+    // treat q / k exactly like the extraction pass whose keys it reuses
+    const bool qk_fuse_dbl = qk_fuse_ok && (long)((S + 255) / 256) * ((3 * d + 255) / 256) >= 100;
+    // V^T straight out of a GEMM with the operands' roles swapped (A = the V rows of the fused weight, W = the
+    // activation, C = vt, key order permuted in the store): no V round trip through qkv, no transpose kernel.
+    // Plain forwards only (the KV-cache passes move reference columns of vt around on unaligned boundaries).
+    static const bool vt_gemm_on = [] {
+        const char* e = getenv("FLUX2MI_VT_GEMM");
+        return e ? atoi(e) != 0 : true;
+    }();
+    const bool vt_gemm = vt_gemm_on && mode == FWD_PLAIN && (s_txt & 15) == 0;
     // ---- double-stream blocks (Flux2TransformerBlock.swift:80-168)
     for (int i = 0; i < m->cfg.n_double; ++i) {
         const flux2mi_dit::Dbl& w = m->dbl[i];
@@ -902,8 +914,9 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         F2_LAUNCH(ln_mod(mod_txt + 0 * d, mod_txt + 1 * d, mod_img + 0 * d, mod_img + 1 * d), "ln_mod(attn)");
         {
             GemmProblem p[2];
-            p[0] = blk(xn, d, 0, w.qkv[0], qkv, 3 * d, s_txt, 3 * d, d, EPI_BF16);
-            p[1] = blk(xn, d, img0, w.qkv[1], qkv + (size_t)img0 * 3 * d, 3 * d, n_img, 3 * d, d, EPI_BF16);
+            const int nq = (qk_fuse_dbl && vt_gemm) ? 2 * d : 3 * d;   // [q|k] only: V^T comes from its own GEMM below
+            p[0] = blk(xn, d, 0, w.qkv[0], qkv, 3 * d, s_txt, nq, d, EPI_BF16);
+            p[1] = blk(xn, d, img0, w.qkv[1], qkv + (size_t)img0 * 3 * d, 3 * d, n_img, nq, d, EPI_BF16);
             if (qk_fuse_dbl) {   // per-stream norm weights: one set per problem
                 for (int r = 0; r < 2; ++r) {
                     p[r].qk_qw = w.qn[r]; p[r].qk_kw = w.kn[r]; p[r].qk_pos = pos_tab;
@@ -913,7 +926,13 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
             }
             F2_TRY(run_gemm(m, p, 2, 0, "dbl.qkv"));
         }
-        if (qk_fuse_dbl) {
+        if (qk_fuse_dbl && vt_gemm) {
+            GemmProblem pv[2];
+            pv[0] = mk(w.qkv[0].w + (size_t)2 * d * d, d, xn, d, vt, s_pad, d, s_txt, d, EPI_BF16);
+            pv[1] = mk(w.qkv[1].w + (size_t)2 * d * d, d, xn + (size_t)img0 * d, d, vt + img0, s_pad, d, n_img, d, EPI_BF16);
+            pv[0].col_perm16 = pv[1].col_perm16 = 1;
+            F2_TRY(run_gemm(m, pv, 2, 0, "dbl.vt"));
+        } else if (qk_fuse_dbl) {
             F2_LAUNCH(launch_v_transpose_only(st, qkv, 3 * d, S, H, vt, s_pad), "v_transpose");
         } else
         F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, s_txt, w.qn[0], w.kn[0], w.qn[1], w.kn[1], cos_tab, sin_tab,
@@ -954,12 +973,27 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     // on the same weights
     const int n_rng = img0 == s_txt ? 1 : 2;
     const int rng0[2] = {0, img0}, rngn[2] = {img0 == s_txt ? S : s_txt, n_img};
-    long lin1_tiles = 0;
-    for (int r = 0; r < n_rng; ++r) lin1_tiles += (long)((rngn[r] + 255) / 256) * ((9 * d + 255) / 256);
-    const bool qk_fuse = qk_fuse_ok && lin1_tiles >= 100;
+    const bool qk_fuse = qk_fuse_ok && (long)((S + 255) / 256) * ((9 * d + 255) / 256) >= 100;
     for (int i = 0; i < m->cfg.n_single; ++i) {
         const flux2mi_dit::Sgl& w = m->sgl[i];
         F2_LAUNCH(ln_mod(mod_sgl, mod_sgl + d, mod_sgl, mod_sgl + d), "ln_mod(single)");
+        if (qk_fuse && vt_gemm) {
+            // linear1 as [q | k] (fused norm + RoPE) and the SwiGLU rows in one launch, V^T in a second one
+            GemmProblem p[2];
+            p[0] = blk(xn, d, 0, w.lin1, qkv, 3 * d, S, 2 * d, d, EPI_BF16);
+            p[0].qk_qw = w.qn; p[0].qk_kw = w.kn; p[0].qk_pos = pos_tab;
+            p[0].qk_cols = 2 * d; p[0].qk_row0 = 0; p[0].qk_qmul = q_mul;
+            p[0].qk_l2t16 = log2f(2000.0f) / 16.0f;
+            W wmlp = w.lin1;
+            wmlp.w += (size_t)3 * d * d;
+            p[1] = blk(xn, d, 0, wmlp, nullptr, 0, S, 6 * d, d, EPI_SWIGLU);
+            p[1].C2 = comb + d;
+            p[1].ldc2 = 4 * d;
+            F2_TRY(run_gemm(m, p, 2, PROF_LINEAR1, "single.linear1(qk|mlp)"));
+            GemmProblem pv = mk(w.lin1.w + (size_t)2 * d * d, d, xn, d, vt, s_pad, d, S, d, EPI_BF16);
+            pv.col_perm16 = 1;
+            F2_TRY(run_gemm(m, &pv, 1, PROF_LINEAR1, "single.linear1(vt)"));
+        } else
         {
             GemmProblem p[2];
             for (int r = 0; r < n_rng; ++r) {
@@ -975,7 +1009,8 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
             }
             F2_TRY(run_gemm(m, p, n_rng, PROF_LINEAR1, "single.linear1"));
         }
-        if (qk_fuse) {
+        if (qk_fuse && vt_gemm) {
+        } else if (qk_fuse) {
             F2_LAUNCH(launch_v_transpose_only(st, qkv, 3 * d, S, H, vt, s_pad), "v_transpose");
         } else
         F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, 0, w.qn, w.kn, w.qn, w.kn, cos_tab, sin_tab, vt, s_pad, q_mul),

@@ -327,8 +327,9 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
             return e ? atoi(e) : 2;
         }();
         bool fused_qk = false;   // only the 256x256 kernel (gemm256.hip) applies GemmProblem::qk_*
-        for (int i = 0; i < nprob; ++i) fused_qk |= probs[i].qk_qw != nullptr;
-        if (fused_qk && !((force == 256 || (force != 128 && big)) && ver == 2)) return 1;
+        for (int i = 0; i < nprob; ++i) fused_qk |= probs[i].qk_qw != nullptr || probs[i].col_perm16 != 0;
+        if (fused_qk && (force == 128 || ver != 2)) return 1;
+        if (fused_qk) big = true;   // the caller decides fusion per model and sequence, not per launch (dit.cpp)
         if (force == 256 || (force != 128 && big))
             return ver == 5 ? launch_gemm_ws(stream, probs, nprob)
                  : ver == 4 ? launch_gemm256_r4(stream, probs, nprob)

@@ -50,6 +50,11 @@ __device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
 
+// v_permlane32_swap_b32 a, b: lanes 32-63 of a <-> lanes 0-31 of b (inline asm: see attention.hip's xhalf_swap)
+__device__ __forceinline__ void swap32(uint32_t& a, uint32_t& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+
 __device__ __forceinline__ void tile_coords256(int local, int ntiles, int tiles_m, int tiles_n, int& tm, int& tn) {
     const int q = ntiles >> 3, r = ntiles & 7;
     const int xcd = local & 7, within = local >> 3;
@@ -468,8 +473,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
         const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 7) == 0;
         if ((batch.flags & 1) && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && n0 + BN2 <= p.N) {
-            // 16-byte stores: half the store instructions of the 8-byte form below
-            const int wcol = n0 + wn * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
+            // 16-byte stores: half the store instructions of the 8-byte form below.  col_perm16: the four-column
+            // groups of a 16-group go fq 0,2,1,3, so the 16-byte runs pair fq with fq^2 (lanes l, l^32): after the
+            // exchange lanes fq 0,1 hold block 2jp at (fq&1)*8 and lanes fq 2,3 block 2jp+1
+            const int wcol = p.col_perm16 ? n0 + wn * 64 + (fq >> 1) * 16 + (fq & 1) * 8
+                                          : n0 + wn * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int row = row_base + i * 16;
@@ -478,8 +486,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
                     const f32x4 vx = acc[i][2 * jp] * p.alpha, vy = acc[i][2 * jp + 1] * p.alpha;
                     uint32_t x0 = pack_bf16x2(vx[0], vx[1]), x1 = pack_bf16x2(vx[2], vx[3]);
                     uint32_t y0 = pack_bf16x2(vy[0], vy[1]), y1 = pack_bf16x2(vy[2], vy[3]);
-                    swap16(x0, y0);
-                    swap16(x1, y1);
+                    if (p.col_perm16) {
+                        swap32(x0, y0);
+                        swap32(x1, y1);
+                    } else {
+                        swap16(x0, y0);
+                        swap16(x1, y1);
+                    }
                     if (ABL & 64) {   // timing only: the same bytes as whole 128-B rows (8 full lines per instruction)
                         const int fr = m0 + wm * WROWS + i * 16 + jp * 8 + (lane >> 3);
                         if (fr < p.M) *reinterpret_cast<uint4*>(C + (size_t)fr * p.ldc + n0 + wn * 64 + (lane & 7) * 8) = make_uint4(x0, x1, y0, y1);
@@ -495,8 +508,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
             if (row < p.M) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    // col = the output column (bounds), scol = where it is stored (col_perm16: a valid key of a
+                    // partial last group may land past N, inside the padded row)
                     const int col = col_base + j * 16;
-                    uint16_t* dst = C + (size_t)row * p.ldc + col;
+                    const int scol = p.col_perm16 ? n0 + wn * 64 + j * 16 + ((fq & 1) * 2 + (fq >> 1)) * 4 : col;
+                    uint16_t* dst = C + (size_t)row * p.ldc + scol;
                     const f32x4 v = acc[i][j] * p.alpha;
                     if (vec_ok && col + 3 < p.N) {
                         *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));

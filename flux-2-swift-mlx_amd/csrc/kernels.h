@@ -37,6 +37,10 @@ struct GemmProblem {
     // times qk_qmul.  The rotation angles are computed in the epilogue from the positions qk_pos f32 [rows, 4]
     // (launch_rope_tables' third output; table row = qk_row0 + row) and qk_l2t16 = log2(theta) / 16: v_sin / v_cos
     // on pos * theta^(-k/16) / 2pi, no table traffic.  nullptr = off.
+    // 256x256 kernel, EPI_BF16: inside every aligned group of 16 output columns, column 8a+4h+b is stored at 8h+4a+b
+    // (the key order of the attention's V^T operand, attention.hip).  With A = W_v [dim, K], W = the activation
+    // [S, K] and C = vt [dim, s_pad] the GEMM writes V^T directly: no V round trip, no transpose kernel.
+    int col_perm16;
     const uint16_t* qk_qw;
     const uint16_t* qk_kw;
     const float* qk_pos;
