@@ -131,7 +131,7 @@ def main():
     # HBM-side traffic of that kernel from the committed PMC passes (rocprofv3 cannot run inside this
     # process); null when the summary is not there or another model / size / format is benchmarked
     traffic = None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c_linear1_traffic.json")
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_h_linear1_traffic.json")
     if args.model == "klein-4b" and (H, W) == (1024, 1024) and args.weights == "bf16" and os.path.exists(tpath):
         with open(tpath) as f:
             traffic = json.load(f)["traffic_bytes_per_launch"]
