@@ -906,7 +906,8 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         const char* e = getenv("FLUX2MI_VT_GEMM");
         return e ? atoi(e) != 0 : true;
     }();
-    const bool vt_gemm = vt_gemm_on && mode == FWD_PLAIN && (s_txt & 15) == 0;
+    // (only when the V^T launch fills the chip on its own: at 256x256 it is 36 workgroups and the step got 12 % slower)
+    const bool vt_gemm = vt_gemm_on && mode == FWD_PLAIN && (s_txt & 15) == 0 && (long)((d + 255) / 256) * ((S + 255) / 256) >= 160;
     // ---- double-stream blocks (Flux2TransformerBlock.swift:80-168)
     for (int i = 0; i < m->cfg.n_double; ++i) {
         const flux2mi_dit::Dbl& w = m->dbl[i];
