@@ -163,8 +163,14 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a, int Ho, int Wo,
 // workgroups per CU, operands staged through registers (issued before the MFMAs of a K-step, written to
 // LDS after them), one barrier per K-step.  The weight fragment is the MFMA's A operand, so a lane holds 4
 // CONSECUTIVE output channels of one pixel: bias, residual and the store are 16 / 8 / 8-byte accesses.
+// TK = 64 (Cin % 64 == 0) or 32 (the 96-channel level of the small decoder: rows of 64 B, which ds_read_b128 reads
+// conflict-free without a swizzle; one MFMA k-step per barrier).
+template <int TK>
 __global__ __launch_bounds__(256, 2) void conv2d_g128_kernel(ConvArgs a, int Ho, int Wo, int cout_pad) {
-    constexpr int TM = 128, TN = 128, TK = 64;
+    constexpr int TM = 128, TN = 128;
+    constexpr int RB = TK * 2;            // bytes per LDS row
+    constexpr int CPR = TK / 8;           // 16-byte chunks per row
+    constexpr int NP = (TM * CPR) / 256;  // chunks per operand per thread
     __shared__ __attribute__((aligned(16))) uint8_t smem[2 * 2 * TM * TK * 2];   // 64 KB
 
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -190,27 +196,27 @@ __global__ __launch_bounds__(256, 2) void conv2d_g128_kernel(ConvArgs a, int Ho,
     const int pad_tl = a.downsample ? 0 : pad;
     const int Hv = a.Hin << up, Wv = a.Win << up;
 
-    // ---- staging: 4 x 16 B per operand per thread: rows (t >> 3) + 32 i, chunk t & 7
-    const int chunk = t & 7;
-    int a_y[4], a_x[4], lds_off[4];
-    const uint16_t* w_src[4];
+    // ---- staging: NP x 16 B per operand per thread: rows t / CPR + (256 / CPR) i, chunk t % CPR
+    const int chunk = t % CPR;
+    int a_y[NP], a_x[NP], lds_off[NP];
+    const uint16_t* w_src[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (t >> 3) + 32 * i;
+    for (int i = 0; i < NP; ++i) {
+        const int row = t / CPR + (256 / CPR) * i;
         const int p = m0 + row;
         const bool ok = p < P;
         const int pp = ok ? p : 0;
         a_y[i] = ok ? (pp / Wo) * stride - pad_tl : -100000;   // a dead row is out of bounds for every tap
         a_x[i] = (pp % Wo) * stride - pad_tl;
         w_src[i] = a.w + (size_t)min(n0 + row, cout_pad - 1) * taps * a.Cin + chunk * 8;
-        lds_off[i] = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+        lds_off[i] = TK == 64 ? row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) : row * 64 + (chunk << 4);
     }
-    u32x4 a_reg[4], w_reg[4];
+    u32x4 a_reg[NP], w_reg[NP];
 #define CG_LOAD(kt_)                                                                                           \
     {                                                                                                          \
         const int tap_ = (kt_) / cblocks, cb_ = (kt_) - tap_ * cblocks;                                        \
         const int ky_ = tap_ / a.ks, kx_ = tap_ - ky_ * a.ks;                                                  \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) {                                                    \
             const int iy_ = a_y[i_] + ky_, ix_ = a_x[i_] + kx_;                                                \
             u32x4 v_ = {0u, 0u, 0u, 0u};                                                                       \
             if (iy_ >= 0 && iy_ < Hv && ix_ >= 0 && ix_ < Wv)                                                  \
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_g128_kernel(ConvArgs a, int Ho,
 #define CG_STORE(buf_)                                                                                         \
     {                                                                                                          \
         uint8_t* base_ = smem + (buf_) * (2 * TM * TK * 2);                                                    \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) {                                                    \
             *reinterpret_cast<u32x4*>(base_ + lds_off[i_]) = a_reg[i_];                                        \
             *reinterpret_cast<u32x4*>(base_ + TM * TK * 2 + lds_off[i_]) = w_reg[i_];                          \
         }                                                                                                      \
@@ -245,13 +251,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_g128_kernel(ConvArgs a, int Ho,
         const uint8_t* sa = smem + buf * (2 * TM * TK * 2);
         const uint8_t* sb = sa + TM * TK * 2;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int coff = (((kk * 4 + fq) ^ sw) << 4);
+        for (int kk = 0; kk < TK / 32; ++kk) {
+            const int coff = TK == 64 ? (((kk * 4 + fq) ^ sw) << 4) : (fq << 4);
             bf16x8 af[4], bf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(sa + (wm * 64 + i * 16 + frow) * 128 + coff);
-                bf[i] = *reinterpret_cast<const bf16x8*>(sb + (wn * 64 + i * 16 + frow) * 128 + coff);
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + (wm * 64 + i * 16 + frow) * RB + coff);
+                bf[i] = *reinterpret_cast<const bf16x8*>(sb + (wn * 64 + i * 16 + frow) * RB + coff);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -503,11 +509,12 @@ int launch_conv2d(hipStream_t stream, const ConvArgs& a) {
         const char* e = getenv("FLUX2MI_CONV");
         return e ? atoi(e) : 0;
     }();
-    if (conv_force != 32 && a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.Cout >= 128 && a.y && !a.y_f32_nchw && !a.y_u8_hwc &&
+    if (conv_force != 32 && a.Cin % 32 == 0 && a.Cin >= 64 && a.Cout % 32 == 0 && a.Cout >= 96 && a.y && !a.y_f32_nchw && !a.y_u8_hwc &&
         (reinterpret_cast<uintptr_t>(a.y) & 7) == 0 && (!a.resid || (reinterpret_cast<uintptr_t>(a.resid) & 7) == 0) &&
         (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0)) {
         const int tm128 = (P + 127) / 128, tn128 = (a.Cout + 127) / 128;
-        hipLaunchKernelGGL(conv2d_g128_kernel, dim3(tm128 * tn128), dim3(256), 0, stream, a, Ho, Wo, cout_pad);
+        if (a.Cin % 64 == 0) hipLaunchKernelGGL(conv2d_g128_kernel<64>, dim3(tm128 * tn128), dim3(256), 0, stream, a, Ho, Wo, cout_pad);
+        else hipLaunchKernelGGL(conv2d_g128_kernel<32>, dim3(tm128 * tn128), dim3(256), 0, stream, a, Ho, Wo, cout_pad);
         VK_DONE();
     }
     int bn;
