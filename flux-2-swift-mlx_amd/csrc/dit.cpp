@@ -835,6 +835,27 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         }
         return p;
     };
+    // rows [r, ...) of a weight (bf16: 2 B per element, e4m3: 1 B) with their per-row scales
+    auto wrows = [&](const W& w, int r, int K) {
+        W o = w;
+        o.w = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(w.w) + (size_t)r * K * (f8 ? 1 : 2));
+        if (o.scale) o.scale += r;
+        return o;
+    };
+    // V^T [d, rows] = W_v [d, K] (activation rows [r0, r0 + rows))^T into vt columns r0.. (key order permuted in the store)
+    auto vt_problem = [&](const W& wv, int r0, int rows) {
+        GemmProblem p;
+        if (f8) {
+            p = mk(wv.w, d, reinterpret_cast<const uint16_t*>(xq + (size_t)r0 * d), d, vt + r0, s_pad, d, rows, d, EPI_BF16);
+            p.fp8 = 1;
+            p.a_scale = wv.scale;        // the A operand is the weight here: its per-row scales
+            p.w_scale = xs + r0;         // the W operand is the activation: its per-token scales
+        } else {
+            p = mk(wv.w, d, xn + (size_t)r0 * d, d, vt + r0, s_pad, d, rows, d, EPI_BF16);
+        }
+        p.col_perm16 = 1;
+        return p;
+    };
     // LayerNorm + modulate of the text rows with (sh0, sc0) and of the live image rows with (sh1, sc1)
     auto ln_mod = [&](const float* sh0, const float* sc0, const float* sh1, const float* sc1) {
         if (img0 == s_txt) {
@@ -895,7 +916,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         const char* e = getenv("FLUX2MI_QK_FUSE");
         return e ? atoi(e) != 0 : true;
     }();
-    const bool qk_fuse_ok = qk_fuse_on && !f8 && d % 256 == 0 && !getenv("FLUX2MI_GEMM") && !getenv("FLUX2MI_GEMM_V");
+    const bool qk_fuse_ok = qk_fuse_on && d % 256 == 0 && !getenv("FLUX2MI_GEMM") && !getenv("FLUX2MI_GEMM_V");
     // decided on the whole sequence S, not on the live rows of this pass: a KV-cached pass (fewer live rows) must
     // treat q / k exactly like the extraction pass whose keys it reuses
     const bool qk_fuse_dbl = qk_fuse_ok && (long)((S + 255) / 256) * ((3 * d + 255) / 256) >= 100;
@@ -929,9 +950,8 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         }
         if (qk_fuse_dbl && vt_gemm) {
             GemmProblem pv[2];
-            pv[0] = mk(w.qkv[0].w + (size_t)2 * d * d, d, xn, d, vt, s_pad, d, s_txt, d, EPI_BF16);
-            pv[1] = mk(w.qkv[1].w + (size_t)2 * d * d, d, xn + (size_t)img0 * d, d, vt + img0, s_pad, d, n_img, d, EPI_BF16);
-            pv[0].col_perm16 = pv[1].col_perm16 = 1;
+            pv[0] = vt_problem(wrows(w.qkv[0], 2 * d, d), 0, s_txt);
+            pv[1] = vt_problem(wrows(w.qkv[1], 2 * d, d), img0, n_img);
             F2_TRY(run_gemm(m, pv, 2, 0, "dbl.vt"));
         } else if (qk_fuse_dbl) {
             F2_LAUNCH(launch_v_transpose_only(st, qkv, 3 * d, S, H, vt, s_pad), "v_transpose");
@@ -985,14 +1005,11 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
             p[0].qk_qw = w.qn; p[0].qk_kw = w.kn; p[0].qk_pos = pos_tab;
             p[0].qk_cols = 2 * d; p[0].qk_row0 = 0; p[0].qk_qmul = q_mul;
             p[0].qk_l2t16 = log2f(2000.0f) / 16.0f;
-            W wmlp = w.lin1;
-            wmlp.w += (size_t)3 * d * d;
-            p[1] = blk(xn, d, 0, wmlp, nullptr, 0, S, 6 * d, d, EPI_SWIGLU);
+            p[1] = blk(xn, d, 0, wrows(w.lin1, 3 * d, d), nullptr, 0, S, 6 * d, d, EPI_SWIGLU);
             p[1].C2 = comb + d;
             p[1].ldc2 = 4 * d;
             F2_TRY(run_gemm(m, p, 2, PROF_LINEAR1, "single.linear1(qk|mlp)"));
-            GemmProblem pv = mk(w.lin1.w + (size_t)2 * d * d, d, xn, d, vt, s_pad, d, S, d, EPI_BF16);
-            pv.col_perm16 = 1;
+            GemmProblem pv = vt_problem(wrows(w.lin1, 2 * d, d), 0, S);
             F2_TRY(run_gemm(m, &pv, 1, PROF_LINEAR1, "single.linear1(vt)"));
         } else
         {

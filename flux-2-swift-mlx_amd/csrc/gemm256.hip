@@ -375,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         }
     }
 
-    if (!FP8 && p.qk_qw != nullptr && epi == EPI_BF16 && n0 < p.qk_cols) {   // (bf16 only: the e4m3 epilogue has no registers left for it)
+    if (p.qk_qw != nullptr && epi == EPI_BF16 && n0 < p.qk_cols) {
         // ---- fused QK RMSNorm + RoPE (Flux2Attention.swift:137-157).  A 256-column tile is two heads: waves wn 0,1
         // hold head A's 128 columns, wn 2,3 head B's.  Sum of squares: 16 values in the lane, the 4 fq lanes of a row
         // by two lane exchanges, the partner wave through LDS (free now; one barrier on each side).
@@ -704,7 +704,7 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
         const GemmProblem& q = probs[i];   // fused QK norm + RoPE: whole heads per tile, 16-byte row stores
         if (q.qk_qw && (!q.qk_kw || !q.qk_pos || q.qk_cols % 512 != 0 || q.qk_cols > q.N || (q.N & 255) || (q.ldc & 7) ||
                         (reinterpret_cast<uintptr_t>(q.C) & 15) || (q.epi != EPI_BF16 && q.epi != EPI_QKV_MLP) ||
-                        (q.epi == EPI_QKV_MLP && q.qk_cols > q.n_split) || dev_env || q.fp8))
+                        (q.epi == EPI_QKV_MLP && q.qk_cols > q.n_split) || dev_env))
             return 1;
     }
     count_tiles(ni, tiles);

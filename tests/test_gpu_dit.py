@@ -201,6 +201,24 @@ def test_tiny_forward_fp8(flux2mi, ctx, s_txt, h, w):
     assert outs["fp8_bytes"] < 0.7 * outs["bf16_bytes"]  # block weights are stored in one byte
 
 
+def test_production_width_fused_paths_bf16_and_fp8(flux2mi, ctx):
+    """Klein-4B width, 1 double + 1 single block, 512 text + 768x1024 image tokens (S 3584): large enough for every
+    fused form of the production path — QK RMSNorm + RoPE in the GEMM epilogue and V^T written by its own
+    role-swapped GEMM (12 x 14 = 168 tiles) — with bf16 and with e4m3 block GEMMs.  bf16 vs the f32 oracle
+    <= 2e-2; fp8 vs the oracle running the same e4m3 emulation: closer to it than to the unquantised oracle."""
+    cfg = dict(dim=3072, heads=24, n_double=1, n_single=1, joint_dim=7680, guidance=False)
+    outs, ref32, ref8 = _fp8_case(ctx, cfg, 512, 768, 1024, std=0.02)
+    assert torch.isfinite(outs["bf16"]).all() and torch.isfinite(outs["fp8"]).all()
+    assert rel_l2(outs["bf16"], ref32) < 2e-2
+    # e4m3 noise at this width (K 3072 ... 12288, weights at std 0.02): q = rel-L2(emulating oracle, f32 oracle) = 3.9e-2;
+    # the HIP path sits 2.5e-2 from the emulation (roundings flipped by bf16-level differences de-correlate part of the
+    # noise, see test_tiny_forward_fp8) — the same value with the fused epilogue / V^T GEMM switched off
+    q = rel_l2(ref8, ref32)
+    e8 = rel_l2(outs["fp8"], ref8)
+    assert e8 < 3e-2 and e8 < q
+    assert 0.5 * q < rel_l2(outs["fp8"], ref32) < 1.5 * q
+
+
 def test_fp8_rejects_unsupported_dim(flux2mi, ctx):
     """dim must be a multiple of 256 for the fp8 tiles (include/flux2mi.h weight_format)."""
     from flux2mi import Flux2Error
