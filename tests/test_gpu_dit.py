@@ -201,6 +201,16 @@ def test_tiny_forward_fp8(flux2mi, ctx, s_txt, h, w):
     assert outs["fp8_bytes"] < 0.7 * outs["bf16_bytes"]  # block weights are stored in one byte
 
 
+def test_klein9b_width_blocks(flux2mi, ctx):
+    """Klein-9B width (d 4096, 32 heads, J 12288), 1 double + 1 single block, S 3584: the N = 4096 GEMMs run on
+    160-row tiles (5 MFMA row blocks per wave: 2 rounds of 5/8 tiles instead of 2 rounds at 56 %), the V^T GEMM
+    among them with the permuted key order, next to the fused QK epilogue on 256-row tiles."""
+    cfg = dict(dim=4096, heads=32, n_double=1, n_single=1, joint_dim=12288, guidance=False)
+    out, ref = _forward_both(flux2mi, ctx, cfg, s_txt=512, h=768, w=1024)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 2e-2
+
+
 def test_production_width_fused_paths_bf16_and_fp8(flux2mi, ctx):
     """Klein-4B width, 1 double + 1 single block, 512 text + 768x1024 image tokens (S 3584): large enough for every
     fused form of the production path — QK RMSNorm + RoPE in the GEMM epilogue and V^T written by its own
