@@ -137,10 +137,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     const int nk = p.K / TILE_K;
     const int total_elems = nk * 4;
 
+    // Shorter tiles (NI < 8): the second half-tile of a wave-row has NI1*16 < 64 rows, i.e. slot rows [0, NI1*16) and
+    // [64, 64 + NI1*16): the 8-row groups of waves >= 2*NI1 (both of their instructions) are never read, so those waves
+    // skip their A1 loads.  Every wave still has exactly A0, B0, B1 of K-tile kt+2 as its 6 youngest loads at the
+    // counted wait, so vmcnt(6) means the same thing for all of them.
+    const bool a1_skip = NI1 < 4 && __builtin_amdgcn_readfirstlane(wid) >= 2 * NI1 && !(batch.flags & 2);   // FLUX2MI_GEMM_FLAGS=3: load them anyway (A/B runs)
 #define G2_ISSUE(kind_, u_)                                                                                   \
     {                                                                                                         \
         const int u__ = (u_);                                                                                 \
-        if (u__ < nk) {                                                                                       \
+        if (u__ < nk && !((kind_) == KIND_A1 && a1_skip)) {                                                   \
             uint8_t* dst__ = smem + (u__ & 1) * STAGE2_BYTES + (kind_) * SLOT_BYTES + lds_wave;               \
             __builtin_amdgcn_global_load_lds((gptr_t)(src[kind_][0] + u__ * 128), (lptr_t)(dst__), 16, 0, 0);      \
             __builtin_amdgcn_global_load_lds((gptr_t)(src[kind_][1] + u__ * 128), (lptr_t)(dst__ + 8192), 16, 0, 0); \
