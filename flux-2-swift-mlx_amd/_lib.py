@@ -22,7 +22,7 @@ class Flux2Error(RuntimeError):
 
 
 MASK_GRAYSCALE_WHITE_INPAINT, MASK_ALPHA_TRANSPARENT_INPAINT = 0, 1  # Flux2MaskConvention
-OK, ERR_INVALID_ARG, ERR_HIP, ERR_NOT_LOADED, ERR_SHAPE, ERR_CANCELLED, ERR_UNSUPPORTED, ERR_OOM = range(8)
+OK, ERR_INVALID_ARG, ERR_HIP, ERR_NOT_LOADED, ERR_SHAPE, ERR_CANCELLED, ERR_UNSUPPORTED, ERR_OOM, ERR_UNKNOWN_KEY = range(9)
 F32, BF16, F16 = 0, 1, 2
 
 
@@ -65,7 +65,7 @@ class GenerateParams(C.Structure):
         ("on_progress", PROGRESS_CB), ("on_progress_user", C.c_void_p),
         ("on_checkpoint", CHECKPOINT_CB), ("on_checkpoint_user", C.c_void_p),
         ("skip_decode", C.c_int), ("use_kv_cache", C.c_int),
-        ("out_image", C.c_void_p), ("out_latents", C.c_void_p),
+        ("out_image", C.c_void_p), ("out_image_device", C.c_void_p), ("out_latents", C.c_void_p),
         ("out_height", C.c_int), ("out_width", C.c_int), ("effective_steps", C.c_int),
         ("ms_denoise", C.c_float), ("ms_decode", C.c_float),
     ]

@@ -48,8 +48,20 @@ struct Buf {
     float* scale = nullptr;   //                  per output channel (row) scale
     bool fp8 = false;
     int rows = 0, cols = 0;
-    int got_rows = 0;
+    // rows written so far, as [begin, end) destination ranges keyed by begin: loading a slot twice (BFL and
+    // diffusers aliases in one file, a reload, duplicate shards) covers its rows once, and `to_q` three times
+    // never stands in for `to_k` / `to_v`
+    std::map<int, int> loaded;
     std::string label;
+    void mark(int begin, int end) { int& e = loaded[begin]; e = std::max(e, end); }
+    int got_rows() const {
+        int n = 0, hi = 0;
+        for (const auto& r : loaded) {   // ascending begin
+            const int b = std::max(r.first, hi);
+            if (r.second > b) { n += r.second - b; hi = r.second; }
+        }
+        return n;
+    }
 };
 
 }  // namespace
@@ -325,7 +337,7 @@ extern "C" int flux2mi_dit_set_tensor(flux2mi_dit* m, const char* name, int dtyp
     auto it = m->slots.find(name);
     if (it == m->slots.end()) {
         flux2mi_set_error("dit_set_tensor: unknown key '%s'", name);
-        return FLUX2MI_ERR_INVALID_ARG;
+        return FLUX2MI_ERR_UNKNOWN_KEY;
     }
     const Slot& s = it->second;
     int64_t rows = 1, cols = 1;
@@ -353,7 +365,10 @@ extern "C" int flux2mi_dit_set_tensor(flux2mi_dit* m, const char* name, int dtyp
     // 3. place with the layout transform
     F2_TRY(place_rows(m, s, src, b.fp8 ? nullptr : b.ptr));
     F2_CHECK_HIP(hipStreamSynchronize(st));  // the caller may free `data` on return
-    b.got_rows += (int)rows;
+    // T_DIRECT slots land at their row offset; the transforming slots (SwiGLU interleave, linear1, half swap) cover
+    // the whole buffer
+    if (s.transform == T_DIRECT) b.mark(s.row_off, s.row_off + (int)rows);
+    else b.mark(0, b.rows);
     m->finalized = false;
     return FLUX2MI_OK;
 }
@@ -394,13 +409,13 @@ extern "C" int flux2mi_dit_merge_lora(flux2mi_dit* m, const char* name, int dtyp
     auto it = m->slots.find(name);
     if (it == m->slots.end()) {
         flux2mi_set_error("dit_merge_lora: unknown key '%s'", name);
-        return FLUX2MI_ERR_INVALID_ARG;
+        return FLUX2MI_ERR_UNKNOWN_KEY;
     }
     const Slot& s = it->second;
     Buf& b = m->bufs[s.buf];
     F2_REQUIRE(!b.fp8, FLUX2MI_ERR_UNSUPPORTED,
                "dit_merge_lora(%s): fp8 weights (merge into the bf16 checkpoint before loading with weight_format 1)", name);
-    F2_REQUIRE(b.got_rows >= b.rows, FLUX2MI_ERR_NOT_LOADED, "dit_merge_lora(%s): base weight not loaded", name);
+    F2_REQUIRE(b.got_rows() >= b.rows, FLUX2MI_ERR_NOT_LOADED, "dit_merge_lora(%s): base weight not loaded", name);
     F2_CHECK_HIP(hipSetDevice(m->ctx->device));
     hipStream_t st = m->ctx->stream;
     const int64_t rows = s.rows, cols = s.cols;
@@ -434,8 +449,8 @@ extern "C" int flux2mi_dit_merge_lora(flux2mi_dit* m, const char* name, int dtyp
 extern "C" int flux2mi_dit_finalize(flux2mi_dit* m) {
     F2_REQUIRE(m, FLUX2MI_ERR_INVALID_ARG, "dit_finalize: NULL");
     for (const Buf& b : m->bufs) {
-        if (b.got_rows < b.rows) {
-            flux2mi_set_error("dit_finalize: tensor '%s' missing (%d of %d rows loaded)", b.label.c_str(), b.got_rows,
+        if (b.got_rows() < b.rows) {
+            flux2mi_set_error("dit_finalize: tensor '%s' missing (%d of %d rows loaded)", b.label.c_str(), b.got_rows(),
                               b.rows);
             return FLUX2MI_ERR_NOT_LOADED;
         }
@@ -661,7 +676,7 @@ extern "C" int flux2mi_dit_load_prequantized(flux2mi_dit* m, const char* path, c
     F2_CHECK_HIP(hipSetDevice(m->ctx->device));
     for (const PreqEntry& e : ent)
         F2_CHECK_HIP(hipMemcpy(const_cast<void*>(e.dev), data + ts[e.key].begin, e.bytes, hipMemcpyHostToDevice));
-    for (Buf& b : m->bufs) b.got_rows = b.rows;
+    for (Buf& b : m->bufs) b.mark(0, b.rows);
     m->lora_merged = md.count("lora_baked") && md["lora_baked"] == "true";
     if (lora_baked) *lora_baked = m->lora_merged ? 1 : 0;
     m->finalized = false;

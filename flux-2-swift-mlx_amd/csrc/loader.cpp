@@ -57,14 +57,16 @@ struct Json {
         ++p;
         return s;
     }
+    // non-negative integer < 2^62 (shapes and byte offsets): a sign or an overflowing literal is a malformed header
     int64_t integer() {
         ws();
-        bool neg = false;
-        if (p < e && *p == '-') { neg = true; ++p; }
         if (p >= e || *p < '0' || *p > '9') { ok = false; return 0; }
         int64_t v = 0;
-        while (p < e && *p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0');
-        return neg ? -v : v;
+        while (p < e && *p >= '0' && *p <= '9') {
+            if (v > ((int64_t)1 << 62) / 10 - 1) { ok = false; return 0; }
+            v = v * 10 + (*p++ - '0');
+        }
+        return v;
     }
     void skip_value() {   // any JSON value
         ws();
@@ -158,7 +160,9 @@ int parse_safetensors(const char* path, MappedFile& f, std::map<std::string, Ten
                 } else j.skip_value();
                 (void)j.eat(',');
             }
-            if (t.end < t.begin || 8 + hlen + t.end > f.size) {
+            // payload = f.size - 8 - hlen bytes (hlen <= f.size - 8 checked above): no sum that can wrap
+            if (!j.ok) break;
+            if (t.begin > t.end || t.end > (uint64_t)f.size - 8 - hlen) {
                 flux2mi_set_error("load_safetensors: '%s': tensor '%s' lies outside the file", path, key.c_str());
                 return FLUX2MI_ERR_INVALID_ARG;
             }
@@ -184,6 +188,17 @@ int st_dtype(const std::string& s) {
     return -1;
 }
 
+// prod(shape) * elem_size == end - begin, without overflow (every dim < 2^62 from the parser)
+bool bytes_match(const TensorInfo& t, uint64_t elem_size) {
+    uint64_t n = 1;
+    for (int64_t d : t.shape) {
+        if (d < 0) return false;
+        if (d != 0 && n > (UINT64_MAX / elem_size) / (uint64_t)d) return false;
+        n *= (uint64_t)d;
+    }
+    return n * elem_size == t.end - t.begin;
+}
+
 bool ends_with(const std::string& s, const char* suf) {
     const size_t n = strlen(suf);
     return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
@@ -205,23 +220,28 @@ int load_all(const char* path, const char* const* prefixes, SetFn set_tensor, Q8
         if (ends_with(key, "._data")) {   // quanto qint8: needs its "._scale" partner
             const std::string base = key.substr(0, key.size() - 6);
             auto sc = ts.find(kv.first.substr(0, kv.first.size() - 6) + "._scale");
-            if (t.dtype != "I8" || t.shape.size() != 2 || sc == ts.end() || sc->second.dtype != "F32" ||
-                (int64_t)((sc->second.end - sc->second.begin) / 4) != t.shape[0]) {
+            if (t.dtype != "I8" || t.shape.size() != 2 || !bytes_match(t, 1) || sc == ts.end() || sc->second.dtype != "F32" ||
+                !bytes_match(sc->second, 4) || sc->second.end - sc->second.begin != (uint64_t)t.shape[0] * 4) {
                 flux2mi_set_error("load_safetensors: '%s': quantised tensor '%s' without a matching f32 per-row ._scale",
                                   path, kv.first.c_str());
                 return FLUX2MI_ERR_SHAPE;
             }
             const int r = set_q8(base.c_str(), reinterpret_cast<const int8_t*>(data + t.begin),
                                  reinterpret_cast<const float*>(data + sc->second.begin), t.shape[0], t.shape[1]);
-            if (r == FLUX2MI_ERR_INVALID_ARG) { ++skipped; continue; }   // unknown key
+            if (r == FLUX2MI_ERR_UNKNOWN_KEY) { ++skipped; continue; }
             F2_TRY(r);
             ++loaded;
             continue;
         }
         const int dt = st_dtype(t.dtype);
         if (dt < 0) { ++skipped; continue; }
+        if (!bytes_match(t, dt == FLUX2MI_F32 ? 4 : 2)) {
+            flux2mi_set_error("load_safetensors: '%s': tensor '%s': data_offsets span %llu bytes, shape x dtype says otherwise",
+                              path, kv.first.c_str(), (unsigned long long)(t.end - t.begin));
+            return FLUX2MI_ERR_SHAPE;
+        }
         const int r = set_tensor(key.c_str(), dt, t.shape.data(), (int)t.shape.size(), data + t.begin);
-        if (r == FLUX2MI_ERR_INVALID_ARG) { ++skipped; continue; }       // key of another component
+        if (r == FLUX2MI_ERR_UNKNOWN_KEY) { ++skipped; continue; }       // key of another component
         F2_TRY(r);
         ++loaded;
     }
@@ -248,6 +268,6 @@ extern "C" int flux2mi_vae_load_safetensors(flux2mi_vae* vae, const char* path, 
     return load_all(
         path, prefixes,
         [&](const char* k, int dt, const int64_t* sh, int nd, const void* p) { return flux2mi_vae_set_tensor(vae, k, dt, sh, nd, p); },
-        [&](const char*, const int8_t*, const float*, int64_t, int64_t) { return (int)FLUX2MI_ERR_INVALID_ARG; },
+        [&](const char*, const int8_t*, const float*, int64_t, int64_t) { return (int)FLUX2MI_ERR_UNKNOWN_KEY; },
         n_loaded, n_skipped);
 }

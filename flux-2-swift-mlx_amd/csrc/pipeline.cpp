@@ -26,6 +26,18 @@ struct GenScratch {
     }
 };
 
+// events + KV cache of one generation: released on every exit path
+struct GenGuard {
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    flux2mi_kv_cache* kv = nullptr;
+    ~GenGuard() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (ev2) (void)hipEventDestroy(ev2);
+        if (kv) (void)flux2mi_kv_cache_destroy(kv);
+    }
+};
+
 int upload_ids(hipStream_t st, DevBuf& buf, const std::vector<int32_t>& host) {
     F2_TRY(buf.reserve(host.size() * 4));
     F2_CHECK_HIP(hipMemcpyAsync(buf.ptr, host.data(), host.size() * 4, hipMemcpyHostToDevice, st));
@@ -40,9 +52,10 @@ extern "C" int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae*
     F2_REQUIRE(p->txt_emb && p->s_txt > 0 && p->noise && p->steps > 0, FLUX2MI_ERR_INVALID_ARG,
                "generate: txt_emb/noise/steps missing");
     F2_REQUIRE(p->skip_decode || vae, FLUX2MI_ERR_NOT_LOADED, "generate: VAE required unless skip_decode");
-    // strength < 1 without initLatents is an error (Flux2Pipeline.swift:1210-1213)
-    F2_REQUIRE(!(p->strength < 1.0f && p->init_latents == nullptr), FLUX2MI_ERR_INVALID_ARG,
-               "generate: strength %.3f < 1 requires init_latents", p->strength);
+    // effectiveStrength = clamp(strength, 0.01, 1); < 1 without initLatents is an error (Flux2Pipeline.swift:1208-1213)
+    const float strength = fmaxf(0.01f, fminf(1.0f, p->strength));
+    F2_REQUIRE(!(strength < 1.0f && p->init_latents == nullptr), FLUX2MI_ERR_INVALID_ARG,
+               "generate: strength %.3f < 1 requires init_latents", strength);
     F2_CHECK_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
 
@@ -55,19 +68,21 @@ extern "C" int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae*
     const int s_ref = (p->ref_latents && p->s_ref > 0) ? p->s_ref : 0;
     const int S_all = S_img + s_ref;
     const int64_t n_lat = (int64_t)S_img * 128;
-    const bool use_init = p->init_latents != nullptr;
+    const bool custom = p->custom_sigmas && p->n_custom_sigmas > 0;
+    // useImg2ImgInit (:1209); a custom sigma schedule (LoRA scheduler override) ignores strength / initLatents (:1879-1883)
+    const bool use_init = p->init_latents != nullptr && strength < 1.0f && !custom;
     const bool use_cfg = p->neg_emb != nullptr && p->s_neg > 0 && p->cfg_scale > 1.0f;
 
     // ---- scheduler (:1873-1907)
     std::vector<float> sigmas((size_t)p->steps + 2 + (p->n_custom_sigmas > 0 ? p->n_custom_sigmas : 0));
     int n_sig = 0;
-    if (p->custom_sigmas && p->n_custom_sigmas > 0) {
+    if (custom) {
         F2_TRY(flux2mi_set_custom_sigmas(p->custom_sigmas, p->n_custom_sigmas, sigmas.data(), (int)sigmas.size(), &n_sig));
     } else {
-        F2_TRY(flux2mi_set_timesteps(p->steps, S_img, use_init ? p->strength : 1.0f, sigmas.data(), (int)sigmas.size(),
+        F2_TRY(flux2mi_set_timesteps(p->steps, S_img, use_init ? strength : 1.0f, sigmas.data(), (int)sigmas.size(),
                                      &n_sig, nullptr));
         F2_REQUIRE(!(use_init && n_sig < 2), FLUX2MI_ERR_INVALID_ARG,
-                   "generate: strength %.3f with %d steps yields zero denoising steps", p->strength, p->steps);
+                   "generate: strength %.3f with %d steps yields zero denoising steps", strength, p->steps);
     }
     const int n_steps = n_sig - 1;
     p->effective_steps = n_steps;
@@ -114,22 +129,18 @@ extern "C" int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae*
         lat_in = g.lat_in.as<float>();
     }
 
-    hipEvent_t ev0, ev1, ev2;
-    F2_CHECK_HIP(hipEventCreate(&ev0));
-    F2_CHECK_HIP(hipEventCreate(&ev1));
-    F2_CHECK_HIP(hipEventCreate(&ev2));
-    flux2mi_kv_cache* kv = nullptr;
+    GenGuard guard;
+    F2_CHECK_HIP(hipEventCreate(&guard.ev0));
+    F2_CHECK_HIP(hipEventCreate(&guard.ev1));
+    F2_CHECK_HIP(hipEventCreate(&guard.ev2));
+    hipEvent_t ev0 = guard.ev0, ev1 = guard.ev1, ev2 = guard.ev2;
+    flux2mi_kv_cache*& kv = guard.kv;
     if (p->use_kv_cache) {
         F2_REQUIRE(s_ref > 0, FLUX2MI_ERR_INVALID_ARG, "generate: use_kv_cache needs reference latents");
         F2_REQUIRE(!use_cfg, FLUX2MI_ERR_UNSUPPORTED, "generate: use_kv_cache with classical CFG (the reference's KV path has none)");
         F2_TRY(flux2mi_kv_cache_create(dit, p->s_txt, s_ref, &kv));
     }
-    auto cleanup = [&]() {
-        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(ev2);
-        if (kv) (void)flux2mi_kv_cache_destroy(kv);
-        kv = nullptr;
-    };
-#define GEN_TRY(expr) do { int _s = (expr); if (_s != FLUX2MI_OK) { cleanup(); return _s; } } while (0)
+#define GEN_TRY(expr) F2_TRY(expr)
 
     std::vector<uint8_t> ckpt_host;
     F2_CHECK_HIP(hipEventRecord(ev0, st));
@@ -137,11 +148,7 @@ extern "C" int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae*
     for (int k = 0; k < n_steps; ++k) {
         const float sigma = sigmas[k], sigma_next = sigmas[k + 1];
         if (s_ref && !kv)  // per-step concat [out ; ref] (:1703)
-            if (hipMemcpyAsync(g.lat_in.ptr, packed, (size_t)n_lat * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
-                cleanup();
-                flux2mi_set_error("generate: concat copy failed");
-                return FLUX2MI_ERR_HIP;
-            }
+            F2_CHECK_HIP(hipMemcpyAsync(g.lat_in.ptr, packed, (size_t)n_lat * 4, hipMemcpyDeviceToDevice, st));
         if (kv) {
             // KV-cached reference conditioning (Flux2Pipeline.swift:1555-1682): step 0 runs
             // [txt | ref | out] and stores the reference K/V of every layer, later steps run
@@ -167,31 +174,24 @@ extern "C" int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae*
         if (p->on_step) {
             flux2mi_step_context sc{k, n_steps, sigma, sigma_next, H, W, s_ref ? 1 : 0};
             if (p->on_step(&sc, packed, (void*)st, p->on_step_user) != 0) {
-                cleanup();
                 flux2mi_set_error("generate: cancelled by step hook at step %d", k);
                 return FLUX2MI_ERR_CANCELLED;
             }
         }
         if (p->on_progress) {  // progress after the hook (:2013); the reference has synchronised here
-            if (hipStreamSynchronize(st) != hipSuccess) { cleanup(); flux2mi_set_error("generate: sync failed"); return FLUX2MI_ERR_HIP; }
+            F2_CHECK_HIP(hipStreamSynchronize(st));
             p->on_progress(k + 1, n_steps, p->on_progress_user);
         }
         // checkpoint image every N steps (:2018-2046)
         if (p->checkpoint_interval > 0 && p->on_checkpoint && vae && (k + 1) % p->checkpoint_interval == 0) {
-            if (g.z.reserve((size_t)32 * (H / 8) * (W / 8) * 4) != FLUX2MI_OK || g.img_u8.reserve((size_t)H * W * 3) != FLUX2MI_OK) {
-                cleanup();
-                return FLUX2MI_ERR_OOM;
-            }
+            F2_TRY(g.z.reserve((size_t)32 * (H / 8) * (W / 8) * 4));
+            F2_TRY(g.img_u8.reserve((size_t)H * W * 3));
             GEN_TRY(flux2mi_latents_to_vae_input(ctx, packed, flux2mi_vae_bn_mean(vae), flux2mi_vae_bn_var(vae),
                                                  g.z.as<float>(), h16, w16));
             GEN_TRY(flux2mi_vae_decode(vae, g.z.as<float>(), H / 8, W / 8, nullptr, g.img_u8.as<uint8_t>()));
             ckpt_host.resize((size_t)H * W * 3);
-            if (hipMemcpyAsync(ckpt_host.data(), g.img_u8.ptr, ckpt_host.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess) {
-                cleanup();
-                flux2mi_set_error("generate: checkpoint copy failed");
-                return FLUX2MI_ERR_HIP;
-            }
+            F2_CHECK_HIP(hipMemcpyAsync(ckpt_host.data(), g.img_u8.ptr, ckpt_host.size(), hipMemcpyDeviceToHost, st));
+            F2_CHECK_HIP(hipStreamSynchronize(st));
             p->on_checkpoint(k + 1, ckpt_host.data(), H, W, p->on_checkpoint_user);
         }
     }
@@ -209,12 +209,13 @@ extern "C" int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae*
         GEN_TRY(flux2mi_vae_decode(vae, g.z.as<float>(), H / 8, W / 8, nullptr, g.img_u8.as<uint8_t>()));
         if (p->out_image)  // the path's only D2H copy (:2448)
             F2_CHECK_HIP(hipMemcpyAsync(p->out_image, g.img_u8.ptr, (size_t)H * W * 3, hipMemcpyDeviceToHost, st));
+        if (p->out_image_device)
+            F2_CHECK_HIP(hipMemcpyAsync(p->out_image_device, g.img_u8.ptr, (size_t)H * W * 3, hipMemcpyDeviceToDevice, st));
     }
     F2_CHECK_HIP(hipEventRecord(ev2, st));
     F2_CHECK_HIP(hipStreamSynchronize(st));
     (void)hipEventElapsedTime(&p->ms_denoise, ev0, ev1);
     (void)hipEventElapsedTime(&p->ms_decode, ev1, ev2);
-    cleanup();
 #undef GEN_TRY
     return FLUX2MI_OK;
 }

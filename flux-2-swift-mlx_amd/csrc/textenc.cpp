@@ -164,7 +164,7 @@ extern "C" int flux2mi_textenc_set_tensor(flux2mi_textenc* m, const char* name, 
     auto it = m->slots.find(name);
     if (it == m->slots.end()) {
         flux2mi_set_error("textenc_set_tensor: unknown key '%s'", name);
-        return FLUX2MI_ERR_INVALID_ARG;   // layers past the last extracted one, lm_head, final norm: not part of this path
+        return FLUX2MI_ERR_UNKNOWN_KEY;   // layers past the last extracted one, lm_head, final norm: not part of this path
     }
     const TSlot& s = it->second;
     int64_t rows = 1, cols = 1;

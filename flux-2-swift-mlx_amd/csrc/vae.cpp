@@ -247,7 +247,7 @@ extern "C" int flux2mi_vae_set_tensor(flux2mi_vae* v, const char* name, int dtyp
     auto it = v->index.find(name);
     if (it == v->index.end()) {
         flux2mi_set_error("vae_set_tensor: unknown key '%s'", name);
-        return FLUX2MI_ERR_INVALID_ARG;
+        return FLUX2MI_ERR_UNKNOWN_KEY;
     }
     Param& p = v->params[it->second];
     F2_REQUIRE(ndim == p.ndim, FLUX2MI_ERR_SHAPE, "vae_set_tensor(%s): ndim %d, expected %d", name, ndim, p.ndim);

@@ -58,6 +58,52 @@ class Flux2GenerationResult:
     msDecode: float = 0.0
 
 
+@dataclass
+class SchedulerOverrides:
+    """LoRA/LoRAConfig.swift:7-35."""
+    customSigmas: Optional[List[float]] = None
+    numSteps: Optional[int] = None
+    guidance: Optional[float] = None
+
+    @property
+    def hasOverrides(self) -> bool:
+        return self.customSigmas is not None or self.numSteps is not None or self.guidance is not None
+
+
+@dataclass
+class LoRAConfig:
+    """LoRA/LoRAConfig.swift:38-94 (JSON field names as the Codable struct writes them)."""
+    filePath: str
+    scale: Optional[float] = 1.0
+    activationKeyword: Optional[str] = None
+    schedulerOverrides: Optional[SchedulerOverrides] = None
+
+    @property
+    def name(self) -> str:
+        return os.path.splitext(os.path.basename(self.filePath))[0]
+
+    @property
+    def effectiveScale(self) -> float:
+        return 1.0 if self.scale is None else float(self.scale)
+
+    @classmethod
+    def load(cls, path: str) -> "LoRAConfig":
+        import json
+        with open(path) as f:
+            d = json.load(f)
+        so = d.get("schedulerOverrides")
+        return cls(filePath=d["filePath"], scale=d.get("scale"), activationKeyword=d.get("activationKeyword"),
+                   schedulerOverrides=None if so is None else SchedulerOverrides(so.get("customSigmas"), so.get("numSteps"), so.get("guidance")))
+
+    def save(self, path: str):
+        import json
+        d = {"filePath": self.filePath, "scale": self.scale, "activationKeyword": self.activationKeyword}
+        if self.schedulerOverrides is not None:
+            d["schedulerOverrides"] = {k: v for k, v in vars(self.schedulerOverrides).items() if v is not None}
+        with open(path, "w") as f:
+            json.dump({k: v for k, v in d.items() if v is not None}, f, indent=2, sort_keys=True)
+
+
 class Flux2Pipeline:
     """`Flux2Pipeline(model:...)` restricted to the hot path: embeddings in, image out."""
 
@@ -110,17 +156,21 @@ class Flux2Pipeline:
         return self
 
     # ---- LoRA (Flux2Pipeline.swift:618-689, LoRA/LoRALoader.swift, WeightLoader.mergeLoRAWeights) ------
-    def load_lora(self, path: str, scale: Optional[float] = None) -> int:
-        """`loadLoRA(LoRAConfig(filePath:scale:))`: reads `<layer>.lora_A.weight` / `.lora_B.weight` pairs
-        (prefixes `base_model.model.` / `transformer.` dropped), scale = (metadata lora_alpha / lora_rank,
-        default 1) x `scale` (LoRAConfig.effectiveScale, default 1), and merges W += s B A into the resident
-        bf16 weights.  Returns the number of merged layers; layers the transformer does not have are skipped
-        like in the reference (:783-789)."""
+    def load_lora(self, config, scale: Optional[float] = None) -> int:
+        """`loadLoRA(LoRAConfig)`: `config` is a `LoRAConfig` or a file path (then `scale` = LoRAConfig.scale).
+        Reads `<layer>.lora_A.weight` / `.lora_B.weight` pairs, strips the prefixes `base_model.model.`, `transformer.`,
+        `diffusion_model.` one after the other (LoRALoader.swift:132-140), scale = (metadata lora_alpha / lora_rank,
+        default 1) x LoRAConfig.effectiveScale, and merges W += s B A into the resident bf16 weights.  Scheduler
+        overrides of the config become `activeSchedulerOverrides` (:625-637).  Returns the number of merged layers;
+        layers the transformer does not have are skipped like in the reference (:783-789) — a file in which NO layer
+        matches is an error instead of a LoRA that silently does nothing."""
         from safetensors import safe_open
+        if not isinstance(config, LoRAConfig):
+            config = LoRAConfig(filePath=str(config), scale=scale)
         if self.transformer is None:
             raise Flux2Error(L.ERR_NOT_LOADED, "Transformer")
-        merged = 0
-        with safe_open(str(path), framework="pt") as f:
+        merged, unknown = 0, []
+        with safe_open(config.filePath, framework="pt") as f:
             md = f.metadata() or {}
             s = 1.0
             try:
@@ -128,7 +178,7 @@ class Flux2Pipeline:
                     s = float(md["lora_alpha"]) / float(md["lora_rank"])
             except (KeyError, ValueError):
                 s = 1.0
-            s *= 1.0 if scale is None else float(scale)
+            s *= config.effectiveScale
             keys = set(f.keys())
             for k in sorted(keys):
                 if not k.endswith(".lora_A.weight"):
@@ -138,17 +188,41 @@ class Flux2Pipeline:
                 if kb not in keys:
                     continue
                 layer = base
-                for pre in ("base_model.model.", "transformer."):
+                for pre in ("base_model.model.", "transformer.", "diffusion_model."):
                     if layer.startswith(pre):
                         layer = layer[len(pre):]
                 try:
                     self.transformer.merge_lora(layer + ".weight", f.get_tensor(k), f.get_tensor(kb), s)
                     merged += 1
                 except Flux2Error as e:
-                    if e.code != L.ERR_INVALID_ARG:   # unknown layer: skip; anything else is an error
+                    if e.code != L.ERR_UNKNOWN_KEY:   # a layer this transformer does not have: skip; anything else is an error
                         raise
-        self._lora = getattr(self, "_lora", []) + [str(path)]
+                    unknown.append(layer)
+        if merged == 0:
+            raise Flux2Error(L.ERR_INVALID_ARG, f"LoRA '{config.filePath}': none of its {len(unknown)} layers matches this transformer "
+                                                f"(first: {unknown[:3]})")
+        self._lora = getattr(self, "_lora", []) + [config.name]
+        if config.schedulerOverrides is not None and config.schedulerOverrides.hasOverrides:
+            self._lora_scheduler_overrides = config.schedulerOverrides
         return merged
+
+    loadLoRA = load_lora
+
+    def unloadLoRA(self, name: str):
+        """:666-672.  As in the reference, weights already merged into the transformer stay merged; the name is dropped
+        and the scheduler overrides are cleared when no LoRA is left."""
+        self._lora = [n for n in getattr(self, "_lora", []) if n != name]
+        if not self._lora:
+            self._lora_scheduler_overrides = None
+
+    def unloadAllLoRAs(self):
+        self._lora = []
+        self._lora_scheduler_overrides = None
+
+    @property
+    def activeSchedulerOverrides(self) -> Optional["SchedulerOverrides"]:
+        """:685-689."""
+        return getattr(self, "_lora_scheduler_overrides", None)
 
     def exportPrequantizedTransformer(self, path: str, source_fingerprint: str = "", allowLoRABaked: bool = False) -> str:
         """`Flux2Pipeline.exportPrequantizedTransformer` (Flux2Pipeline.swift:759-840): only for a quantised
@@ -198,7 +272,8 @@ class Flux2Pipeline:
                              strength: float = 1.0, on_progress=None, on_checkpoint=None,
                              on_step: Optional[Flux2StepHook] = None, reference_latents=None, reference_ids=None,
                              custom_sigmas: Optional[Sequence[float]] = None, skip_decode: bool = False,
-                             return_latents: bool = False, kv_cache: Optional[bool] = None) -> Flux2GenerationResult:
+                             return_latents: bool = False, kv_cache: Optional[bool] = None,
+                             image_device: Optional[torch.Tensor] = None) -> Flux2GenerationResult:
         """`kv_cache`: reference tokens through the KV-cached path (the klein-9b-kv variant,
         Flux2Pipeline.swift:1555-1682); default = the pipeline's `supports_kv_cache`."""
         if self.transformer is None:
@@ -244,6 +319,9 @@ class Flux2Pipeline:
             ri = reference_ids.to(device=dev, dtype=torch.int32).contiguous()
             keep += [rl, ri]
             p.ref_latents, p.ref_ids, p.s_ref = rl.data_ptr(), ri.data_ptr(), rl.shape[0]
+        if custom_sigmas is None and self.activeSchedulerOverrides is not None:
+            # Turbo-style LoRAs bring their own schedule; strength / initLatents are then ignored (Flux2Pipeline.swift:1879-1884)
+            custom_sigmas = self.activeSchedulerOverrides.customSigmas
         if custom_sigmas is not None:
             cs = (C.c_float * len(custom_sigmas))(*[float(s) for s in custom_sigmas])
             keep.append(cs)
@@ -287,7 +365,12 @@ class Flux2Pipeline:
             p.on_checkpoint = ccb
 
         image = None
-        if not skip_decode:
+        if not skip_decode and image_device is not None:
+            # the decoded bytes stay in HBM (u8 [H,W,3] device tensor of the caller), no D2H copy here
+            if image_device.dtype != torch.uint8 or not image_device.is_cuda or image_device.numel() != H * W * 3 or not image_device.is_contiguous():
+                raise Flux2Error(L.ERR_SHAPE, f"image_device must be a contiguous u8 device tensor of {H}x{W}x3")
+            p.out_image_device = image_device.data_ptr()
+        elif not skip_decode:
             image = np.empty((H, W, 3), dtype=np.uint8)
             p.out_image = image.ctypes.data
         lat_out = None

@@ -41,7 +41,10 @@ enum flux2mi_status {
     FLUX2MI_ERR_SHAPE = 4,         /* shape mismatch (e.g. initLatents, Flux2Pipeline.swift:1898-1901) */
     FLUX2MI_ERR_CANCELLED = 5,     /* Flux2Error.generationCancelled (Flux2Pipeline.swift:1940-1942) */
     FLUX2MI_ERR_UNSUPPORTED = 6,
-    FLUX2MI_ERR_OOM = 7            /* Flux2Error.insufficientMemory */
+    FLUX2MI_ERR_OOM = 7,           /* Flux2Error.insufficientMemory */
+    FLUX2MI_ERR_UNKNOWN_KEY = 8    /* set_tensor / merge_lora: the model has no tensor of that name (a key of another
+                                      component or of a layer this path does not run) — callers may skip it; every
+                                      other argument error stays FLUX2MI_ERR_INVALID_ARG */
 };
 
 enum flux2mi_dtype { FLUX2MI_F32 = 0, FLUX2MI_BF16 = 1, FLUX2MI_F16 = 2 };
@@ -265,7 +268,7 @@ int flux2mi_textenc_preset(const char* name, flux2mi_textenc_config* out);
 int flux2mi_textenc_create(flux2mi_ctx* ctx, const flux2mi_textenc_config* cfg, flux2mi_textenc** out);
 int flux2mi_textenc_destroy(flux2mi_textenc* te);
 /* HF keys ("model.layers.N.self_attn.q_proj.weight", ..., with or without the "model." prefix);
- * keys of layers that are not run return FLUX2MI_ERR_INVALID_ARG and can be skipped by the caller. */
+ * keys of layers that are not run return FLUX2MI_ERR_UNKNOWN_KEY and can be skipped by the caller. */
 int flux2mi_textenc_set_tensor(flux2mi_textenc* te, const char* name, int dtype, const int64_t* shape, int ndim,
                                const void* data);
 int flux2mi_textenc_finalize(flux2mi_textenc* te);
@@ -365,6 +368,8 @@ typedef struct flux2mi_generate_params {
                                       steps 1+ = flux2mi_dit_forward_kv_cached */
     /* outputs */
     uint8_t* out_image;            /* host u8 [H,W,3] or NULL */
+    uint8_t* out_image_device;     /* device u8 [H,W,3] or NULL: the same bytes left in HBM (e.g. as the send buffer of
+                                      the all-gather of a data-parallel batch) */
     float* out_latents;            /* device f32 [S_img,128] or NULL: final packed latents */
     int out_height, out_width;
     int effective_steps;

@@ -730,9 +730,10 @@ def generate(P: Dict[str, Tensor], cfg: dict, VP: Optional[Dict[str, Tensor]], v
     S_img = packed.shape[1]
     txt_ids = text_position_ids(txt_emb.shape[1])
     img_ids = image_position_ids(height, width)
-    use_init = init_latents is not None
-    if strength < 1.0 and not use_init:
+    strength = max(0.01, min(1.0, strength))                  # effectiveStrength, Flux2Pipeline.swift:1208
+    if strength < 1.0 and init_latents is None:
         raise ValueError("strength < 1 requires initLatents (Flux2Pipeline.swift:1210-1213)")
+    use_init = init_latents is not None and strength < 1.0    # useImg2ImgInit, :1209
     if custom_sigmas is not None:
         sigmas = set_custom_sigmas(custom_sigmas)
     else:

@@ -336,3 +336,126 @@ def test_prequantized_checkpoint_lora_tag(flux2mi, ctx, tmp_path):
     assert b.load_prequantized(path) is True
     assert torch.equal(_fwd(b, cfg, inp, lat, 64, 64, 16), ref)
     b.close()
+
+
+# ---- round 2: hostile / inconsistent headers, slot coverage, LoRA prefixes + scheduler overrides -----------------
+def _write_raw_safetensors(path, header: dict, payload: bytes):
+    import json
+    import struct
+    h = json.dumps(header).encode()
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(h)) + h + payload)
+
+
+@pytest.mark.parametrize("case", ["negative_offsets", "overflowing_offset", "span_shorter_than_shape", "span_longer_than_shape",
+                                  "q8_data_span", "q8_scale_span"])
+def test_safetensors_header_is_validated(flux2mi, ctx, tmp_path, case):
+    """A corrupt or hostile header must be refused before any byte is read through it: negative / overflowing
+    data_offsets (they used to wrap past the bounds check), and a byte span that does not equal prod(shape) x dtype size
+    (set_tensor copies shape-many bytes, whatever the span says).  The model stays usable afterwards."""
+    from flux2mi import Flux2Error
+    from flux2mi.api import DiT
+    syn, cfg, P, inp, lat = _setup()
+    d = cfg["dim"]
+    name = "double_blocks.0.img_attn.proj.weight"
+    good = P[name].contiguous().view(torch.uint8).numpy().tobytes()
+    n = len(good)
+    hdr = {name: {"dtype": "BF16", "shape": [d, d], "data_offsets": [0, n]}}
+    payload = good
+    if case == "negative_offsets":
+        hdr[name]["data_offsets"] = [-16, -8]
+    elif case == "overflowing_offset":
+        hdr[name]["data_offsets"] = [0, 2 ** 64 - 8]
+    elif case == "span_shorter_than_shape":
+        hdr[name]["data_offsets"] = [0, n // 2]
+    elif case == "span_longer_than_shape":
+        hdr[name]["shape"] = [d, d // 2]
+    else:
+        q = torch.zeros((d, d), dtype=torch.int8).numpy().tobytes()
+        sc = torch.ones((d,), dtype=torch.float32).numpy().tobytes()
+        key = name[:-len(".weight")] + ".weight"
+        hdr = {key + "._data": {"dtype": "I8", "shape": [d, d], "data_offsets": [0, len(q) - (d if case == "q8_data_span" else 0)]},
+               key + "._scale": {"dtype": "F32", "shape": [d], "data_offsets": [len(q), len(q) + len(sc) - (4 if case == "q8_scale_span" else 0)]}}
+        payload = q + sc
+    path = str(tmp_path / f"{case}.safetensors")
+    _write_raw_safetensors(path, hdr, payload)
+    dit = DiT(ctx, cfg).load(P).finalize()
+    before = _fwd(dit, cfg, inp, lat, 64, 64, 16)
+    with pytest.raises(Flux2Error):
+        dit.load_safetensors(path)
+    dit.finalize()
+    assert torch.equal(_fwd(dit, cfg, inp, lat, 64, 64, 16), before)
+    dit.close()
+
+
+def test_duplicate_slot_does_not_stand_in_for_missing_rows(flux2mi, ctx):
+    """`to_q` loaded three times covers d rows of the fused [3d, d] qkv buffer, not 3d: finalize must still report the
+    tensor missing (it used to count rows and pass with k / v never written); BFL + diffusers aliases of the same
+    tensor in one load are fine."""
+    from flux2mi import Flux2Error
+    from flux2mi.api import DiT
+    syn, cfg, P, inp, lat = _setup()
+    d = cfg["dim"]
+    qkv = P.pop("double_blocks.0.img_attn.qkv.weight")
+    dit = DiT(ctx, cfg).load(P)
+    for _ in range(3):
+        dit.load({"transformer_blocks.0.attn.to_q.weight": qkv[:d].contiguous()})
+    with pytest.raises(Flux2Error) as e:
+        dit.finalize()
+    assert "dbl0.img.qkv" in str(e.value)
+    dit.load({"transformer_blocks.0.attn.to_k.weight": qkv[d:2 * d].contiguous(),
+              "transformer_blocks.0.attn.to_v.weight": qkv[2 * d:].contiguous()}).finalize()
+    ref = DiT(ctx, cfg).load({**P, "double_blocks.0.img_attn.qkv.weight": qkv}).finalize()
+    ref.load({"transformer_blocks.0.attn.to_q.weight": qkv[:d].contiguous()}).finalize()     # alias on top: still complete
+    assert torch.equal(_fwd(dit, cfg, inp, lat, 64, 64, 16), _fwd(ref, cfg, inp, lat, 64, 64, 16))
+    dit.close(); ref.close()
+
+
+def test_lora_prefixes_overrides_and_no_match(flux2mi, ctx, tmp_path):
+    """LoRALoader.swift:132-140 strips `base_model.model.`, `transformer.`, `diffusion_model.` in sequence (a ComfyUI-style
+    file uses the last); a file that matches NO layer is an error and leaves hasLoRA false; LoRAConfig scheduler overrides
+    become activeSchedulerOverrides, drive the schedule (custom sigmas) and are cleared with the last LoRA
+    (Flux2Pipeline.swift:618-689, LoRAConfig.swift:7-35)."""
+    from safetensors.torch import save_file
+    from flux2mi import Flux2Error
+    from flux2mi.pipeline import Flux2Pipeline, LoRAConfig, SchedulerOverrides
+    syn, cfg, P, inp, lat = _setup()
+    g = torch.Generator().manual_seed(4)
+    key = "single_blocks.0.linear2.weight"
+    A = (torch.randn((4, P[key].shape[1]), generator=g) * 0.1).to(torch.bfloat16)
+    B = (torch.randn((P[key].shape[0], 4), generator=g) * 0.1).to(torch.bfloat16)
+    vcfg = syn.VAE_PRESETS["tiny"]
+    outs = []
+    for prefix in ("transformer.", "diffusion_model.", "base_model.model.transformer."):
+        path = str(tmp_path / "l.safetensors")
+        save_file({f"{prefix}single_blocks.0.linear2.lora_A.weight": A, f"{prefix}single_blocks.0.linear2.lora_B.weight": B}, path)
+        pipe = Flux2Pipeline(model=cfg, vae_variant=vcfg).load_models(P, syn.make_vae_weights(vcfg))
+        assert pipe.load_lora(path) == 1 and pipe.hasLoRA
+        outs.append(_fwd(pipe.transformer, cfg, inp, lat, 64, 64, 16))
+        pipe.clearAll()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+    pipe = Flux2Pipeline(model=cfg, vae_variant=vcfg).load_models(P, syn.make_vae_weights(vcfg))
+    bad = str(tmp_path / "bad.safetensors")
+    save_file({"unet.down.0.lora_A.weight": A, "unet.down.0.lora_B.weight": B}, bad)
+    with pytest.raises(Flux2Error):
+        pipe.load_lora(bad)
+    assert not pipe.hasLoRA and pipe.activeSchedulerOverrides is None
+
+    sig = [1.0, 0.55, 0.2]
+    cfg_json = str(tmp_path / "turbo.json")
+    LoRAConfig(filePath=path, scale=0.5, schedulerOverrides=SchedulerOverrides(customSigmas=sig, numSteps=3, guidance=1.0)).save(cfg_json)
+    lc = LoRAConfig.load(cfg_json)
+    assert lc.name == "l" and lc.effectiveScale == 0.5 and lc.schedulerOverrides.customSigmas == sig
+    assert pipe.loadLoRA(lc) == 1
+    assert pipe.activeSchedulerOverrides.numSteps == 3
+    # the override drives the schedule: same result as passing the sigmas explicitly, and init latents / strength are ignored
+    kw = dict(height=64, width=64, steps=28, precomputed_embeddings=inp["txt"], noise=inp["noise"], skip_decode=True)
+    a = pipe.generate_with_result("textToImage", **kw)
+    assert a.effectiveSteps == 3
+    b = pipe.generate_with_result("textToImage", init_latents=torch.ones((1, 16, 128)), strength=0.3, **kw)
+    pipe.unloadLoRA("l")
+    assert pipe.activeSchedulerOverrides is None and not pipe.hasLoRA
+    c = pipe.generate_with_result("textToImage", custom_sigmas=sig, **kw)
+    assert torch.equal(a.latents, b.latents) and torch.equal(a.latents, c.latents)
+    pipe.clearAll()
