@@ -2,31 +2,42 @@
 """bench.py — Flux.2 Klein-4B 1024x1024 @ 28 steps on N MI355X (BASELINE.json configs[1]).
 
 One bench "step" = one batch of N images (one per GPU, batch-level data parallel): the
-28 denoise steps of the DiT, VAE decode and the D2H copy of the u8 image, with text
-embeddings and noise resident in HBM when the timed region starts.  Per batch the ranks
-exchange exactly two collectives (RCCL over xGMI): broadcast of the text embeddings from
-rank 0 and all-gather of the decoded images.
+28 denoise steps of the DiT, VAE decode, the all-gather of the decoded u8 images and the D2H
+copy of the batch on rank 0, with text embeddings and noise resident in HBM when the timed
+region starts.  Per batch the ranks exchange exactly two collectives (RCCL over xGMI):
+broadcast of the text embeddings from rank 0 and all-gather of the decoded images (device
+buffers, no host staging).
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself (fresh child processes, spawned before anything in this process touches a GPU); under
+`torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.  WORLD_SIZE != --gpus is an error.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
   value     = total denoise steps of all ranks / wall time of the timed region (incl. decode)
   roofline  = dominant kernel (single-stream linear1 GEMM) measured with HIP events on the
               library's stream during the timed region, vs the 2.5 PF dense bf16 MFMA peak
-  cpu_baseline = the restated fp32 oracle (NOT MLX) timed on the host cores on a bounded sample.
+  cpu_baseline = the restated fp32 oracle (NOT MLX) timed on the host cores on ONE denoise step
+              of this very workload (Klein-4B, S = 4608), extrapolated x28 for the image.
 Weights are synthetic (seeded N(0,0.02), bf16) — there are no checkpoints on the box.
+`--dry-run` exercises launcher + rendezvous + both collectives over gloo on CPU tensors with the
+hot path replaced by a placeholder (no compute, no library): a harness self-test, never a result.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="timed batches (one image per GPU each)")
@@ -38,22 +49,84 @@ def main():
     ap.add_argument("--vae", default="standard", choices=["standard", "small"])
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
                     help="transformer block-GEMM format; the headline (BASELINE.json configs[1]) is bf16")
+    ap.add_argument("--attn-softmax", default="auto", choices=["auto", "online"],
+                    help="auto: fixed-offset softmax where the QK-RMSNorm weights bound the scores, running maximum "
+                         "otherwise (what a checkpoint with larger norm scales gets); online: force the running maximum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-class", type=int, default=0, help="kernel class timed with HIP events (0 = linear1 GEMM)")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true", help="harness self-test on CPU/gloo: no GPU, no compute")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args) -> int:
+    """Start --gpus fresh rank processes of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* as torchrun sets them)
+    and wait for them.  Nothing here imports torch or makes a HIP call: the children are the first to touch a GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:          # a rank died: the others would hang in a collective
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def host_threads() -> int:
+    """Threads for the CPU baseline: the cgroup CPU quota where there is one (x2: measured best), else the visible CPUs."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, 2 * int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        sys.exit(launch_ranks(args))
+    if int(env_world or "1") != max(1, args.gpus):
+        sys.exit(f"bench.py: WORLD_SIZE={env_world} but --gpus {args.gpus}: start it as `python bench.py --gpus N` "
+                 f"(self-launching) or under torch.distributed.run with --nproc-per-node equal to --gpus")
 
     import torch
 
     import flux2mi
     from flux2mi import parallel as par
     from flux2mi import synthetic as syn
-    from flux2mi.pipeline import Flux2Pipeline
 
-    rank, world, local = par.init_distributed()
-    assert world == max(1, args.gpus) or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
-    dev_index = local if world > 1 else 0
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    dry = args.dry_run
+    rank, world, local = par.init_distributed(backend="gloo" if dry else None)
+    assert world == max(1, args.gpus), (world, args.gpus)
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        dev_index = local if world > 1 else 0
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
 
     cfg = syn.DIT_PRESETS[args.model]
     vcfg = syn.VAE_PRESETS[args.vae]
@@ -65,94 +138,129 @@ def main():
 
     # ---- model: synthetic weights generated on the GPU, replicated per rank
     t0 = time.time()
-    pipe = Flux2Pipeline(model=args.model, vae_variant=args.vae, device=dev_index, quantization=args.weights)
-    P = syn.make_dit_weights(cfg, seed=1234, device=dev)
-    VP = syn.make_vae_weights(vcfg, seed=4321, device=dev)
-    pipe.load_models(P, VP)
-    if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
-        del P
-    del VP
-    torch.cuda.synchronize()
+    pipe = P = None
+    if not dry:
+        from flux2mi.pipeline import Flux2Pipeline
+        pipe = Flux2Pipeline(model=args.model, vae_variant=args.vae, device=dev.index, quantization=args.weights)
+        P = syn.make_dit_weights(cfg, seed=1234, device=dev)
+        VP = syn.make_vae_weights(vcfg, seed=4321, device=dev)
+        pipe.load_models(P, VP)
+        if args.attn_softmax == "online":
+            pipe.transformer.set_attention_softmax("online")
+        if not (rank == 0 and not args.no_cpu_baseline):
+            del P
+            P = None
+        del VP
+        torch.cuda.synchronize()
     t_load = time.time() - t0
 
     # ---- inputs resident in HBM: per-rank noise (seed 42 + rank), text embeddings on rank 0
     gen = torch.Generator(device=dev)
     gen.manual_seed(42 + rank)
     noise = torch.randn((1, 128, H // 16, W // 16), generator=gen, device=dev, dtype=torch.float32)
-    emb_shape = (world, s_txt, cfg["joint_dim"])
+    J = cfg["joint_dim"] if not dry else 64
+    emb_shape = (world, s_txt, J)
     emb_all = None
     if rank == 0:
         g7 = torch.Generator(device=dev)
         g7.manual_seed(7)
         emb_all = torch.randn(emb_shape, generator=g7, device=dev, dtype=torch.float32).to(torch.bfloat16)
     guidance = 4.0
+    img_dev = torch.zeros((1, H, W, 3), dtype=torch.uint8, device=dev)      # this rank's decoded image, in HBM
+    host_batch = torch.empty((world, H, W, 3), dtype=torch.uint8, pin_memory=not dry) if rank == 0 else None
 
     def one_batch():
         emb = par.broadcast_text_embeddings(emb_all, emb_shape, dev, src=0)          # collective 1
-        res = pipe.generate_text_to_image(height=H, width=W, steps=T, guidance=guidance,
-                                          precomputed_embeddings=emb[rank if world > 1 else 0], noise=noise)
-        img = torch.from_numpy(res.image).to(dev).unsqueeze(0)
-        imgs = par.all_gather_images(img)                                            # collective 2
-        return res, imgs
+        if dry:
+            res = None
+            img_dev.fill_(rank + 1)                                                  # placeholder, no compute
+        else:
+            res = pipe.generate_with_result("textToImage", height=H, width=W, steps=T, guidance=guidance,
+                                            precomputed_embeddings=emb[rank], noise=noise, image_device=img_dev[0],
+                                            return_latents=True)
+        imgs = par.all_gather_images(img_dev)                                        # collective 2 (device buffers)
+        if rank == 0:
+            host_batch.copy_(imgs, non_blocking=False)                               # the batch's D2H copy
+        return res
 
     for _ in range(args.warmup):
         one_batch()
 
     par.barrier()
-    torch.cuda.synchronize()
-    pipe.ctx.prof_begin(args.prof_class)
+    if not dry:
+        torch.cuda.synchronize()
+        pipe.ctx.prof_begin(args.prof_class)
     t_start = time.perf_counter()
     ms_denoise = ms_decode = 0.0
+    res = None
     for _ in range(args.steps):
-        res, imgs = one_batch()
-        ms_denoise += res.msDenoise
-        ms_decode += res.msDecode
-    torch.cuda.synchronize()
+        res = one_batch()
+        if res is not None:
+            ms_denoise += res.msDenoise
+            ms_decode += res.msDecode
+    if not dry:
+        torch.cuda.synchronize()
     par.barrier()
     elapsed = time.perf_counter() - t_start
-    n_launch, prof_ms, prof_flops = pipe.ctx.prof_end()
+    n_launch, prof_ms, prof_flops = (0, 0.0, 0.0) if dry else pipe.ctx.prof_end()
     elapsed = par.all_reduce_max(elapsed, dev)
 
+    # ---- outside the timed region: the output is a real result (finite latents on every rank, a checksum of the batch)
+    ok = 1.0
+    if res is not None:
+        ok = 1.0 if bool(torch.isfinite(res.latents).all()) else 0.0
+    ok = -par.all_reduce_max(-ok, dev)                                               # min over ranks
     if rank != 0:
         par.finalize()
         return
+    assert ok == 1.0, "non-finite latents after the timed region"
+    batch_np = host_batch.numpy()
+    checksum = f"{zlib.crc32(batch_np.tobytes()) & 0xffffffff:08x}"
+    hist = None
+    if not dry:
+        import numpy as np
+        hcount = np.bincount(batch_np.reshape(-1), minlength=256)
+        hist = {"zero_frac": round(float(hcount[0]) / batch_np.size, 4), "full_frac": round(float(hcount[255]) / batch_np.size, 4),
+                "levels_used": int((hcount > 0).sum())}
+        assert hist["levels_used"] > 16, f"decoded image is degenerate: {hist}"
 
     K = args.steps
     total_denoise_steps = world * K * T
     value = total_denoise_steps / elapsed
     sec_per_image = elapsed / K   # latency of one image (every rank produces one per batch)
 
-    # ---- roofline of the dominant kernel: single-stream linear1 GEMM [S,d] x [9d,d]^T
-    flops_per_launch = prof_flops / max(n_launch, 1)
-    avg_ms = prof_ms / max(n_launch, 1)
-    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-    # TFLOP/s dense MFMA, MI355X_MICROARCH.md chip table: bf16 2500, fp8 5000
+    roofline = None
+    step_ms = 0.0
     peak = 5000.0 if args.weights == "fp8" else 2500.0
-    # HBM-side traffic of that kernel from the committed PMC passes (rocprofv3 cannot run inside this
-    # process); null when the summary is not there or another model / size / format is benchmarked
-    traffic = None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_h_linear1_traffic.json")
-    if args.model == "klein-4b" and (H, W) == (1024, 1024) and args.weights == "bf16" and os.path.exists(tpath):
-        with open(tpath) as f:
-            traffic = json.load(f)["traffic_bytes_per_launch"]
-    roofline = {"bound": "mfma", "kernel": "gemm_bf16_256x256_kernel (single_blocks.linear1: [S,d] x [9d,d]^T as two launches: [q|k] with fused RMSNorm+RoPE + SwiGLU rows, and V^T = W_v x^T)",
-                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic,
-                "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
-                "flops_per_launch": flops_per_launch}
-
-    # whole-step algorithmic FLOPs for context
     blocks = cfg["n_double"] + cfg["n_single"]
     step_flops = blocks * (26.0 * S * d * d + 4.0 * S * S * d) + 2.0 * (s_img * 128 * d * 2 + s_txt * cfg["joint_dim"] * d)
-    step_ms = ms_denoise / (K * T)
+    if not dry:
+        # ---- roofline of the dominant kernel: single-stream linear1 GEMM [S,d] x [9d,d]^T
+        flops_per_launch = prof_flops / max(n_launch, 1)
+        avg_ms = prof_ms / max(n_launch, 1)
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        # HBM-side traffic of that kernel from the committed PMC passes (rocprofv3 cannot run inside this
+        # process); null when the summary is not there or another model / size / format is benchmarked
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "linear1_traffic.json")
+        if args.model == "klein-4b" and (H, W) == (1024, 1024) and args.weights == "bf16" and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f)["traffic_bytes_per_launch"]
+        roofline = {"bound": "mfma", "kernel": pipe.ctx.prof_kernel_name(args.prof_class),
+                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
+                    "flops_per_launch": flops_per_launch}
+        step_ms = ms_denoise / (K * T)
 
     cpu_baseline = None
-    if world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(P, cfg, syn)
+    if world == 1 and not dry and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(P, cfg, syn, H, W, T, s_txt)
 
     out = {
-        "metric": f"denoise-steps/sec (Flux.2 {args.model} {H}x{W} @ {T} steps; seconds/image reported alongside)",
-        "value": round(value, 4),
+        "metric": f"denoise-steps/sec (Flux.2 {args.model} {H}x{W} @ {T} steps; seconds/image reported alongside)"
+                  + (" — DRY RUN: launcher/collectives self-test, no compute" if dry else ""),
+        "value": None if dry else round(value, 4),
         "unit": "denoise-steps/s",
         "n_gpus": world,
         "steps": K,
@@ -163,42 +271,56 @@ def main():
         "vs_baseline": None,
         "dtype": "bf16" if args.weights == "bf16" else "fp8 (e4m3 block GEMMs; bf16 attention, f32 residual)",
         "data": "synthetic",
-        "config": {"workload": f"Flux.2 {args.model} {args.weights}, {H}x{W}, {T} denoise steps + {args.vae} VAE decode + D2H, "
-                               f"1 image per GPU per bench step (BASELINE.json configs[1])",
+        "config": {"workload": f"Flux.2 {args.model} {args.weights}, {H}x{W}, {T} denoise steps + {args.vae} VAE decode + "
+                               f"image all-gather + D2H, 1 image per GPU per bench step (BASELINE.json configs[1])",
                    "images_per_bench_step": world, "s_txt": s_txt, "s_img": s_img, "parallelism": f"dp{world}"},
         "seconds_per_image": round(sec_per_image, 4),
         "denoise_ms_per_denoise_step": round(step_ms, 3),
         "decode_ms_per_image": round(ms_decode / K, 3),
         "dit_step_tflops": round(step_flops / (step_ms * 1e-3) / 1e12, 2) if step_ms > 0 else None,
         "dit_step_mfma_frac": round(step_flops / (step_ms * 1e-3) / 1e12 / peak, 4) if step_ms > 0 else None,
+        "attention_softmax": None if dry else pipe.transformer.attention_softmax_paths(),
+        "output_check": {"latents_finite": True, "image_crc32": checksum, "u8_histogram": hist},
         "model_load_s": round(t_load, 2),
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
     }
+    if dry:
+        out["dry_run"] = True
     print(json.dumps(out), flush=True)
     par.finalize()
 
 
-def run_cpu_baseline(P_dev, cfg, syn):
-    """The restated oracle (torch CPU fp32 — NOT the reference's MLX path, which cannot run
-    here) on a bounded sample: ONE DiT forward of the same model at 256x256 (S = 768,
-    4.9 TFLOP).  Reported in the metric's unit for that sample."""
+def run_cpu_baseline(P_dev, cfg, syn, H, W, T, s_txt):
+    """The restated oracle (torch CPU fp32 — NOT the reference's MLX path, which cannot run here) on a bounded
+    sample of THE metric's workload: ONE denoise step (one DiT forward at S = s_txt + HW/256) of the same model,
+    size and inputs; the image time is that x T (extrapolated, no VAE).  BASELINE.md §3.  A 256x256 forward
+    (config A's step) is timed alongside."""
     import torch
 
     from oracle import flux2_ref as R
 
-    cores = torch.get_num_threads()
+    cores = host_threads()
+    torch.set_num_threads(cores)
     Pc = {k: v.cpu() for k, v in P_dev.items()}
-    inp = syn.make_inputs(cfg, 256, 256, s_txt=512)
-    lat = R.pack_patchified_to_sequence(inp["noise"])
-    ii, ti = R.image_position_ids(256, 256), R.text_position_ids(512)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        R.dit_forward(Pc, cfg, lat, inp["txt"].float(), torch.tensor([0.9]), None, ii, ti)
-    dt = time.perf_counter() - t0
+
+    def one(h, w):
+        inp = syn.make_inputs(cfg, h, w, s_txt=s_txt)
+        lat = R.pack_patchified_to_sequence(inp["noise"])
+        ii, ti = R.image_position_ids(h, w), R.text_position_ids(s_txt)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            R.dit_forward(Pc, cfg, lat, inp["txt"].float(), torch.tensor([0.9]), torch.tensor([4.0]) if cfg["guidance"] else None, ii, ti)
+        return time.perf_counter() - t0
+
+    dt_small = one(256, 256)
+    dt = one(H, W)
     return {"value": round(1.0 / dt, 5), "unit": "denoise-steps/s", "cores": cores, "kind": "port",
-            "sample": "1 DiT forward of the restated fp32 oracle (torch CPU), Klein-4B, 256x256 (S=768, 4.92 TFLOP); "
-                      "the 1024x1024 step is 7.1x more FLOPs", "seconds": round(dt, 2)}
+            "sample": f"1 denoise step (DiT forward) of the restated fp32 oracle (torch CPU, {cores} threads = 2 per core of the "
+                      f"cgroup quota), same model / {H}x{W} / S={s_txt + (H // 16) * (W // 16)} as the metric",
+            "seconds_per_step": round(dt, 2), "extrapolated": True,
+            "seconds_per_image_extrapolated": round(dt * T, 1),
+            "sample_256": {"seconds_per_step": round(dt_small, 2), "steps_per_s": round(1.0 / dt_small, 4)}}
 
 
 if __name__ == "__main__":

@@ -122,6 +122,8 @@ PROTOTYPES = {
     "flux2mi_dit_merge_lora": (_I, [_P, C.c_char_p, _I, _P, _P, _I, _F]),
     "flux2mi_dit_param_bytes": (_I64, [_P]),
     "flux2mi_dit_forward": (_I, [_P, _P, _I, _P, _I, _F, _F, _P, _P, _P, _I]),
+    "flux2mi_dit_set_attention_softmax": (_I, [_P, _I]),
+    "flux2mi_dit_attention_softmax_info": (_I, [_P, _PI, _PI]),
     "flux2mi_kv_cache_create": (_I, [_P, _I, _I, C.POINTER(_P)]),
     "flux2mi_kv_cache_destroy": (_I, [_P]),
     "flux2mi_dit_forward_kv_extract": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _F, _F, _P, _P, _P, _P]),
@@ -148,6 +150,7 @@ PROTOTYPES = {
     "flux2mi_prof_begin": (_I, [_P, _I]),
     "flux2mi_prof_end": (_I, [_P, _PI, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "flux2mi_op_gemm_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I]),
+    "flux2mi_op_gemm_bf16_ex": (_I, [_P, _P, _I, C.c_longlong, _P, _I, C.c_longlong, _P, _I, _I, _I]),
     "flux2mi_op_gemm_fp8": (_I, [_P, _P, _P, _P, _I, _I, _I]),
     "flux2mi_op_gemm_gate_resid": (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
     "flux2mi_op_attention": (_I, [_P, _P, _P, _I, _I]),

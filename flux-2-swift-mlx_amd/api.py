@@ -284,12 +284,30 @@ class Context:
     def prof_begin(self, kernel_class: int):
         check(lib().flux2mi_prof_begin(self.handle, kernel_class))
 
+    PROF_KERNELS = {
+        0: "gemm_bf16_256x256_kernel (single_blocks.linear1: [S,d] x [9d,d]^T as two launches: [q|k] with fused RMSNorm+RoPE "
+           "+ SwiGLU rows, and V^T = W_v x^T)",
+        1: "gemm_bf16_256x256_kernel / gemm_bf16_128x128_kernel (every DiT GEMM)",
+        2: "attn_fwd_kernel (joint attention)",
+        3: "conv2d_g128_kernel / conv2d_kernel (VAE convolutions)",
+    }
+
+    def prof_kernel_name(self, kernel_class: int) -> str:
+        return self.PROF_KERNELS.get(kernel_class, str(kernel_class))
+
     def prof_end(self):
         n, ms, fl = C.c_int(0), C.c_double(0.0), C.c_double(0.0)
         check(lib().flux2mi_prof_end(self.handle, C.byref(n), C.byref(ms), C.byref(fl)))
         return n.value, ms.value, fl.value
 
     # ---- standalone ops
+    def op_gemm_bf16_ex(self, a, lda, a_kstride, w, ldw, w_kstride, m, n, k) -> torch.Tensor:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+        self._enter()
+        check(lib().flux2mi_op_gemm_bf16_ex(self.handle, _ptr(a), lda, a_kstride, _ptr(w), ldw, w_kstride, _ptr(out), m, n, k))
+        self._exit()
+        return out
+
     def op_gemm_bf16(self, a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
         a, w = _req(a, torch.bfloat16, "A"), _req(w, torch.bfloat16, "W")
         m, k = a.shape
@@ -458,6 +476,17 @@ class DiT:
     @property
     def param_bytes(self) -> int:
         return int(lib().flux2mi_dit_param_bytes(self.handle))
+
+    def set_attention_softmax(self, mode: str):
+        """"auto": fixed-offset softmax in the blocks whose QK-RMSNorm weights bound the scores; "online": running maximum
+        everywhere (what blocks with larger norm scales get anyway)."""
+        check(lib().flux2mi_dit_set_attention_softmax(self.handle, {"auto": 0, "online": 1}[mode]))
+        return self
+
+    def attention_softmax_paths(self) -> dict:
+        fx, on = C.c_int(0), C.c_int(0)
+        check(lib().flux2mi_dit_attention_softmax_info(self.handle, C.byref(fx), C.byref(on)))
+        return {"fixed_offset_blocks": fx.value, "online_blocks": on.value}
 
     def forward(self, latents: torch.Tensor, txt_emb: torch.Tensor, timestep: float, guidance: float,
                 img_ids: torch.Tensor, txt_ids: torch.Tensor, s_out: Optional[int] = None) -> torch.Tensor:

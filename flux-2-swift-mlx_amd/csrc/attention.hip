@@ -349,23 +349,27 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
 
 }  // namespace
 
+// p >= 2^(-2 bound): 2 * 40 stays far inside the f32 / bf16 exponent range
+bool attention_uses_fixed_offset(float score_bound_log2) {
+    static const int fixm_on = [] {   // FLUX2MI_ATTN_FIXM=0 keeps the running maximum everywhere (dev A/B runs)
+        const char* e = F2_DEV_ENV("FLUX2MI_ATTN_FIXM");
+        return e ? atoi(e) : 1;
+    }();
+    return fixm_on && score_bound_log2 > 0.f && score_bound_log2 <= 40.f;
+}
+
 int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
                      int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads, float score_bound_log2, bool q_prescaled) {
     if (Sq <= 0 || S <= 0 || heads <= 0 || (ldqk & 7) || (ldo & 3) || s_pad < attn_s_pad(S) || (s_pad & 7)) return 1;
     const float scale_log2e = q_prescaled ? 1.0f : 1.4426950408889634f / sqrtf((float)HD);
     static const int nw_env = [] {   // FLUX2MI_ATTN_NW=4|8 forces a workgroup size (A/B runs)
-        const char* e = getenv("FLUX2MI_ATTN_NW");
+        const char* e = F2_DEV_ENV("FLUX2MI_ATTN_NW");
         return e ? atoi(e) : 0;
     }();
     // 8-wave workgroups (one per CU) when the 4-wave grid would be under two full rounds of the 512
     // workgroup slots (Klein-4B: 864): +0.6 % on the step; 4-wave ones are faster on larger grids
     const int nw = nw_env ? nw_env : (((long)((Sq + 127) / 128) * heads < 1024 && Sq >= 1024) ? 8 : 4);
-    static const int fixm_on = [] {   // FLUX2MI_ATTN_FIXM=0 keeps the running maximum everywhere (A/B runs)
-        const char* e = getenv("FLUX2MI_ATTN_FIXM");
-        return e ? atoi(e) : 1;
-    }();
-    // p >= 2^(-2 bound): 2 * 40 stays far inside the f32 / bf16 exponent range
-    const bool fixm = fixm_on && score_bound_log2 > 0.f && score_bound_log2 <= 40.f;
+    const bool fixm = attention_uses_fixed_offset(score_bound_log2);
     const dim3 grid((Sq + nw * 32 - 1) / (nw * 32), heads), block(nw * 64);
 #define ATTN_GO(NW_, FX_) hipLaunchKernelGGL((attn_fwd_kernel<false, NW_, FX_>), grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, scale_log2e, S, 1, score_bound_log2, 0)
     const int fx = fixm ? (q_prescaled ? 2 : 1) : 0;

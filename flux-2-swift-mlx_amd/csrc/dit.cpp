@@ -72,6 +72,7 @@ struct flux2mi_dit {
     std::vector<Buf> bufs;
     std::unordered_map<std::string, Slot> slots;
     bool finalized = false;
+    int attn_softmax_mode = 0;  // 0: fixed-offset softmax where score_bound allows it; 1: running maximum everywhere
     bool lora_merged = false;  // a LoRA was merged into the resident weights (tagged in pre-quantized exports)
     int64_t param_bytes = 0;
 
@@ -893,11 +894,12 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     // the score scale log2(e)/sqrt(128) rides on Q from the norm+RoPE kernel (one rounding, as before), so the
     // attention's softmax needs no multiply (FLUX2MI_ATTN_PRESCALE=0: scale inside the attention, for A/B runs)
     static const bool q_pre = [] {
-        const char* e = getenv("FLUX2MI_ATTN_PRESCALE");
+        const char* e = F2_DEV_ENV("FLUX2MI_ATTN_PRESCALE");
         return e ? atoi(e) != 0 : true;
     }();
     const float q_mul = q_pre ? 1.4426950408889634f / sqrtf(128.0f) : 1.0f;
     auto attend = [&](int layer, uint16_t* o_buf, int ldo, float score_bound) -> int {
+        if (m->attn_softmax_mode == 1) score_bound = 0.f;   // no bound given: launch_attention keeps the running maximum
         if (mode == FWD_KV_EXTRACT) {
             F2_CHECK_HIP(hipMemcpy2DAsync(cache->k(layer), (size_t)d * 2, qkv + (size_t)s_txt * 3 * d + d, (size_t)3 * d * 2,
                                           (size_t)d * 2, (size_t)s_ref, hipMemcpyDeviceToDevice, st));
@@ -928,10 +930,10 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     // FLUX2MI_QK_FUSE=0: QK norm + RoPE as a separate kernel after the qkv projection (A/B runs).  The fused form needs
     // whole heads inside a 256-column tile and the 256x256 bf16 kernel (>= 100 tiles, see launch_gemm).
     static const bool qk_fuse_on = [] {
-        const char* e = getenv("FLUX2MI_QK_FUSE");
+        const char* e = F2_DEV_ENV("FLUX2MI_QK_FUSE");
         return e ? atoi(e) != 0 : true;
     }();
-    const bool qk_fuse_ok = qk_fuse_on && d % 256 == 0 && !getenv("FLUX2MI_GEMM") && !getenv("FLUX2MI_GEMM_V");
+    const bool qk_fuse_ok = qk_fuse_on && d % 256 == 0 && !F2_DEV_ENV("FLUX2MI_GEMM") && !F2_DEV_ENV("FLUX2MI_GEMM_V");
     // decided on the whole sequence S, not on the live rows of this pass: a KV-cached pass (fewer live rows) must
     // treat q / k exactly like the extraction pass whose keys it reuses
     const bool qk_fuse_dbl = qk_fuse_ok && (long)((S + 255) / 256) * ((3 * d + 255) / 256) >= 100;
@@ -939,7 +941,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     // activation, C = vt, key order permuted in the store): no V round trip through qkv, no transpose kernel.
     // Plain forwards only (the KV-cache passes move reference columns of vt around on unaligned boundaries).
     static const bool vt_gemm_on = [] {
-        const char* e = getenv("FLUX2MI_VT_GEMM");
+        const char* e = F2_DEV_ENV("FLUX2MI_VT_GEMM");
         return e ? atoi(e) != 0 : true;
     }();
     // (only when the V^T launch fills the chip on its own: at 256x256 it is 36 workgroups and the step got 12 % slower)
@@ -1084,6 +1086,27 @@ extern "C" int flux2mi_dit_forward(flux2mi_dit* m, const float* latents, int s_i
                             txt_ids, nullptr, out, s_out);
 }
 
+// Which softmax form the attention of each block runs.  The fixed-offset form (attention.hip, FIXM) needs the block's
+// QK-RMSNorm weights to bound the scores: 16.8 max|w_q| max|w_k| <= 40 in the log2 domain; blocks of a checkpoint with
+// larger norm scales keep the running maximum (online softmax), which costs ~11 % more attention time.
+extern "C" int flux2mi_dit_set_attention_softmax(flux2mi_dit* m, int mode) {
+    F2_REQUIRE(m && (mode == 0 || mode == 1), FLUX2MI_ERR_INVALID_ARG, "dit_set_attention_softmax: mode 0 (auto) or 1 (online)");
+    m->attn_softmax_mode = mode;
+    return FLUX2MI_OK;
+}
+
+extern "C" int flux2mi_dit_attention_softmax_info(const flux2mi_dit* m, int* n_fixed_offset, int* n_online) {
+    F2_REQUIRE(m && n_fixed_offset && n_online, FLUX2MI_ERR_INVALID_ARG, "dit_attention_softmax_info: NULL argument");
+    F2_REQUIRE(m->finalized, FLUX2MI_ERR_NOT_LOADED, "dit_attention_softmax_info: weights not finalized");
+    int fx = 0, on = 0;
+    auto count = [&](float bound) { (m->attn_softmax_mode == 0 && attention_uses_fixed_offset(bound) ? fx : on) += 1; };
+    for (const auto& b : m->dbl) count(b.score_bound);
+    for (const auto& b : m->sgl) count(b.score_bound);
+    *n_fixed_offset = fx;
+    *n_online = on;
+    return FLUX2MI_OK;
+}
+
 // ------------------------------------------------------------------ KV-cached reference conditioning
 extern "C" int flux2mi_kv_cache_create(flux2mi_dit* m, int s_txt, int s_ref, flux2mi_kv_cache** out) {
     F2_REQUIRE(m && out && s_txt > 0 && s_ref > 0, FLUX2MI_ERR_INVALID_ARG, "kv_cache_create: bad argument");
@@ -1151,6 +1174,22 @@ extern "C" int flux2mi_op_gemm_bf16(flux2mi_ctx* ctx, const void* A, const void*
     const int r = launch_gemm(ctx->stream, &p, 1);
     prof_after(ctx, PROF_DIT_GEMM, 2.0 * M * (double)N * K);
     F2_LAUNCH(r, "op_gemm");
+    return FLUX2MI_OK;
+}
+
+// C = A W^T with explicit operand strides: lda / ldw in elements, a_kstride / w_kstride = bytes between consecutive
+// 128-byte K-tile pieces of a row (0 = contiguous rows).  Layout experiments of tools/gemm_bench.py (256x256 kernel only).
+extern "C" int flux2mi_op_gemm_bf16_ex(flux2mi_ctx* ctx, const void* A, int lda, long long a_kstride, const void* W, int ldw,
+                                       long long w_kstride, float* C, int M, int N, int K) {
+    F2_REQUIRE(ctx && A && W && C && M > 0 && N > 0 && K > 0 && K % 64 == 0, FLUX2MI_ERR_INVALID_ARG, "op_gemm_ex: bad argument");
+    F2_REQUIRE((long)((M + 255) / 256) * ((N + 255) / 256) >= 100, FLUX2MI_ERR_UNSUPPORTED, "op_gemm_ex: needs >= 100 tiles (256x256 kernel)");
+    GemmProblem p = mk(reinterpret_cast<const uint16_t*>(A), lda, reinterpret_cast<const uint16_t*>(W), ldw, C, N, M, N, K, EPI_F32);
+    p.a_kstride = a_kstride;
+    p.w_kstride = w_kstride;
+    prof_before(ctx, PROF_DIT_GEMM);
+    const int r = launch_gemm(ctx->stream, &p, 1);
+    prof_after(ctx, PROF_DIT_GEMM, 2.0 * M * (double)N * K);
+    F2_LAUNCH(r, "op_gemm_ex");
     return FLUX2MI_OK;
 }
 

@@ -14,8 +14,8 @@
 //   body:  64 MFMA on frags(s), with in the gaps: 16 ds_read (frags(s+1) <- half-stage (s+1)&3),
 //          8 ds_write (data(s+2), staging set s&1 -> half-stage (s+2)&3), then 8 global loads
 //          (data(s+4) -> staging set s&1).
-#include "dev.h"
-#include "kernels.h"
+#include "../dev.h"
+#include "../kernels.h"
 #include <stdlib.h>
 
 namespace {
@@ -357,7 +357,7 @@ int launch_gemm256_r4(hipStream_t stream, const GemmProblem* probs, int nprob) {
     if (nprob == 1) b.p[1] = probs[0];
     b.tile_start1 = tiles[0];
     static const int abl = [] {
-        const char* e = getenv("FLUX2MI_GEMM_ABLATE");
+        const char* e = F2_DEV_ENV("FLUX2MI_GEMM_ABLATE");
         return e ? atoi(e) : 0;
     }();
     const dim3 grid(tiles[0] + tiles[1]), block(256);

@@ -17,8 +17,8 @@
 //             ds_read frags(s+1) <- half-stage (s+1)&3     (16 x ds_read_b128)
 //             64 x MFMA 16x16x32 on frags(s)
 // DMA data has three sub-steps (~3 x 1024 MFMA cycles) to land; vmcnt is never 0 in the loop.
-#include "dev.h"
-#include "kernels.h"
+#include "../dev.h"
+#include "../kernels.h"
 #include <stdlib.h>
 
 namespace {
@@ -331,7 +331,7 @@ int launch_gemm256_w4(hipStream_t stream, const GemmProblem* probs, int nprob) {
     if (nprob == 1) b.p[1] = probs[0];
     b.tile_start1 = tiles[0];
     static const int abl = [] {
-        const char* e = getenv("FLUX2MI_GEMM_ABLATE");
+        const char* e = F2_DEV_ENV("FLUX2MI_GEMM_ABLATE");
         return e ? atoi(e) : 0;
     }();
     const dim3 grid(tiles[0] + tiles[1]), block(256);

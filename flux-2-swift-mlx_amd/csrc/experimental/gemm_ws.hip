@@ -14,8 +14,8 @@
 //   loader  it. t:  DMA tile t+2 -> stage (t+2)%3 ; s_waitcnt vmcnt(12) [tile t+1 landed] ; barrier
 //   consumer it. t: fragments of tile t <- stage t%3 ; 64 MFMA ; lgkmcnt(0) ; barrier
 // (stage (t+2)%3 held tile t-1, whose reads retired before the barrier that ended iteration t-1.)
-#include "dev.h"
-#include "kernels.h"
+#include "../dev.h"
+#include "../kernels.h"
 #include <stdlib.h>
 
 namespace {

@@ -313,7 +313,7 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
     // large problems -> 256x256 LDS-DMA kernel (gemm256.hip); FLUX2MI_GEMM=128|256 forces a kernel
     {
         static const int force = [] {
-            const char* e = getenv("FLUX2MI_GEMM");
+            const char* e = F2_DEV_ENV("FLUX2MI_GEMM");
             return e ? atoi(e) : 0;
         }();
         long tiles256 = 0;
@@ -323,7 +323,7 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
         for (int i = 0; i < nprob; ++i)
             if (probs[i].epi == EPI_QKV_MLP && probs[i].n_split % 256 != 0) big = false;  // a 256-wide tile must not straddle the split
         static const int ver = [] {
-            const char* e = getenv("FLUX2MI_GEMM_V");
+            const char* e = F2_DEV_ENV("FLUX2MI_GEMM_V");
             return e ? atoi(e) : 2;
         }();
         bool fused_qk = false;   // only the 256x256 kernel (gemm256.hip) applies GemmProblem::qk_*
@@ -331,9 +331,14 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
         if (fused_qk && (force == 128 || ver != 2)) return 1;
         if (fused_qk) big = true;   // the caller decides fusion per model and sequence, not per launch (dit.cpp)
         if (force == 256 || (force != 128 && big))
-            return ver == 5 ? launch_gemm_ws(stream, probs, nprob)
-                 : ver == 4 ? launch_gemm256_r4(stream, probs, nprob)
-                 : ver == 3 ? launch_gemm256_w4(stream, probs, nprob) : launch_gemm256(stream, probs, nprob);
+        {
+#ifdef FLUX2MI_DEV   // experimental structures (csrc/experimental/, `make dev` only)
+            if (ver == 5) return launch_gemm_ws(stream, probs, nprob);
+            if (ver == 4) return launch_gemm256_r4(stream, probs, nprob);
+            if (ver == 3) return launch_gemm256_w4(stream, probs, nprob);
+#endif
+            return launch_gemm256(stream, probs, nprob);
+        }
     }
     GemmBatch b;
     b.nprob = nprob;

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         src[KIND_B0][j] = gW + (size_t)min(n0 + b_row0, p.N - 1) * p.ldw * ES + chunk * 16;
         src[KIND_B1][j] = gW + (size_t)min(n0 + b_row0 + 32, p.N - 1) * p.ldw * ES + chunk * 16;
     }
+    const long long ksA = p.a_kstride ? p.a_kstride : 128, ksB = p.w_kstride ? p.w_kstride : 128;
     const int lds_wave = wid * 1024;  // + j*8192 + slot*SLOT_BYTES + stage*STAGE2_BYTES
     const int nk = p.K / TILE_K;
     const int total_elems = nk * 4;
@@ -147,8 +148,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         const int u__ = (u_);                                                                                 \
         if (u__ < nk && !((kind_) == KIND_A1 && a1_skip)) {                                                   \
             uint8_t* dst__ = smem + (u__ & 1) * STAGE2_BYTES + (kind_) * SLOT_BYTES + lds_wave;               \
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[kind_][0] + u__ * 128), (lptr_t)(dst__), 16, 0, 0);      \
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[kind_][1] + u__ * 128), (lptr_t)(dst__ + 8192), 16, 0, 0); \
+            const long long ko__ = u__ * (((kind_) == KIND_A0 || (kind_) == KIND_A1) ? ksA : ksB);            \
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[kind_][0] + ko__), (lptr_t)(dst__), 16, 0, 0);      \
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[kind_][1] + ko__), (lptr_t)(dst__ + 8192), 16, 0, 0); \
         }                                                                                                     \
     }
 
@@ -677,7 +679,7 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
     // Tile height by wave quantisation: rounds of 256 workgroups x relative tile cost (+2 % per row block dropped for
     // the lower arithmetic intensity); ties keep the taller tile.  FLUX2MI_GEMM_NI=8 forces 256 rows (A/B runs).
     static const int ni_force = [] {
-        const char* e = getenv("FLUX2MI_GEMM_NI");
+        const char* e = F2_DEV_ENV("FLUX2MI_GEMM_NI");
         return e ? atoi(e) : 0;
     }();
     auto count_tiles = [&](int ni, int* per) {
@@ -690,8 +692,8 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
         return tot;
     };
     // the ablation / diagnostic / schedule-variant instantiations only exist for the 256-row tile
-    static const bool dev_env = getenv("FLUX2MI_GEMM_ABLATE") || getenv("FLUX2MI_GEMM_VAR") || getenv("FLUX2MI_GEMM_STAGGER") ||
-                                getenv("FLUX2MI_GEMM_DIAG");
+    static const bool dev_env = F2_DEV_ENV("FLUX2MI_GEMM_ABLATE") || F2_DEV_ENV("FLUX2MI_GEMM_VAR") || F2_DEV_ENV("FLUX2MI_GEMM_STAGGER") ||
+                                F2_DEV_ENV("FLUX2MI_GEMM_DIAG");
     int ni = 8;
     if (dev_env) ni = 8;
     else if (ni_force >= 5 && ni_force <= 8) ni = ni_force;
@@ -717,12 +719,12 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
     b.tile_start1 = tiles[0];
     // bit 0: 16-byte bf16 / SwiGLU epilogue stores (FLUX2MI_GEMM_FLAGS=0 for A/B runs: linear1 0.617 -> 0.604 ms)
     static const int flags = [] {
-        const char* e = getenv("FLUX2MI_GEMM_FLAGS");
+        const char* e = F2_DEV_ENV("FLUX2MI_GEMM_FLAGS");
         return e ? atoi(e) : 1;
     }();
     b.flags = flags;
     b.trace = nullptr;
-    static const char* trace_path = getenv("FLUX2MI_GEMM_TRACE");
+    static const char* trace_path = F2_DEV_ENV("FLUX2MI_GEMM_TRACE");
     static int trace_seen = 0;
     const bool trace_now = trace_path && probs[0].epi == EPI_QKV_MLP && !probs[0].fp8 && ++trace_seen == 30;   // a warm linear1
     const size_t trace_n = (size_t)(tiles[0] + tiles[1]) * 8 * 8;
@@ -741,11 +743,11 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
     static const int abl = [] {
-        const char* e = getenv("FLUX2MI_GEMM_ABLATE");
+        const char* e = F2_DEV_ENV("FLUX2MI_GEMM_ABLATE");
         return e ? atoi(e) : 0;
     }();
     static const int stagger = [] {
-        const char* e = getenv("FLUX2MI_GEMM_STAGGER");
+        const char* e = F2_DEV_ENV("FLUX2MI_GEMM_STAGGER");
         return e ? atoi(e) : 1;
     }();
     const dim3 grid(tiles[0] + tiles[1]), block(512);
@@ -753,7 +755,7 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
     // over a wait in every phase: linear1 0.649 -> 0.605 ms, 8192^3 1224 -> 1326 TF on one box) and
     // the fragment-read wait behind the phase's first barrier (+0..1 %)
     static const int var = [] {
-        const char* e = getenv("FLUX2MI_GEMM_VAR");
+        const char* e = F2_DEV_ENV("FLUX2MI_GEMM_VAR");
         return e ? atoi(e) : 3;
     }();
     if (abl == 32 || abl == 64) {
@@ -779,7 +781,7 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
     static const int diag = [] {
-        const char* e = getenv("FLUX2MI_GEMM_DIAG");
+        const char* e = F2_DEV_ENV("FLUX2MI_GEMM_DIAG");
         return e ? atoi(e) : 0;
     }();
     if (diag && nprob == 1 && probs[0].epi == EPI_F32) {

@@ -1,6 +1,16 @@
 // kernels.h — launchers of the gfx950 kernels (defined in *.hip).  Every launcher
 // enqueues on `stream` and returns 0 on success (1 = bad argument, 2 = launch error).
 #pragma once
+// Development switches (A/B runs, ablations, diagnostics) are environment variables read through F2_DEV_ENV.  They
+// exist only in the development library (`make dev` -> libflux2mi_dev.so, -DFLUX2MI_DEV); in the product library the
+// macro is a null pointer constant, every switch folds to its default and no environment variable can change a result.
+#ifdef FLUX2MI_DEV
+#include <stdlib.h>
+#define F2_DEV_ENV(name) getenv(name)
+#else
+#define F2_DEV_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -31,6 +41,10 @@ struct GemmProblem {
     const float* a_scale;
     const float* w_scale;
     int fp8;
+    // 256x256 kernel: bytes from one 128-byte K-tile piece of a row to the next (0 = 128: plain row-major rows).
+    // rows * 128 with lda / ldw = 128 bytes' worth of elements describes the K-blocked layout [K/tile][rows][128 B],
+    // in which the 256-row slice a workgroup stages per K-tile is one contiguous 32 KB block.
+    long long a_kstride, w_kstride;
     // 256x256 kernel, EPI_BF16 columns [0, qk_cols) (= q | k of a fused qkv projection, qk_cols = 2*dim, dim % 256 == 0):
     // per-head RMSNorm (eps 1e-6, weights qk_qw / qk_kw bf16 [128]) + RoPE applied to the f32 accumulators before
     // the store — what launch_qk_norm_rope_vt does in a separate pass over the stored bf16 values; q additionally
@@ -68,6 +82,8 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob);
 // q_prescaled: Q already carries the factor log2(e)/sqrt(128) (launch_qk_norm_rope_vt's q_mul), so the scores
 // come out of the MFMA in the log2 domain; with a bound the offset is then taken as ZERO and p = exp2(s)
 // needs no multiply-add at all (p in [2^-40, 2^40]: far inside f32 / bf16 range, any offset cancels in O / l).
+// true when launch_attention takes the fixed-offset softmax for this score bound (log2 domain; 0 = no bound known)
+bool attention_uses_fixed_offset(float score_bound_log2);
 int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
                      int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads, float score_bound_log2 = 0.f,
                      bool q_prescaled = false);

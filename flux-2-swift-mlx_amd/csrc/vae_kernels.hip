@@ -506,7 +506,7 @@ int launch_conv2d(hipStream_t stream, const ConvArgs& a) {
     const int cout_pad = ((a.Cout + 31) / 32) * 32;
     // the heavy decoder / encoder convolutions: 128x128x64 tiles (FLUX2MI_CONV=32 keeps the first kernel, A/B runs)
     static const int conv_force = [] {
-        const char* e = getenv("FLUX2MI_CONV");
+        const char* e = F2_DEV_ENV("FLUX2MI_CONV");
         return e ? atoi(e) : 0;
     }();
     if (conv_force != 32 && a.Cin % 32 == 0 && a.Cin >= 64 && a.Cout % 32 == 0 && a.Cout >= 96 && a.y && !a.y_f32_nchw && !a.y_u8_hwc &&

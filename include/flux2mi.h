@@ -377,6 +377,13 @@ typedef struct flux2mi_generate_params {
     float ms_decode;               /* phases "7. VAE Decode" + "8. Post-processing" */
 } flux2mi_generate_params;
 
+/* Softmax form of the DiT's joint attention (replaces MLXFast.scaledDotProductAttention, Flux2Attention.swift:168,
+ * Flux2ParallelAttention.swift:104 — the same softmax either way, any offset cancels in O / l).
+ * mode 0 (default): blocks whose QK-RMSNorm weights bound the scores take the fixed-offset form, the others the
+ * running-maximum (online) form; mode 1: running maximum everywhere.  _info reports how many blocks take which form. */
+int flux2mi_dit_set_attention_softmax(flux2mi_dit* dit, int mode);
+int flux2mi_dit_attention_softmax_info(const flux2mi_dit* dit, int* n_fixed_offset, int* n_online);
+
 int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae* vae, flux2mi_generate_params* p);
 
 /* ---- measurement aid ---------------------------------------------------- */
@@ -389,6 +396,10 @@ int flux2mi_prof_end(flux2mi_ctx* ctx, int* n_launches, double* total_ms, double
 /* Standalone op entry points (tests / microbenchmarks; same kernels the forward uses). */
 /* C[M,N] (f32) = A[M,K] (bf16) * W[N,K]^T (bf16) */
 int flux2mi_op_gemm_bf16(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K);
+/* the same product with explicit operand layouts (microbenchmarks of operand layouts): lda / ldw in elements,
+ * a_kstride / w_kstride = bytes between consecutive 128-byte K pieces of a row (0 = contiguous rows) */
+int flux2mi_op_gemm_bf16_ex(flux2mi_ctx* ctx, const void* A, int lda, long long a_kstride, const void* W, int ldw,
+                            long long w_kstride, float* C, int M, int N, int K);
 /* X f32 [M,N] += gate f32 [N] (per column) * (A W^T): the gate + residual epilogue of the block output GEMMs
  * (Flux2TransformerBlock.swift:117-166 applyGate + residual). */
 int flux2mi_op_gemm_gate_resid(flux2mi_ctx* ctx, const void* A, const void* W, const float* gate, float* X, int M,

@@ -50,3 +50,38 @@ def test_dp_world_size_2_gloo():
         p.join(timeout=180)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert sorted(q.get(timeout=5) for _ in range(world)) == list(range(world))
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts two fresh ranks itself (the parent touches no GPU), which
+    rendezvous on 127.0.0.1, run both collectives and print ONE JSON line from rank 0 with n_gpus = 2.  --dry-run:
+    gloo on CPU tensors, the hot path replaced by a placeholder (rank r's image is filled with r + 1)."""
+    import zlib
+    r, out = _run_bench(["--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1", "--height", "64", "--width", "64"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert sum(1 for l in r.stdout.splitlines() if l.startswith("{")) == 1
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["value"] is None and out["steps"] == 2
+    assert out["config"]["images_per_bench_step"] == 2 and out["config"]["parallelism"] == "dp2"
+    expect = bytes([1]) * (64 * 64 * 3) + bytes([2]) * (64 * 64 * 3)      # all-gathered batch in rank order
+    assert out["output_check"]["image_crc32"] == f"{zlib.crc32(expect) & 0xffffffff:08x}"
+
+
+def test_bench_refuses_world_size_mismatch():
+    """--gpus 8 inside a 1-rank environment (or any WORLD_SIZE != --gpus) must fail instead of reporting n_gpus = 1."""
+    r, out = _run_bench(["--gpus", "8", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and out is None
+    assert "WORLD_SIZE" in r.stderr
+    r, out = _run_bench(["--gpus", "1", "--dry-run"], env_extra={"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and out is None
