@@ -108,6 +108,20 @@ PROTOTYPES = {
     "flux2mi_mlx_random_bits": (_I, [_P, C.POINTER(C.c_uint32), _P, _I64]),
     "flux2mi_mlx_random_uniform": (_I, [_P, C.POINTER(C.c_uint32), _P, _I64, _F, _F]),
     "flux2mi_mlx_random_normal": (_I, [_P, C.POINTER(C.c_uint32), _P, _I64]),
+    "flux2mi_array_alloc": (_I, [_P, C.POINTER(_I64), _I, C.POINTER(_P)]),
+    "flux2mi_array_from_scalar": (_I, [_P, _F, C.POINTER(_P)]),
+    "flux2mi_array_from_host": (_I, [_P, _P, C.POINTER(_I64), _I, C.POINTER(_P)]),
+    "flux2mi_array_wrap": (_I, [_P, _P, C.POINTER(_I64), _I, C.POINTER(_P)]),
+    "flux2mi_array_free": (_I, [_P]),
+    "flux2mi_array_ndim": (_I, [_P]),
+    "flux2mi_array_dim": (_I64, [_P, _I]),
+    "flux2mi_array_data": (_P, [_P]),
+    "flux2mi_array_add": (_I, [_P, _P, _P, C.POINTER(_P)]),
+    "flux2mi_array_sub": (_I, [_P, _P, _P, C.POINTER(_P)]),
+    "flux2mi_array_mul": (_I, [_P, _P, _P, C.POINTER(_P)]),
+    "flux2mi_array_copy_to": (_I, [_P, _P, _P, _I64]),
+    "flux2mi_array_to_host": (_I, [_P, _P, _P]),
+    "flux2mi_array_random_normal": (_I, [_P, C.POINTER(C.c_uint32), C.POINTER(_I64), _I, C.POINTER(_P)]),
     "flux2mi_pack_patchified_to_sequence": (_I, [_P, _P, _P, _I, _I, _I]),
     "flux2mi_unpack_sequence_to_patchified": (_I, [_P, _P, _P, _I, _I, _I]),
     "flux2mi_latents_to_vae_input": (_I, [_P, _P, _P, _P, _P, _I, _I]),
@@ -153,6 +167,10 @@ PROTOTYPES = {
     "flux2mi_op_gemm_bf16_ex": (_I, [_P, _P, _I, C.c_longlong, _P, _I, C.c_longlong, _P, _I, _I, _I]),
     "flux2mi_op_gemm_fp8": (_I, [_P, _P, _P, _P, _I, _I, _I]),
     "flux2mi_op_gemm_gate_resid": (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
+    "flux2mi_op_layernorm_modulate": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "flux2mi_op_qk_norm_rope": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _F]),
+    "flux2mi_op_qk_proj_norm_rope": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _F, _P]),
+    "flux2mi_op_groupnorm_silu": (_I, [_P, _P, _P, C.c_longlong, _I, _I, _P, _P, _F, _I]),
     "flux2mi_op_attention": (_I, [_P, _P, _P, _I, _I]),
 }
 

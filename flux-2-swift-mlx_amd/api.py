@@ -339,6 +339,45 @@ class Context:
         self._exit()
         return out
 
+    def op_layernorm_modulate(self, x, split, shift0, scale0, shift1, scale1) -> torch.Tensor:
+        x = _req(x, torch.float32, "x")
+        vs = [_req(v, torch.float32, "modulation vector") for v in (shift0, scale0, shift1, scale1)]
+        y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        self._enter()
+        check(lib().flux2mi_op_layernorm_modulate(self.handle, _ptr(x), _ptr(y), x.shape[0], x.shape[1], split, *[_ptr(v) for v in vs]))
+        self._exit()
+        return y
+
+    def op_qk_norm_rope(self, qkv, heads, split, qw0, kw0, qw1, kw1, ids, q_mul=1.0) -> torch.Tensor:
+        """Returns a copy of qkv with q | k normalised and rotated (v untouched)."""
+        out = _req(qkv, torch.bfloat16, "qkv").clone()
+        ws = [_req(w, torch.bfloat16, "norm weight") for w in (qw0, kw0, qw1, kw1)]
+        ids = _req(ids, torch.int32, "ids")
+        self._enter()
+        check(lib().flux2mi_op_qk_norm_rope(self.handle, _ptr(out), out.shape[0], heads, split, *[_ptr(w) for w in ws], _ptr(ids), q_mul))
+        self._exit()
+        return out
+
+    def op_qk_proj_norm_rope(self, x, w, qw, kw, ids, q_mul=1.0) -> torch.Tensor:
+        x, w = _req(x, torch.bfloat16, "x"), _req(w, torch.bfloat16, "w")
+        qw, kw, ids = _req(qw, torch.bfloat16, "qw"), _req(kw, torch.bfloat16, "kw"), _req(ids, torch.int32, "ids")
+        s, d = x.shape
+        out = torch.empty((s, 2 * d), dtype=torch.bfloat16, device=x.device)
+        self._enter()
+        check(lib().flux2mi_op_qk_proj_norm_rope(self.handle, _ptr(x), _ptr(w), s, d, _ptr(qw), _ptr(kw), _ptr(ids), q_mul, _ptr(out)))
+        self._exit()
+        return out
+
+    def op_groupnorm_silu(self, x_nhwc, groups, gamma, beta, eps=1e-6, silu=True) -> torch.Tensor:
+        x = _req(x_nhwc, torch.bfloat16, "x")
+        gamma, beta = _req(gamma, torch.float32, "gamma"), _req(beta, torch.float32, "beta")
+        c = x.shape[-1]
+        y = torch.empty_like(x)
+        self._enter()
+        check(lib().flux2mi_op_groupnorm_silu(self.handle, _ptr(x), _ptr(y), x.numel() // c, c, groups, _ptr(gamma), _ptr(beta), eps, int(silu)))
+        self._exit()
+        return y
+
     def op_attention(self, qkv: torch.Tensor, heads: int) -> torch.Tensor:
         qkv = _req(qkv, torch.bfloat16, "qkv")
         s = qkv.shape[0]
@@ -395,6 +434,96 @@ class MLXRandom:
 
     def normal(self, shape) -> torch.Tensor:
         return self._draw(shape, lib().flux2mi_mlx_random_normal)
+
+    def normal_array(self, shape) -> "MLXArray":
+        """`MLXRandom.normal(shape)` as the façade type (same key split, same values as `normal`)."""
+        h = C.c_void_p()
+        sh = (C.c_int64 * max(len(shape), 1))(*shape)
+        key = self.next_key()
+        self.ctx._enter()
+        check(lib().flux2mi_array_random_normal(self.ctx.handle, key, sh, len(shape), C.byref(h)))
+        self.ctx._exit()
+        return MLXArray(self.ctx, _handle=h)
+
+
+class MLXArray:
+    """What the Swift shim's `MLXArray` is (include/flux2mi.h, "MLXArray façade"): a handle to a flux2mi_array, with
+    exactly the MLX surface code outside Flux2Core uses on hook / chain tensors — `MLXArray(Float)`, `+ - *` with
+    broadcasting (Python scalars promote like Swift literals do), `.shape`, `eval`.  Every operator is one C-ABI call."""
+
+    def __init__(self, ctx: "Context", value=None, *, _handle=None, _keep=None):
+        self.ctx = ctx
+        self._keep = _keep          # memory a view depends on
+        if _handle is not None:
+            self.handle = _handle
+            return
+        h = C.c_void_p()
+        if isinstance(value, (int, float)):
+            check(lib().flux2mi_array_from_scalar(ctx.handle, float(value), C.byref(h)))
+        else:
+            t = torch.as_tensor(value, dtype=torch.float32).cpu().contiguous()
+            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+            check(lib().flux2mi_array_from_host(ctx.handle, t.data_ptr(), shape, t.dim(), C.byref(h)))
+        self.handle = h
+
+    @classmethod
+    def wrap(cls, ctx: "Context", t: torch.Tensor) -> "MLXArray":
+        """Zero-copy view of an f32 device tensor (the hook's latents, `encodeImageToPackedSequence` results)."""
+        t = _req(t, torch.float32, "tensor")
+        h = C.c_void_p()
+        shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+        check(lib().flux2mi_array_wrap(ctx.handle, t.data_ptr(), shape, t.dim(), C.byref(h)))
+        return cls(ctx, _handle=h, _keep=t)
+
+    @property
+    def shape(self):
+        n = lib().flux2mi_array_ndim(self.handle)
+        return [int(lib().flux2mi_array_dim(self.handle, i)) for i in range(n)]
+
+    def _bin(self, fn, a, b):
+        a = a if isinstance(a, MLXArray) else MLXArray(self.ctx, a)
+        b = b if isinstance(b, MLXArray) else MLXArray(self.ctx, b)
+        h = C.c_void_p()
+        self.ctx._enter()
+        check(fn(self.ctx.handle, a.handle, b.handle, C.byref(h)))
+        self.ctx._exit()
+        return MLXArray(self.ctx, _handle=h, _keep=(a, b))   # operands stay alive until the result is released
+
+    def __add__(self, o): return self._bin(lib().flux2mi_array_add, self, o)
+    def __radd__(self, o): return self._bin(lib().flux2mi_array_add, o, self)
+    def __sub__(self, o): return self._bin(lib().flux2mi_array_sub, self, o)
+    def __rsub__(self, o): return self._bin(lib().flux2mi_array_sub, o, self)
+    def __mul__(self, o): return self._bin(lib().flux2mi_array_mul, self, o)
+    def __rmul__(self, o): return self._bin(lib().flux2mi_array_mul, o, self)
+
+    def eval(self):
+        self.ctx.sync()
+        return self
+
+    def torch(self) -> torch.Tensor:
+        """A device tensor with a copy of the values (test aid)."""
+        shape = self.shape
+        out = torch.empty(shape, dtype=torch.float32, device=self.ctx.device)
+        self.ctx._enter()
+        check(lib().flux2mi_array_copy_to(self.ctx.handle, self.handle, out.data_ptr(), out.numel()))
+        self.ctx._exit()
+        return out
+
+    def tolist(self):
+        n = 1
+        for d in self.shape:
+            n *= d
+        buf = (C.c_float * n)()
+        check(lib().flux2mi_array_to_host(self.ctx.handle, self.handle, buf))
+        return list(buf)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                lib().flux2mi_array_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 class DiT:

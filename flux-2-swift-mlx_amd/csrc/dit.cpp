@@ -1243,3 +1243,79 @@ extern "C" int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv_in, void* 
     F2_LAUNCH(r, "op_attention");
     return FLUX2MI_OK;
 }
+
+// ------------------------------------------------------------------ per-op parity entry points (HBM-bound kernels)
+// SURVEY §8c gives LayerNorm+modulate / RMSNorm+RoPE / GroupNorm their own tolerance (<= 4e-3 vs the fp32 oracle): these
+// run exactly the kernels the forward runs, on caller buffers.
+
+// y bf16 [rows, dim] = LayerNorm(x f32 [rows, dim], eps 1e-6, no affine) * (1 + scale) + shift; rows < split take
+// (shift0, scale0), the others (shift1, scale1)  (Flux2TransformerBlock.swift:56-61, Flux2Modulation.swift:96-112)
+extern "C" int flux2mi_op_layernorm_modulate(flux2mi_ctx* ctx, const float* x, void* y, int rows, int dim, int split,
+                                             const float* shift0, const float* scale0, const float* shift1, const float* scale1) {
+    F2_REQUIRE(ctx && x && y && shift0 && scale0 && shift1 && scale1 && rows > 0 && dim > 0, FLUX2MI_ERR_INVALID_ARG,
+               "op_layernorm_modulate: bad argument");
+    F2_LAUNCH(launch_layernorm_modulate(ctx->stream, x, reinterpret_cast<uint16_t*>(y), rows, dim, split, shift0, scale0, shift1, scale1),
+              "op_layernorm_modulate");
+    return FLUX2MI_OK;
+}
+
+// In place on qkv bf16 [S, 3*heads*128] (q | k | v): per-head RMSNorm (eps 1e-6, bf16 weights [128]; rows < split use
+// set 0, the others set 1) then the 4-axis RoPE of the position ids i32 [S,4] on q and k; q is multiplied by q_mul
+// before its rounding.  The STANDALONE kernel (fp8 models, small problems; Flux2Attention.swift:137-157, Flux2RoPE.swift:129-169).
+extern "C" int flux2mi_op_qk_norm_rope(flux2mi_ctx* ctx, void* qkv, int S, int heads, int split, const void* qw0, const void* kw0,
+                                       const void* qw1, const void* kw1, const int32_t* ids, float q_mul) {
+    F2_REQUIRE(ctx && qkv && qw0 && kw0 && qw1 && kw1 && ids && S > 0 && heads > 0, FLUX2MI_ERR_INVALID_ARG, "op_qk_norm_rope: bad argument");
+    const int s_pad = attn_s_pad(S);
+    const size_t tab = (size_t)S * 128 * 4;
+    F2_TRY(ctx->scratch.reserve(2 * tab + (size_t)heads * 128 * s_pad * 2 + 256));
+    float* cos_tab = ctx->scratch.as<float>();
+    float* sin_tab = cos_tab + (size_t)S * 128;
+    uint16_t* vt = reinterpret_cast<uint16_t*>(sin_tab + (size_t)S * 128);
+    F2_LAUNCH(launch_rope_tables(ctx->stream, ids, 0, ids, S, cos_tab, sin_tab), "rope_tables");
+    auto W = [](const void* p) { return reinterpret_cast<const uint16_t*>(p); };
+    F2_LAUNCH(launch_qk_norm_rope_vt(ctx->stream, reinterpret_cast<uint16_t*>(qkv), 3 * heads * 128, S, heads, split, W(qw0), W(kw0), W(qw1),
+                                     W(kw1), cos_tab, sin_tab, vt, s_pad, q_mul),
+              "op_qk_norm_rope");
+    return FLUX2MI_OK;
+}
+
+// out bf16 [S, 2*dim] = RoPE(RMSNorm(x W^T)) for the q | k rows of a fused projection weight W bf16 [2*dim, dim]: the
+// FUSED form, norm + rotation in the epilogue of the 256x256 GEMM with the angles computed from the ids (bf16 models)
+extern "C" int flux2mi_op_qk_proj_norm_rope(flux2mi_ctx* ctx, const void* x, const void* w, int S, int dim, const void* qw,
+                                            const void* kw, const int32_t* ids, float q_mul, void* out) {
+    F2_REQUIRE(ctx && x && w && qw && kw && ids && out && S > 0 && dim > 0 && dim % 256 == 0, FLUX2MI_ERR_INVALID_ARG,
+               "op_qk_proj_norm_rope: bad argument (dim %% 256 == 0)");
+    const size_t tab = (size_t)S * 128 * 4;
+    F2_TRY(ctx->scratch.reserve(2 * tab + (size_t)S * 16 + 256));
+    float* cos_tab = ctx->scratch.as<float>();
+    float* sin_tab = cos_tab + (size_t)S * 128;
+    float* pos_tab = sin_tab + (size_t)S * 128;
+    F2_LAUNCH(launch_rope_tables(ctx->stream, ids, 0, ids, S, cos_tab, sin_tab, pos_tab), "rope_tables");
+    GemmProblem p = mk(reinterpret_cast<const uint16_t*>(x), dim, reinterpret_cast<const uint16_t*>(w), dim, out, 2 * dim, S, 2 * dim, dim, EPI_BF16);
+    p.qk_qw = reinterpret_cast<const uint16_t*>(qw);
+    p.qk_kw = reinterpret_cast<const uint16_t*>(kw);
+    p.qk_pos = pos_tab;
+    p.qk_cols = 2 * dim;
+    p.qk_row0 = 0;
+    p.qk_qmul = q_mul;
+    p.qk_l2t16 = log2f(2000.0f) / 16.0f;
+    F2_LAUNCH(launch_gemm(ctx->stream, &p, 1), "op_qk_proj_norm_rope");
+    return FLUX2MI_OK;
+}
+
+// y = [SiLU](GroupNorm(x)) on NHWC bf16 [pixels, C]: f32 statistics per (group), eps, per-channel gamma / beta f32
+// (VAE/ResnetBlock.swift:9-55, :168-186)
+extern "C" int flux2mi_op_groupnorm_silu(flux2mi_ctx* ctx, const void* x, void* y, long long pixels, int C, int groups, const float* gamma,
+                                         const float* beta, float eps, int silu) {
+    F2_REQUIRE(ctx && x && y && gamma && beta && pixels > 0 && C > 0 && groups > 0 && C % groups == 0, FLUX2MI_ERR_INVALID_ARG,
+               "op_groupnorm_silu: bad argument");
+    const size_t part = (size_t)groupnorm_partial_floats(pixels, groups) * 4;
+    F2_TRY(ctx->scratch.reserve(part + (size_t)2 * C * 4 + 256));
+    float* partial = ctx->scratch.as<float>();
+    float* ab = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(partial) + ((part + 255) & ~(size_t)255));
+    F2_LAUNCH(launch_groupnorm_stats(ctx->stream, reinterpret_cast<const uint16_t*>(x), pixels, C, groups, gamma, beta, eps, partial, ab),
+              "groupnorm_stats");
+    F2_LAUNCH(launch_groupnorm_apply(ctx->stream, reinterpret_cast<const uint16_t*>(x), reinterpret_cast<uint16_t*>(y), pixels, C, ab, silu),
+              "groupnorm_apply");
+    return FLUX2MI_OK;
+}

@@ -206,7 +206,45 @@ __global__ void cfg_kernel(float* __restrict__ vc, const float* __restrict__ vu,
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         vc[i] = vu[i] + g * (vc[i] - vu[i]);
 }
-// RePaint: x = (1-m)*((1-s)*img + s*noise) + m*x, m [S,1]
+// ---- MLXArray façade: out = a (op) b with numpy-style broadcasting over <= 4 dims (array.cpp).  HBM-bound: one thread
+// per 4 consecutive output elements of the last dim when both operands are contiguous or broadcast there (16-byte
+// accesses), else one per element.  Each op is its own kernel, so every product and sum is rounded separately to f32
+// exactly like the un-fused MLX graph (no FMA contraction across ops).
+struct BcastArgs {
+    int64_t n;            // output elements
+    int d[4];             // output dims (padded with leading 1s)
+    int64_t sa[4], sb[4]; // element strides of a / b per output dim (0 = broadcast)
+};
+template <int OP> __device__ __forceinline__ float bc_op(float x, float y) {
+    return OP == 0 ? x + y : OP == 1 ? x - y : x * y;
+}
+template <int OP, bool VEC>
+__global__ void bcast_binary_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, BcastArgs g) {
+    const int64_t step = VEC ? 4 : 1;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * step; i < g.n; i += (int64_t)gridDim.x * blockDim.x * step) {
+        int64_t r = i;
+        const int i3 = (int)(r % g.d[3]); r /= g.d[3];
+        const int i2 = (int)(r % g.d[2]); r /= g.d[2];
+        const int i1 = (int)(r % g.d[1]); r /= g.d[1];
+        const int64_t oa = r * g.sa[0] + i1 * g.sa[1] + i2 * g.sa[2] + i3 * g.sa[3];
+        const int64_t ob = r * g.sb[0] + i1 * g.sb[1] + i2 * g.sb[2] + i3 * g.sb[3];
+        if (VEC) {
+            const f32x4 x = g.sa[3] ? *reinterpret_cast<const f32x4*>(a + oa) : f32x4{a[oa], a[oa], a[oa], a[oa]};
+            const f32x4 y = g.sb[3] ? *reinterpret_cast<const f32x4*>(b + ob) : f32x4{b[ob], b[ob], b[ob], b[ob]};
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = bc_op<OP>(x[k], y[k]);
+            *reinterpret_cast<f32x4*>(out + i) = o;
+        } else {
+            out[i] = bc_op<OP>(a[oa], b[ob]);
+        }
+    }
+}
+
+// RePaint: x = (1-m)*((1-s)*img + s*noise) + m*x, m [S,1].  No FMA contraction: every product and sum is rounded on its
+// own, so that the fused kernel is bit-identical to the reference's closure executed op by op
+// (Flux2MaskedInpaintingChain.swift:399-403 through the flux2mi_array_* façade).
+#pragma clang fp contract(off)
 __global__ void repaint_kernel(float* __restrict__ x, const float* __restrict__ img, const float* __restrict__ noise,
                                const float* __restrict__ mask, float s, int64_t n, int c) {
     const float u = 1.0f - s;
@@ -216,6 +254,7 @@ __global__ void repaint_kernel(float* __restrict__ x, const float* __restrict__ 
         x[i] = (1.0f - m) * orig + m * x[i];
     }
 }
+#pragma clang fp contract(fast)
 
 // ---- [rows, cols] f32 -> [cols, rows] (pack / unpack of patchified latents)
 __global__ void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
@@ -346,6 +385,23 @@ int launch_repaint_blend(hipStream_t stream, float* x, const float* img, const f
     const int64_t n = (int64_t)seq * c;
     hipLaunchKernelGGL(repaint_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, stream, x, img, noise, mask, sigma_next,
                        n, c);
+    EW_DONE();
+}
+int launch_bcast_binary(hipStream_t stream, int op, const float* a, const int64_t* sa, const float* b, const int64_t* sb, float* out,
+                        const int* dims) {
+    BcastArgs g;
+    g.n = 1;
+    for (int i = 0; i < 4; ++i) { g.d[i] = dims[i]; g.sa[i] = sa[i]; g.sb[i] = sb[i]; g.n *= dims[i]; }
+    if (g.n <= 0 || op < 0 || op > 2) return 1;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    // 16-byte form: last dim a multiple of 4, each operand contiguous (stride 1, every outer stride a multiple of 4) or broadcast there
+    bool vec = dims[3] % 4 == 0 && al16(a) && al16(b) && al16(out) && (sa[3] == 1 || sa[3] == 0) && (sb[3] == 1 || sb[3] == 0);
+    for (int i = 0; i < 3; ++i) vec = vec && (sa[3] == 0 || sa[i] % 4 == 0) && (sb[3] == 0 || sb[i] % 4 == 0);
+    const unsigned grid = ew_grid(vec ? (g.n + 3) / 4 : g.n);
+#define BC_GO(OP_) if (vec) hipLaunchKernelGGL((bcast_binary_kernel<OP_, true>), dim3(grid), dim3(EW_BLOCK), 0, stream, a, b, out, g); \
+                   else hipLaunchKernelGGL((bcast_binary_kernel<OP_, false>), dim3(grid), dim3(EW_BLOCK), 0, stream, a, b, out, g);
+    if (op == 0) { BC_GO(0) } else if (op == 1) { BC_GO(1) } else { BC_GO(2) }
+#undef BC_GO
     EW_DONE();
 }
 int launch_transpose_2d(hipStream_t stream, const float* in, float* out, int rows, int cols) {

@@ -167,6 +167,9 @@ int launch_lerp(hipStream_t stream, float* out, const float* a, const float* b, 
 int launch_cfg_combine(hipStream_t stream, float* vc, const float* vu, float g, int64_t n);
 int launch_repaint_blend(hipStream_t stream, float* x, const float* img, const float* noise, const float* mask,
                          float sigma_next, int seq, int c);
+// out[dims] = a (op) b, op 0 add / 1 sub / 2 mul; sa / sb: element strides per output dim, 0 where the operand broadcasts
+int launch_bcast_binary(hipStream_t stream, int op, const float* a, const int64_t* sa, const float* b, const int64_t* sb, float* out,
+                        const int* dims);
 int launch_transpose_2d(hipStream_t stream, const float* in, float* out, int rows, int cols);      // [rows,cols]->[cols,rows]
 int launch_latents_to_vae_input(hipStream_t stream, const float* packed, const float* mean, const float* var,
                                 float* z, int h16, int w16);

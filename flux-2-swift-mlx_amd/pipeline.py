@@ -533,8 +533,21 @@ class Flux2MaskedInpaintingChain:
                                           ctx.sigmaNext, latents.shape[-2], latents.shape[-1]))
         return latents
 
+    def on_step_unfused(self, ctx: Flux2StepContext, latents: torch.Tensor) -> torch.Tensor:
+        """The reference's closure AS WRITTEN (:399-403), every operator one façade call (api.MLXArray = what the Swift
+        shim's MLXArray is): bit-identical to `on_step`'s fused kernel."""
+        from .api import MLXArray
+        c = self.pipeline.ctx
+        imageLatentsCaptured = MLXArray.wrap(c, self.image_latents)
+        maskLatentsCaptured = MLXArray.wrap(c, self.mask_latents)
+        blendNoise = MLXArray.wrap(c, self.blend_noise)
+        lat = MLXArray.wrap(c, latents)
+        sigmaNext = MLXArray(c, ctx.sigmaNext)
+        originalNoised = (1 - sigmaNext) * imageLatentsCaptured + sigmaNext * blendNoise
+        return ((1 - maskLatentsCaptured) * originalNoised + maskLatentsCaptured * lat).torch()
+
     def run(self, precomputed_embeddings, height: int, width: int, steps: int, guidance: float = 4.0,
-            strength: float = 1.0, noise=None, seed=None, **kw) -> Flux2GenerationResult:
+            strength: float = 1.0, noise=None, seed=None, unfused_hook: bool = False, **kw) -> Flux2GenerationResult:
         if self.blend_noise is None:
             if seed is not None:
                 self.pipeline.random.seed(seed)
@@ -544,7 +557,7 @@ class Flux2MaskedInpaintingChain:
             mode, height=height, width=width, steps=steps, guidance=guidance, seed=seed, noise=noise,
             precomputed_embeddings=precomputed_embeddings,
             init_latents=self.image_latents if strength < 1.0 else None, strength=strength,
-            on_step=self.on_step, **kw)
+            on_step=self.on_step_unfused if unfused_hook else self.on_step, **kw)
 
 
     @classmethod

@@ -154,6 +154,34 @@ void flux2mi_mlx_random_split(const uint32_t key[2], uint32_t first[2], uint32_t
 int flux2mi_mlx_random_bits(flux2mi_ctx* ctx, const uint32_t key[2], uint32_t* out, int64_t n);
 int flux2mi_mlx_random_uniform(flux2mi_ctx* ctx, const uint32_t key[2], float* out, int64_t n, float lo, float hi);
 int flux2mi_mlx_random_normal(flux2mi_ctx* ctx, const uint32_t key[2], float* out, int64_t n);
+/* ---- MLXArray façade ("MLXArray in the public API") -------------------------------------------------
+ * `Flux2StepHook = @Sendable (Flux2StepContext, MLXArray) -> MLXArray` (Pipeline/Flux2Pipeline.swift:64),
+ * `precomputedEmbeddings` / `initLatents` and the return values of `encodeImageToPackedSequence` /
+ * `packMaskForLatentBlending` hand MLX arrays to code outside Flux2Core.  What that code does with them
+ * (Flux2Chains/Flux2MaskedInpaintingChain.swift:380-403, Flux2CLI InpaintCommand.swift:253-271): `MLXArray(Float)`,
+ * `+ - *` with broadcasting, `.shape`, `eval(_)`, `MLXRandom.seed / normal`.  A Swift shim's `MLXArray` wraps one
+ * flux2mi_array: an immutable f32 device tensor of <= 4 dims; ops are enqueued on the context's stream and return new
+ * arrays; `eval` = flux2mi_ctx_sync.  Each op rounds to f32 on its own (no cross-op FMA contraction), which makes the
+ * closure of :399-403 executed through these entry points bit-identical to flux2mi_repaint_blend. */
+typedef struct flux2mi_array flux2mi_array;
+int flux2mi_array_alloc(flux2mi_ctx* ctx, const int64_t* shape, int ndim, flux2mi_array** out);     /* uninitialised */
+int flux2mi_array_from_scalar(flux2mi_ctx* ctx, float value, flux2mi_array** out);                   /* MLXArray(Float), shape [] */
+int flux2mi_array_from_host(flux2mi_ctx* ctx, const float* host, const int64_t* shape, int ndim, flux2mi_array** out);
+/* non-owning view over device memory of the caller or the library (the hook's latent buffer, encoder outputs) */
+int flux2mi_array_wrap(flux2mi_ctx* ctx, float* device, const int64_t* shape, int ndim, flux2mi_array** out);
+int flux2mi_array_free(flux2mi_array* a);
+int flux2mi_array_ndim(const flux2mi_array* a);                                                       /* .shape */
+int64_t flux2mi_array_dim(const flux2mi_array* a, int i);
+float* flux2mi_array_data(flux2mi_array* a);
+int flux2mi_array_add(flux2mi_ctx* ctx, const flux2mi_array* a, const flux2mi_array* b, flux2mi_array** out);
+int flux2mi_array_sub(flux2mi_ctx* ctx, const flux2mi_array* a, const flux2mi_array* b, flux2mi_array** out);
+int flux2mi_array_mul(flux2mi_ctx* ctx, const flux2mi_array* a, const flux2mi_array* b, flux2mi_array** out);
+/* the hook's returned array -> the library's latent buffer (no-op when it is the same memory) */
+int flux2mi_array_copy_to(flux2mi_ctx* ctx, const flux2mi_array* src, float* dst_device, int64_t n);
+int flux2mi_array_to_host(flux2mi_ctx* ctx, const flux2mi_array* a, float* host);                     /* synchronises */
+/* MLXRandom.normal(shape) with an explicit key (see flux2mi_mlx_random_* for the key bookkeeping) */
+int flux2mi_array_random_normal(flux2mi_ctx* ctx, const uint32_t key[2], const int64_t* shape, int ndim, flux2mi_array** out);
+
 /* classical CFG, Flux2Pipeline.swift:1955-1973: v = v_uncond + g*(v_cond - v_uncond), in place on v_cond. */
 int flux2mi_cfg_combine(flux2mi_ctx* ctx, float* v_cond, const float* v_uncond, float guidance, int64_t n);
 /* RePaint hook body, Flux2Chains/Flux2MaskedInpaintingChain.swift:399-403:
@@ -408,6 +436,22 @@ int flux2mi_op_gemm_gate_resid(flux2mi_ctx* ctx, const void* A, const void* W, c
  * per-row scales (what the fp8 model does to activations / weights), then
  * v_mfma_f32_16x16x32_fp8_fp8; K % 128 == 0. */
 int flux2mi_op_gemm_fp8(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K);
+/* Per-op entry points of the HBM-bound kernels (their own tolerance, SURVEY §8c: <= 4e-3 vs the fp32 oracle).
+ * y bf16 [rows,dim] = LayerNorm(x f32, eps 1e-6, no affine) * (1 + scale) + shift; rows < split: set 0, else set 1
+ * (Flux2TransformerBlock.swift:56-61, Flux2Modulation.swift:96-112). */
+int flux2mi_op_layernorm_modulate(flux2mi_ctx* ctx, const float* x, void* y, int rows, int dim, int split, const float* shift0,
+                                  const float* scale0, const float* shift1, const float* scale1);
+/* in place on qkv bf16 [S, 3*heads*128]: per-head RMSNorm (eps 1e-6, bf16 weights [128], set 0 for rows < split) then
+ * 4-axis RoPE from ids i32 [S,4] on q and k, q times q_mul — the standalone kernel (Flux2Attention.swift:137-157,
+ * Flux2RoPE.swift:129-169) */
+int flux2mi_op_qk_norm_rope(flux2mi_ctx* ctx, void* qkv, int S, int heads, int split, const void* qw0, const void* kw0,
+                            const void* qw1, const void* kw1, const int32_t* ids, float q_mul);
+/* out bf16 [S, 2*dim] = RoPE(RMSNorm(x W^T)), W bf16 [2*dim, dim] = the q | k rows: the same math fused into the GEMM epilogue */
+int flux2mi_op_qk_proj_norm_rope(flux2mi_ctx* ctx, const void* x, const void* w, int S, int dim, const void* qw, const void* kw,
+                                 const int32_t* ids, float q_mul, void* out);
+/* y = [SiLU](GroupNorm(x)), NHWC bf16 [pixels, C], f32 statistics (VAE/ResnetBlock.swift:9-55, :168-186) */
+int flux2mi_op_groupnorm_silu(flux2mi_ctx* ctx, const void* x, void* y, long long pixels, int C, int groups, const float* gamma,
+                              const float* beta, float eps, int silu);
 /* joint attention: qkv bf16 [S, 3*heads*128] (q|k|v, already normalised/rotated) -> out bf16 [S, heads*128] */
 int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv, void* out, int S, int heads);
 

@@ -259,3 +259,97 @@ def test_gemm_gate_resid_random_deterministic(ctx):
         assert torch.equal(o, outs[0])
     ref = x0 + gate[None, :] * (a.float() @ w.float().t())
     assert rel_l2(outs[0], ref) < 2e-3
+
+
+# ---- per-op parity of the HBM-bound kernels (LN/GN/modulate <= 4e-3) --------------------
+def _big_ids(S, seed=0):
+    """Position ids with every axis near its maximum: T up to 30 (three references), H / W up to 127 (2048^2), L up to 511."""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.stack([torch.randint(0, 31, (S,), generator=g), torch.randint(0, 128, (S,), generator=g),
+                       torch.randint(0, 128, (S,), generator=g), torch.randint(0, 512, (S,), generator=g)], dim=1).to(torch.int32)
+    ids[0] = torch.tensor([30, 127, 127, 511])
+    return ids
+
+
+@pytest.mark.parametrize("dim,rows,split", [(3072, 349, 77), (4096, 1030, 512), (6144, 517, 0), (256, 54, 19)])
+def test_op_layernorm_modulate(flux2mi, ctx, dim, rows, split):
+    """LayerNorm (eps 1e-6, no affine) + per-stream (1 + scale) x + shift at Klein-4B / Klein-9B / Dev widths, ragged rows,
+    an offset-heavy residual stream (mean 3, spread 2 — the two-pass variance must not cancel); bf16 output; rel-L2 <= 4e-3."""
+    g = torch.Generator().manual_seed(dim)
+    x = torch.randn((rows, dim), generator=g) * 2.0 + 3.0
+    sh = [torch.randn(dim, generator=g) * 0.3 for _ in range(2)]
+    sc = [torch.randn(dim, generator=g) * 0.3 for _ in range(2)]
+    y = ctx.op_layernorm_modulate(x.cuda(), split, sh[0].cuda(), sc[0].cuda(), sh[1].cuda(), sc[1].cuda()).float().cpu()
+    n = R.layer_norm_noaffine(x.unsqueeze(0))[0]
+    ref = torch.cat([R.apply_modulation(n[:split].unsqueeze(0), sh[0].unsqueeze(0), sc[0].unsqueeze(0))[0],
+                     R.apply_modulation(n[split:].unsqueeze(0), sh[1].unsqueeze(0), sc[1].unsqueeze(0))[0]], dim=0)
+    assert rel_l2(y, ref) < 4e-3
+
+
+def _qk_ref(q_pre, k_pre, heads, qw, kw, ids, q_mul):
+    cos, sin = R.rope_tables(ids)
+    S = q_pre.shape[0]
+    hd = lambda t: t.reshape(1, S, heads, 128).permute(0, 2, 1, 3)
+    q = R.apply_rope(R.rms_norm(hd(q_pre), qw), cos, sin) * q_mul
+    k = R.apply_rope(R.rms_norm(hd(k_pre), kw), cos, sin)
+    un = lambda t: t.permute(0, 2, 1, 3).reshape(S, heads * 128)
+    return un(q), un(k)
+
+
+@pytest.mark.parametrize("heads,S,split", [(24, 349, 77), (32, 300, 0), (48, 130, 64), (2, 54, 19)])
+def test_op_qk_norm_rope_standalone(flux2mi, ctx, heads, S, split):
+    """The standalone RMSNorm + RoPE kernel at d 3072 / 4096 / 6144 with positions at the top of every axis; per-stream
+    norm weights (double blocks: text rows < split); rel-L2 <= 4e-3 for q and k, v bit-untouched."""
+    d = heads * 128
+    g = torch.Generator().manual_seed(S)
+    qkv = (torch.randn((S, 3 * d), generator=g) * 1.7).to(torch.bfloat16)
+    w = [(1.0 + 0.2 * torch.randn(128, generator=g)).to(torch.bfloat16) for _ in range(4)]   # qw0, kw0, qw1, kw1
+    ids = _big_ids(S)
+    q_mul = 1.4426950408889634 / 128 ** 0.5
+    out = ctx.op_qk_norm_rope(qkv.cuda(), heads, split, *[x.cuda() for x in w], ids.cuda(), q_mul).cpu()
+    qf, kf = qkv[:, :d].float(), qkv[:, d:2 * d].float()
+    q0, k0 = _qk_ref(qf, kf, heads, w[0], w[1], ids, q_mul)
+    q1, k1 = _qk_ref(qf, kf, heads, w[2], w[3], ids, q_mul)
+    rows = torch.arange(S).unsqueeze(1) < split
+    assert rel_l2(out[:, :d], torch.where(rows, q0, q1)) < 4e-3
+    assert rel_l2(out[:, d:2 * d], torch.where(rows, k0, k1)) < 4e-3
+    assert torch.equal(out[:, 2 * d:], qkv[:, 2 * d:])
+
+
+@pytest.mark.parametrize("dim,S", [(3072, 349), (4096, 300), (6144, 261)])
+def test_op_qk_proj_norm_rope_fused_epilogue(flux2mi, ctx, dim, S):
+    """The same math in the 256x256 GEMM's epilogue (bf16 models): x W^T -> RMSNorm -> RoPE with the rotation angles computed
+    in-kernel from the ids as v_sin / v_cos(fract(pos theta^(-k/16) / 2 pi)).  Positions at the top of every axis bound the
+    argument-reduction error: the largest angle is 511 rad = 81 revolutions, whose fract keeps 17 of f32's 24 bits.
+    rel-L2 <= 4e-3 vs the oracle on the f32 product."""
+    heads = dim // 128
+    g = torch.Generator().manual_seed(dim + 1)
+    x = torch.randn((S, dim), generator=g).to(torch.bfloat16)
+    w = (torch.randn((2 * dim, dim), generator=g) * 0.03).to(torch.bfloat16)
+    qw = (1.0 + 0.2 * torch.randn(128, generator=g)).to(torch.bfloat16)
+    kw = (1.0 + 0.2 * torch.randn(128, generator=g)).to(torch.bfloat16)
+    ids = _big_ids(S, seed=2)
+    q_mul = 1.4426950408889634 / 128 ** 0.5
+    out = ctx.op_qk_proj_norm_rope(x.cuda(), w.cuda(), qw.cuda(), kw.cuda(), ids.cuda(), q_mul).float().cpu()
+    p = x.float() @ w.float().t()
+    q, k = _qk_ref(p[:, :dim], p[:, dim:], heads, qw, kw, ids, q_mul)
+    assert rel_l2(out[:, :dim], q) < 4e-3
+    assert rel_l2(out[:, dim:], k) < 4e-3
+    # and the two forms agree with each other to bf16 rounding of the intermediate (the standalone one reads a bf16 product)
+    qkv = torch.cat([p.to(torch.bfloat16), torch.zeros((S, dim), dtype=torch.bfloat16)], dim=1)
+    alone = ctx.op_qk_norm_rope(qkv.cuda(), heads, 0, qw.cuda(), kw.cuda(), qw.cuda(), kw.cuda(), ids.cuda(), q_mul).float().cpu()
+    assert rel_l2(out, alone[:, :2 * dim]) < 6e-3
+
+
+@pytest.mark.parametrize("C,hw,silu", [(128, 96, True), (256, 64, True), (512, 32, False), (96, 40, True), (384, 24, True)])
+def test_op_groupnorm_silu(flux2mi, ctx, C, hw, silu):
+    """GroupNorm(32 groups, eps 1e-6, f32 statistics) [+ SiLU] on NHWC bf16 at the VAE's channel counts (standard and small
+    decoder) with a per-channel offset (mean != 0: E[x^2] - E[x]^2 in f32 would lose digits); rel-L2 <= 4e-3."""
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn((1, C, hw, hw), generator=g) * 1.5 + torch.randn((1, C, 1, 1), generator=g) * 2.0).to(torch.bfloat16)
+    gamma, beta = 1.0 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    y = ctx.op_groupnorm_silu(x[0].permute(1, 2, 0).contiguous().cuda(), 32, gamma.cuda(), beta.cuda(), 1e-6, silu).float().cpu()
+    ref = R.group_norm(x.float(), gamma, beta, 32, 1e-6)
+    if silu:
+        ref = torch.nn.functional.silu(ref)
+    assert rel_l2(y.permute(2, 0, 1), ref[0]) < 4e-3
