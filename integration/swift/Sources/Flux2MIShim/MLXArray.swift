@@ -1,0 +1,133 @@
+// MLXArray.swift — the `MLX` / `MLXRandom` façade of the shim (SURVEY §8b, row "MLXArray in the public API").
+//
+// The reference hands `MLXArray`s across its public API (`Flux2StepHook`, `precomputedEmbeddings`, `initLatents`,
+// `encodeImageToPackedSequence`, `packMaskForLatentBlending`) and code OUTSIDE Flux2Core computes with them:
+//   Flux2Chains/Flux2MaskedInpaintingChain.swift:380-403   MLXRandom.seed / normal, eval, MLXArray(Float), + - *
+//   Flux2CLI/InpaintCommand.swift:253-271                   .shape, eval
+// This file gives that code the same names over `flux2mi_array` handles, so it compiles and runs unchanged.
+import CFlux2MI
+
+/// One process-wide context per GPU (the reference is one-generation-at-a-time too, Flux2Pipeline.swift:135).
+public enum MIContext {
+    public static var current: OpaquePointer = {
+        var c: OpaquePointer?
+        let s = flux2mi_ctx_create(0, nil, &c)
+        precondition(s == 0, String(cString: flux2mi_last_error()))
+        return c!
+    }()
+}
+
+/// Maps every status of `enum flux2mi_status` onto the reference's error type (Flux2Core.swift:14-40).
+@inline(__always) func check(_ status: Int32) throws {
+    guard status != FLUX2MI_OK.rawValue else { return }
+    let msg = String(cString: flux2mi_last_error())
+    switch flux2mi_status(rawValue: UInt32(status)) {
+    case FLUX2MI_ERR_INVALID_ARG:  throw Flux2Error.invalidConfiguration(msg)
+    case FLUX2MI_ERR_HIP:          throw Flux2Error.generationFailed(msg)
+    case FLUX2MI_ERR_NOT_LOADED:   throw Flux2Error.modelNotLoaded(msg)
+    case FLUX2MI_ERR_SHAPE:        throw Flux2Error.invalidConfiguration(msg)
+    case FLUX2MI_ERR_CANCELLED:    throw Flux2Error.generationCancelled
+    case FLUX2MI_ERR_UNSUPPORTED:  throw Flux2Error.invalidConfiguration(msg)
+    case FLUX2MI_ERR_OOM:          throw Flux2Error.insufficientMemory(required: 0, available: 0)
+    case FLUX2MI_ERR_UNKNOWN_KEY:  throw Flux2Error.weightLoadingFailed(msg)
+    default:                       throw Flux2Error.generationFailed(msg)
+    }
+}
+
+public final class MLXArray: @unchecked Sendable {
+    let handle: OpaquePointer
+    /// arrays this one was computed from: kept alive until the result is released (work may still be queued)
+    private let inputs: [MLXArray]
+
+    init(handle: OpaquePointer, inputs: [MLXArray] = []) { self.handle = handle; self.inputs = inputs }
+    deinit { flux2mi_array_free(handle) }
+
+    /// `MLXArray(Float)` — shape []
+    public convenience init(_ value: Float) {
+        var h: OpaquePointer?
+        let s = flux2mi_array_from_scalar(MIContext.current, value, &h)
+        precondition(s == 0, String(cString: flux2mi_last_error()))
+        self.init(handle: h!)
+    }
+    public convenience init(_ value: Int) { self.init(Float(value)) }
+
+    /// `MLXArray([Float], shape)`
+    public convenience init(_ values: [Float], _ shape: [Int]) {
+        var h: OpaquePointer?
+        var sh = shape.map { Int64($0) }
+        let s = values.withUnsafeBufferPointer { flux2mi_array_from_host(MIContext.current, $0.baseAddress, &sh, Int32(sh.count), &h) }
+        precondition(s == 0, String(cString: flux2mi_last_error()))
+        self.init(handle: h!)
+    }
+
+    /// Non-owning view over device memory (the hook's latent buffer, an encoder output).
+    static func borrowing(_ ptr: UnsafeMutablePointer<Float>, shape: [Int]) -> MLXArray {
+        var h: OpaquePointer?
+        var sh = shape.map { Int64($0) }
+        let s = flux2mi_array_wrap(MIContext.current, ptr, &sh, Int32(sh.count), &h)
+        precondition(s == 0, String(cString: flux2mi_last_error()))
+        return MLXArray(handle: h!)
+    }
+
+    public var shape: [Int] { (0..<Int(flux2mi_array_ndim(handle))).map { Int(flux2mi_array_dim(handle, Int32($0))) } }
+    var data: UnsafeMutablePointer<Float> { flux2mi_array_data(handle) }
+    var count: Int { shape.reduce(1, *) }
+
+    public func asArray() -> [Float] {
+        var out = [Float](repeating: 0, count: count)
+        let s = out.withUnsafeMutableBufferPointer { flux2mi_array_to_host(MIContext.current, handle, $0.baseAddress) }
+        precondition(s == 0, String(cString: flux2mi_last_error()))
+        return out
+    }
+
+    typealias BinOp = @convention(c) (OpaquePointer?, OpaquePointer?, OpaquePointer?, UnsafeMutablePointer<OpaquePointer?>?) -> Int32
+    static func binary(_ op: BinOp, _ a: MLXArray, _ b: MLXArray) -> MLXArray {
+        var h: OpaquePointer?
+        let s = op(MIContext.current, a.handle, b.handle, &h)
+        precondition(s == 0, String(cString: flux2mi_last_error()))   // MLX traps on non-broadcastable shapes as well
+        return MLXArray(handle: h!, inputs: [a, b])
+    }
+}
+
+// The operators the chains use (`(1 - sigmaNext) * imageLatents + sigmaNext * blendNoise`, `(1 - mask) * a + mask * b`):
+// array (op) array with broadcasting, and numeric literals on either side.
+public func + (a: MLXArray, b: MLXArray) -> MLXArray { MLXArray.binary(flux2mi_array_add, a, b) }
+public func - (a: MLXArray, b: MLXArray) -> MLXArray { MLXArray.binary(flux2mi_array_sub, a, b) }
+public func * (a: MLXArray, b: MLXArray) -> MLXArray { MLXArray.binary(flux2mi_array_mul, a, b) }
+public func + (a: Float, b: MLXArray) -> MLXArray { MLXArray(a) + b }
+public func + (a: MLXArray, b: Float) -> MLXArray { a + MLXArray(b) }
+public func - (a: Float, b: MLXArray) -> MLXArray { MLXArray(a) - b }
+public func - (a: MLXArray, b: Float) -> MLXArray { a - MLXArray(b) }
+public func * (a: Float, b: MLXArray) -> MLXArray { MLXArray(a) * b }
+public func * (a: MLXArray, b: Float) -> MLXArray { a * MLXArray(b) }
+public func + (a: Int, b: MLXArray) -> MLXArray { MLXArray(Float(a)) + b }
+public func - (a: Int, b: MLXArray) -> MLXArray { MLXArray(Float(a)) - b }
+public func * (a: Int, b: MLXArray) -> MLXArray { MLXArray(Float(a)) * b }
+
+/// `eval(_:)`: every op above is already enqueued on the context's stream; evaluation = stream synchronisation.
+public func eval(_ arrays: MLXArray...) { flux2mi_ctx_sync(MIContext.current) }
+
+/// `MLXRandom.seed(_:)` + keyless `MLXRandom.normal(_:)` — MLX's Threefry stream: the global key is split on every
+/// draw, (state, sub) = split(state), and the draw uses `sub` (flux2mi.h, "MLX-compatible random stream").
+public enum MLXRandom {
+    static var state: (UInt32, UInt32) = (0, 0)
+    public static func seed(_ seed: UInt64) {
+        var k: (UInt32, UInt32) = (0, 0)
+        withUnsafeMutablePointer(to: &k) { $0.withMemoryRebound(to: UInt32.self, capacity: 2) { flux2mi_mlx_random_key(seed, $0) } }
+        state = k
+    }
+    public static func normal(_ shape: [Int]) -> MLXArray {
+        var first: (UInt32, UInt32) = (0, 0), second: (UInt32, UInt32) = (0, 0), cur = state
+        withUnsafeMutablePointer(to: &cur) { c in c.withMemoryRebound(to: UInt32.self, capacity: 2) { cp in
+            withUnsafeMutablePointer(to: &first) { f in f.withMemoryRebound(to: UInt32.self, capacity: 2) { fp in
+                withUnsafeMutablePointer(to: &second) { s in s.withMemoryRebound(to: UInt32.self, capacity: 2) { sp in
+                    flux2mi_mlx_random_split(cp, fp, sp) } } } } } }
+        state = first
+        var h: OpaquePointer?
+        var sh = shape.map { Int64($0) }
+        let st = withUnsafeMutablePointer(to: &second) { s in s.withMemoryRebound(to: UInt32.self, capacity: 2) { sp in
+            flux2mi_array_random_normal(MIContext.current, sp, &sh, Int32(sh.count), &h) } }
+        precondition(st == 0, String(cString: flux2mi_last_error()))
+        return MLXArray(handle: h!)
+    }
+}
