@@ -55,6 +55,7 @@ extern "C" int flux2mi_ctx_create(int device, void* hip_stream, flux2mi_ctx** ou
     F2_CHECK_HIP(hipSetDevice(device));
     flux2mi_ctx* c = new flux2mi_ctx();
     c->device = device;
+    if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->n_cu = 0;
     if (hip_stream) {
         c->stream = reinterpret_cast<hipStream_t>(hip_stream);
         c->own_stream = false;
@@ -77,6 +78,7 @@ extern "C" int flux2mi_ctx_destroy(flux2mi_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (hipEvent_t e : ctx->prof.pool) (void)hipEventDestroy(e);
     ctx->scratch.release();
+    ctx->attn_ws.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return FLUX2MI_OK;

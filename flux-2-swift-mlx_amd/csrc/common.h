@@ -65,6 +65,8 @@ struct flux2mi_ctx {
     bool own_stream = false;
     ProfState prof;
     DevBuf scratch;  // small misc scratch
+    int n_cu = 0;    // compute units of the device (workgroup slots for the attention's KV-split)
+    DevBuf attn_ws;  // partial states of KV-split attention items (attention_split_ws_bytes)
 };
 
 // profiling helpers: bracket a launch of class `cls` with events when active.

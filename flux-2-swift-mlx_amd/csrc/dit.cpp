@@ -701,6 +701,9 @@ int ensure_workspace(flux2mi_dit* m, int S, int s_img) {
         F2_CHECK_HIP(hipMemsetAsync(m->vt.ptr, 0, m->vt.bytes, m->ctx->stream));
     }
     F2_TRY(m->comb.reserve(Sz * 4 * d * 2));
+#ifdef FLUX2MI_DEV
+    if (m->ctx->n_cu > 0) F2_TRY(m->ctx->attn_ws.reserve(attention_split_ws_bytes(m->ctx->n_cu)));
+#endif
     F2_TRY(m->mods.reserve((size_t)(256 + 2 * d + 6 * d + 6 * d + 3 * d + 2 * d) * 4));
     F2_TRY(m->rope.reserve(Sz * 128 * 4 * 2 + Sz * 4 * 4));   // cos, sin f32 [S,128] + positions f32 [S,4]
     F2_TRY(m->lat_bf16.reserve((size_t)s_img * 128 * 2));
@@ -920,7 +923,8 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         for (int i = 0; i < nr; ++i) {
             prof_before(m->ctx, PROF_ATTENTION);
             const int ar = launch_attention(st, qkv + (size_t)rg[i].q0 * 3 * d, qkv + d, 3 * d, vt, s_pad,
-                                            o_buf + (size_t)rg[i].q0 * ldo, ldo, rg[i].nq, rg[i].nk, H, score_bound, q_pre);
+                                            o_buf + (size_t)rg[i].q0 * ldo, ldo, rg[i].nq, rg[i].nk, H, score_bound, q_pre,
+                                            m->ctx->attn_ws.as<float>(), m->ctx->n_cu);
             prof_after(m->ctx, PROF_ATTENTION, 4.0 * (double)rg[i].nq * rg[i].nk * d);
             F2_LAUNCH(ar, "attention");
         }
@@ -1238,7 +1242,11 @@ extern "C" int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv_in, void* 
               "v_transpose");
     const uint16_t* q = reinterpret_cast<const uint16_t*>(qkv_in);
     prof_before(ctx, PROF_ATTENTION);
-    const int r = launch_attention(ctx->stream, q, q + d, 3 * d, vt, s_pad, reinterpret_cast<uint16_t*>(out), d, S, S, heads);
+#ifdef FLUX2MI_DEV
+    if (ctx->n_cu > 0) F2_TRY(ctx->attn_ws.reserve(attention_split_ws_bytes(ctx->n_cu)));
+#endif
+    const int r = launch_attention(ctx->stream, q, q + d, 3 * d, vt, s_pad, reinterpret_cast<uint16_t*>(out), d, S, S, heads, 0.f, false,
+                                   ctx->attn_ws.as<float>(), ctx->n_cu);
     prof_after(ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
     F2_LAUNCH(r, "op_attention");
     return FLUX2MI_OK;

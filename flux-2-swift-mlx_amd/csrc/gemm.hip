@@ -31,7 +31,10 @@
 int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob);
 int launch_gemm256_w4(hipStream_t stream, const GemmProblem* probs, int nprob);
 int launch_gemm256_r4(hipStream_t stream, const GemmProblem* probs, int nprob);
+#ifdef FLUX2MI_DEV
 int launch_gemm_ws(hipStream_t stream, const GemmProblem* probs, int nprob);
+int launch_gemm256_g4(hipStream_t stream, const GemmProblem* probs, int nprob);
+#endif
 
 namespace {
 
@@ -333,6 +336,11 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
         if (force == 256 || (force != 128 && big))
         {
 #ifdef FLUX2MI_DEV   // experimental structures (csrc/experimental/, `make dev` only)
+            if (ver == 6) {
+                bool ok = true;
+                for (int i = 0; i < nprob; ++i) ok = ok && !probs[i].fp8 && (probs[i].epi == EPI_F32 || probs[i].epi == EPI_GATE_RESID) && !probs[i].a_kstride && !probs[i].w_kstride;
+                if (ok) return launch_gemm256_g4(stream, probs, nprob);
+            }
             if (ver == 5) return launch_gemm_ws(stream, probs, nprob);
             if (ver == 4) return launch_gemm256_r4(stream, probs, nprob);
             if (ver == 3) return launch_gemm256_w4(stream, probs, nprob);

@@ -84,9 +84,12 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob);
 // needs no multiply-add at all (p in [2^-40, 2^40]: far inside f32 / bf16 range, any offset cancels in O / l).
 // true when launch_attention takes the fixed-offset softmax for this score bound (log2 domain; 0 = no bound known)
 bool attention_uses_fixed_offset(float score_bound_log2);
+// split_ws (optional, attention_split_ws_bytes(n_cu) bytes, n_cu = the device's CU count): lets the launcher cut the items of
+// a partial last round along the keys into equal pieces, one per free workgroup slot (attention.hip, AttnSplit).
+size_t attention_split_ws_bytes(int n_cu);
 int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
-                     int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads, float score_bound_log2 = 0.f,
-                     bool q_prescaled = false);
+                     int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads, float score_bound_log2 = 0.f, bool q_prescaled = false,
+                     float* split_ws = nullptr, int n_cu = 0);
 static inline int attn_s_pad(int S) { return ((S + 63) / 64) * 64; }
 
 // ---------------------------------------------------------------- norms / rope (norm.hip)

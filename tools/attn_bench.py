@@ -1,31 +1,33 @@
 #!/usr/bin/env python3
-"""Microbenchmark of the attention kernel at the DiT's shapes (random data).  Dev tool."""
-import os, sys
+"""Attention microbenchmark on the DiT's shapes: time per call and TFLOP/s (4 S^2 d), online-softmax op entry.  Dev tool.
+With FLUX2MI_LIB=libflux2mi_dev.so, FLUX2MI_ATTN_SPLIT=0 times the un-split launch for comparison."""
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+
 import flux2mi
 from flux2mi.api import Context
 
-def time_fn(fn, iters=10):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
-        fn()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / iters
+SHAPES = [(4608, 24, "klein-4b 1024^2"), (768, 24, "klein-4b 256^2"), (4608, 32, "klein-9b 1024^2"), (4608, 48, "dev 1024^2"),
+          (8704, 24, "klein-4b + 1024^2 reference"), (1536, 24, "klein-4b 512^2")]
 
-ctx = Context(0)
-for S, H in [(4608, 24), (4608, 32), (4608, 48), (8704, 48), (768, 24)]:
-    d = H * 128
-    qkv = torch.randn((S, 3 * d), device="cuda").to(torch.bfloat16)
-    with torch.cuda.stream(ctx.stream):
-        ms = time_fn(lambda: ctx.op_attention(qkv, H))
-    q, k, v = [x.reshape(S, H, 128).permute(1, 0, 2).unsqueeze(0).contiguous() for x in qkv.split(d, dim=1)]
-    ms_t = time_fn(lambda: torch.nn.functional.scaled_dot_product_attention(q, k, v))
-    fl = 4.0 * S * S * d
-    print(f"S{S} H{H}: ours {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF (incl. V^T transpose) | torch sdpa {ms_t:7.3f} ms {fl / ms_t / 1e9:7.1f} TF", flush=True)
+
+def main():
+    ctx = Context(0)
+    for S, heads, name in SHAPES:
+        d = heads * 128
+        qkv = (torch.randn((S, 3 * d), device="cuda") * 0.7).to(torch.bfloat16)
+        for _ in range(3):
+            ctx.op_attention(qkv, heads)
+        ctx.prof_begin(2)
+        for _ in range(10):
+            ctx.op_attention(qkv, heads)
+        n, ms, fl = ctx.prof_end()
+        print(f"{name:30s} S {S:5d} H {heads:2d}: {ms / n * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
