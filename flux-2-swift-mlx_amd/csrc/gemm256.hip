@@ -133,6 +133,27 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         src[KIND_B0][j] = gW + (size_t)min(n0 + b_row0, p.N - 1) * p.ldw * ES + chunk * 16;
         src[KIND_B1][j] = gW + (size_t)min(n0 + b_row0 + 32, p.N - 1) * p.ldw * ES + chunk * 16;
     }
+    // FP8: the eight 64-bit source pointers do not fit next to the 8-register operand tuples of the block-scaled MFMA — hipcc
+    // spilled them and reloaded each one with scratch_load + s_waitcnt vmcnt(0) in front of its LDS-DMA, i.e. the DMA pipeline was
+    // DRAINED in every phase (196 B/lane of scratch since round 1).  The FP8 instantiation therefore issues its LDS-DMA in the
+    // scalar-base + 32-bit-vector-offset form (inline asm: the builtin only takes per-lane 64-bit pointers): eight offset registers
+    // instead of sixteen pointer registers and no 64-bit vector adds.  The loads are invisible to hipcc's counters, which is what
+    // this loop wants anyway (every wait on them is one of the hand-counted s_waitcnt vmcnt below).
+    uint32_t soff[4][2];
+    if (FP8) {
+#pragma unroll
+        for (int kd = 0; kd < 4; ++kd)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                soff[kd][j] = (uint32_t)(src[kd][j] - ((kd == KIND_A0 || kd == KIND_A1) ? gA : gW));
+    }
+    const uint32_t lds_wave_s = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem + wid * 1024);
+#define G2_DMA_ASM(voff_, sbase_, m0_)                                                                                  \
+    {                                                                                                                   \
+        unsigned keep__;                                                                                                \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep__) : "v"(voff_), "s"(m0_), "s"(sbase_) : "memory");                                   \
+    }
     const long long ksA = p.a_kstride ? p.a_kstride : 128, ksB = p.w_kstride ? p.w_kstride : 128;
     const int lds_wave = wid * 1024;  // + j*8192 + slot*SLOT_BYTES + stage*STAGE2_BYTES
     const int nk = p.K / TILE_K;
@@ -149,8 +170,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         if (u__ < nk && !((kind_) == KIND_A1 && a1_skip)) {                                                   \
             uint8_t* dst__ = smem + (u__ & 1) * STAGE2_BYTES + (kind_) * SLOT_BYTES + lds_wave;               \
             const long long ko__ = u__ * (((kind_) == KIND_A0 || (kind_) == KIND_A1) ? ksA : ksB);            \
+            if (FP8) {                                                                                        \
+                const uint8_t* b__ = (((kind_) == KIND_A0 || (kind_) == KIND_A1) ? gA : gW) + ko__;           \
+                const uint32_t m__ = lds_wave_s + (uint32_t)((u__ & 1) * STAGE2_BYTES + (kind_) * SLOT_BYTES); \
+                G2_DMA_ASM(soff[kind_][0], b__, m__)                                                          \
+                G2_DMA_ASM(soff[kind_][1], b__, m__ + 8192)                                                   \
+            } else {                                                                                          \
             __builtin_amdgcn_global_load_lds((gptr_t)(src[kind_][0] + ko__), (lptr_t)(dst__), 16, 0, 0);      \
             __builtin_amdgcn_global_load_lds((gptr_t)(src[kind_][1] + ko__), (lptr_t)(dst__ + 8192), 16, 0, 0); \
+            }                                                                                                 \
         }                                                                                                     \
     }
 
@@ -168,18 +196,31 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     const int c0 = ((0 + fq) ^ sw) << 4, c1 = ((4 + fq) ^ sw) << 4;   // kk = 0, 1
 
     bf16x8 a[4][2], b0[2][2], b1[2][2];
+    // FP8: a lane's two 16-byte chunks are ONE 32-byte operand of the block-scaled MFMA.  The 8-register tuples are formed where
+    // the fragments are READ (the two halves die at once and coalesce into the tuple); forming them at the MFMA kept both the
+    // halves and the tuples live and cost 50 spilled registers inside the K loop (196 B/lane of scratch, scratch loads on the
+    // vmcnt counter of the LDS-DMA pipeline).
+    i32x8 a8[4], b08[2], b18[2];
 
 #define G2_READ_A(slot_)                                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < ((slot_) == KIND_A1 ? NI1 : 4); ++i_) {        \
         const uint8_t* r__ = st + (slot_) * SLOT_BYTES + a_frag + i_ * 2048;               \
-        a[i_][0] = *reinterpret_cast<const bf16x8*>(r__ + c0);                             \
-        a[i_][1] = *reinterpret_cast<const bf16x8*>(r__ + c1);                             \
+        if (FP8) {                                                                         \
+            a8[i_] = __builtin_shufflevector(*reinterpret_cast<const i32x4*>(r__ + c0), *reinterpret_cast<const i32x4*>(r__ + c1), 0, 1, 2, 3, 4, 5, 6, 7); \
+        } else {                                                                           \
+            a[i_][0] = *reinterpret_cast<const bf16x8*>(r__ + c0);                         \
+            a[i_][1] = *reinterpret_cast<const bf16x8*>(r__ + c1);                         \
+        }                                                                                  \
     }
 #define G2_READ_B(dst_, slot_)                                                             \
     _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                     \
         const uint8_t* r__ = st + (slot_) * SLOT_BYTES + b_frag + j_ * 2048;               \
-        dst_[j_][0] = *reinterpret_cast<const bf16x8*>(r__ + c0);                          \
-        dst_[j_][1] = *reinterpret_cast<const bf16x8*>(r__ + c1);                          \
+        if (FP8) {                                                                         \
+            dst_##8[j_] = __builtin_shufflevector(*reinterpret_cast<const i32x4*>(r__ + c0), *reinterpret_cast<const i32x4*>(r__ + c1), 0, 1, 2, 3, 4, 5, 6, 7); \
+        } else {                                                                           \
+            dst_[j_][0] = *reinterpret_cast<const bf16x8*>(r__ + c0);                      \
+            dst_[j_][1] = *reinterpret_cast<const bf16x8*>(r__ + c1);                      \
+        }                                                                                  \
     }
 #define G2_MFMA(mh_, nh_, bsrc_)                                                                         \
     __builtin_amdgcn_s_setprio(1);                                                                       \
@@ -188,13 +229,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
             /* one block-scaled 16x16x128 per (i, j): the lane's 32 bytes are its two 16-B chunks;  */   \
             /* scales are e8m0 127 = 1.0 (the real scales are per row/column, applied in the epilogue) */ \
             _Pragma("unroll") for (int i_ = 0; i_ < ((mh_) ? NI1 : 4); ++i_) {                                           \
-                const i32x8 a8__ = __builtin_shufflevector(__builtin_bit_cast(i32x4, a[i_][0]),          \
-                                                           __builtin_bit_cast(i32x4, a[i_][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
                 _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                       \
-                    const i32x8 b8__ = __builtin_shufflevector(__builtin_bit_cast(i32x4, bsrc_[j_][0]),  \
-                                                               __builtin_bit_cast(i32x4, bsrc_[j_][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
                     acc[(mh_) * 4 + i_][(nh_) * 2 + j_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4( \
-                        b8__, a8__, acc[(mh_) * 4 + i_][(nh_) * 2 + j_], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
+                        bsrc_##8[j_], a8[i_], acc[(mh_) * 4 + i_][(nh_) * 2 + j_], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
                 }                                                                                        \
             }                                                                                            \
         } else {                                                                                         \
@@ -366,19 +403,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     if ((ABL & 32) && p.alpha != 12345.f) return;   // timing only: the K loop without its epilogue
     int epi = p.epi;
     if (epi == EPI_QKV_MLP) epi = (n0 >= p.n_split) ? EPI_SWIGLU : EPI_BF16;
-    if (FP8) {  // de-quantise: per-row activation scale x per-column weight scale
-        float ws[4][4];
+    if (FP8) {  // de-quantise: per-row activation scale x per-column weight scale.  One column block at a time (4 + 1 scale
+                // registers live next to the 128 accumulators, not 16 + 8: the difference was spilled INTO THE K LOOP, see below)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            float w4[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ws[j][r] = p.w_scale[min(col_base + j * 16 + r, p.N - 1)];
+            for (int r = 0; r < 4; ++r) w4[r] = p.w_scale[min(col_base + j * 16 + r, p.N - 1)];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const float as = p.a_scale[min(row_base + i * 16, p.M - 1)];
+            for (int i = 0; i < NI; ++i) {
+                const float as = p.a_scale[min(row_base + i * 16, p.M - 1)];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] *= as * ws[j][r];
+                for (int r = 0; r < 4; ++r) acc[i][j][r] *= as * w4[r];
+            }
         }
     }
 
