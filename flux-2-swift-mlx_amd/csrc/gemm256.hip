@@ -133,14 +133,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         src[KIND_B0][j] = gW + (size_t)min(n0 + b_row0, p.N - 1) * p.ldw * ES + chunk * 16;
         src[KIND_B1][j] = gW + (size_t)min(n0 + b_row0 + 32, p.N - 1) * p.ldw * ES + chunk * 16;
     }
-    // FP8: the eight 64-bit source pointers do not fit next to the 8-register operand tuples of the block-scaled MFMA — hipcc
-    // spilled them and reloaded each one with scratch_load + s_waitcnt vmcnt(0) in front of its LDS-DMA, i.e. the DMA pipeline was
-    // DRAINED in every phase (196 B/lane of scratch since round 1).  The FP8 instantiation therefore issues its LDS-DMA in the
-    // scalar-base + 32-bit-vector-offset form (inline asm: the builtin only takes per-lane 64-bit pointers): eight offset registers
-    // instead of sixteen pointer registers and no 64-bit vector adds.  The loads are invisible to hipcc's counters, which is what
-    // this loop wants anyway (every wait on them is one of the hand-counted s_waitcnt vmcnt below).
+    // LDS-DMA in the scalar-base + 32-bit-vector-offset form (inline asm: the builtin only takes per-lane 64-bit pointers): eight
+    // offset registers instead of sixteen pointer registers, and no 64-bit vector add + v_readfirstlane pair in front of every
+    // piece.  bf16: +3-4 % on every production shape (profiles/r02_d_gemm_asm_dma_ab.log, two interleaved rounds on one box).
+    // FP8: the pointers did not fit next to the 8-register operand tuples of the block-scaled MFMA at all — hipcc had spilled
+    // them and reloaded each one with scratch_load + s_waitcnt vmcnt(0) in front of its DMA, DRAINING the pipeline in every
+    // phase (196 B/lane of scratch since round 1).  The loads are invisible to hipcc's counters, which is what this loop wants
+    // anyway: every wait on them is one of the hand-counted s_waitcnt vmcnt below.
+    constexpr bool ASM_DMA = !(VAR & 8);   // VAR bit 3 (dev A/B, FLUX2MI_GEMM_VAR=11): the builtin with per-lane 64-bit pointers instead
     uint32_t soff[4][2];
-    if (FP8) {
+    if (ASM_DMA) {
 #pragma unroll
         for (int kd = 0; kd < 4; ++kd)
 #pragma unroll
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         if (u__ < nk && !((kind_) == KIND_A1 && a1_skip)) {                                                   \
             uint8_t* dst__ = smem + (u__ & 1) * STAGE2_BYTES + (kind_) * SLOT_BYTES + lds_wave;               \
             const long long ko__ = u__ * (((kind_) == KIND_A0 || (kind_) == KIND_A1) ? ksA : ksB);            \
-            if (FP8) {                                                                                        \
+            if (ASM_DMA) {                                                                                    \
                 const uint8_t* b__ = (((kind_) == KIND_A0 || (kind_) == KIND_A1) ? gA : gW) + ko__;           \
                 const uint32_t m__ = lds_wave_s + (uint32_t)((u__ & 1) * STAGE2_BYTES + (kind_) * SLOT_BYTES); \
                 G2_DMA_ASM(soff[kind_][0], b__, m__)                                                          \
@@ -195,7 +197,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
     const int b_frag = (wn * 32 + frow) * 128;   // + j*16*128
     const int c0 = ((0 + fq) ^ sw) << 4, c1 = ((4 + fq) ^ sw) << 4;   // kk = 0, 1
 
-    bf16x8 a[4][2], b0[2][2], b1[2][2];
+    // PIPE (VAR bit 2, bf16): every phase's MFMAs run on fragments read during the PREVIOUS phase, so no LDS read latency sits
+    // between a phase's barrier and its MFMAs; the rows of the second half-tile then need their own registers (a1f).
+    constexpr bool PIPE = (VAR & 4) && !FP8;
+    bf16x8 a[4][2], a1f[PIPE ? 4 : 1][2], b0[2][2], b1[2][2];
     // FP8: a lane's two 16-byte chunks are ONE 32-byte operand of the block-scaled MFMA.  The 8-register tuples are formed where
     // the fragments are READ (the two halves die at once and coalesce into the tuple); forming them at the MFMA kept both the
     // halves and the tuples live and cost 50 spilled registers inside the K loop (196 B/lane of scratch, scratch loads on the
@@ -207,6 +212,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         const uint8_t* r__ = st + (slot_) * SLOT_BYTES + a_frag + i_ * 2048;               \
         if (FP8) {                                                                         \
             a8[i_] = __builtin_shufflevector(*reinterpret_cast<const i32x4*>(r__ + c0), *reinterpret_cast<const i32x4*>(r__ + c1), 0, 1, 2, 3, 4, 5, 6, 7); \
+        } else if (PIPE && (slot_) == KIND_A1) {                                           \
+            a1f[PIPE ? i_ : 0][0] = *reinterpret_cast<const bf16x8*>(r__ + c0);            \
+            a1f[PIPE ? i_ : 0][1] = *reinterpret_cast<const bf16x8*>(r__ + c1);            \
         } else {                                                                           \
             a[i_][0] = *reinterpret_cast<const bf16x8*>(r__ + c0);                         \
             a[i_][1] = *reinterpret_cast<const bf16x8*>(r__ + c1);                         \
@@ -239,7 +247,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
                 _Pragma("unroll") for (int i_ = 0; i_ < ((mh_) ? NI1 : 4); ++i_)                                         \
                     _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                     \
                         acc[(mh_) * 4 + i_][(nh_) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(  \
-                            bsrc_[j_][kk_], a[i_][kk_], acc[(mh_) * 4 + i_][(nh_) * 2 + j_], 0, 0, 0);   \
+                            bsrc_[j_][kk_], (PIPE && (mh_)) ? a1f[PIPE ? i_ : 0][kk_] : a[i_][kk_],      \
+                            acc[(mh_) * 4 + i_][(nh_) * 2 + j_], 0, 0, 0);                               \
         }                                                                                                \
     }                                                                                                    \
     __builtin_amdgcn_s_setprio(0);
@@ -343,6 +352,48 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         G2_READ_B(b0, KIND_B0) G2_READ_B(b1, KIND_B1) G2_READ_A(KIND_A0)
     }
     if (DIAG) { unsigned long long z__ = 0; G2_STAMP(z__) dg_r = dg_w1 = dg_m = dg_w2 = dg_dma = dg_rd = z__ * 0; }
+    if (PIPE) {
+        // Software-pipelined fragment reads (bf16).  The whole K-tile kt+1 is visible to every wave from phase 3 of K-tile kt on:
+        // the K-tile's counted wait sits in phase 2 (vmcnt(4): only A0, B0 of kt+2 may still fly), so that BOTH wave groups —
+        // which run half a phase apart — have executed it before either passes the barrier that opens its phase 3.
+        //   p0: read B1(kt) | issue A1(kt+1) | MFMA (m0,n0) on a, b0      p2: issue B0(kt+2), vmcnt(4) | MFMA (m1,n0) on a1f, b0
+        //   p1: read A1(kt) | issue A0(kt+2) | MFMA (m0,n1) on a, b1      p3: issue B1(kt+2) | read A0, B0(kt+1) | MFMA (m1,n1) on a1f, b1
+        // hipcc places the lgkmcnt waits itself (counted, in front of the first MFMA that consumes a fragment).
+        {
+            const uint8_t* st = smem;
+            G2_READ_B(b0, KIND_B0)
+            G2_READ_A(KIND_A0)
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const uint8_t* st = smem + (kt & 1) * STAGE2_BYTES;
+            const bool drain = kt + 2 >= nk;
+            G2_READ_B(b1, KIND_B1)
+            G2_ISSUE(KIND_A1, kt + 1)
+            G2_SYNC()
+            G2_MFMA(0, 0, b0)
+            G2_SYNC()
+            G2_READ_A(KIND_A1)
+            G2_ISSUE(KIND_A0, kt + 2)
+            G2_SYNC()
+            G2_MFMA(0, 1, b1)
+            G2_SYNC()
+            G2_ISSUE(KIND_B0, kt + 2)
+            if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            G2_SYNC()
+            G2_MFMA(1, 0, b0)
+            G2_SYNC()
+            G2_ISSUE(KIND_B1, kt + 2)
+            G2_SYNC()
+            if (kt + 1 < nk) {
+                st = smem + ((kt + 1) & 1) * STAGE2_BYTES;
+                G2_READ_B(b0, KIND_B0)
+                G2_READ_A(KIND_A0)
+            }
+            G2_MFMA(1, 1, b1)
+            G2_SYNC()
+        }
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         const uint8_t* st = smem + (kt & 1) * STAGE2_BYTES;
         const bool drain = kt + 2 >= nk;
@@ -804,6 +855,16 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
         hipLaunchKernelGGL((gemm_bf16_256x256_kernel<false, 0, false, false, false, 2>), grid, block, 0, stream, b);
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
+#ifdef FLUX2MI_DEV
+    if (var == 7 && abl == 0 && stagger == 1 && ni == 8) {    // software-pipelined fragment reads (A/B)
+        hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 7, 8>), grid, block, 0, stream, b);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
+    if (var == 11 && abl == 0 && stagger == 1 && ni == 8) {   // the builtin LDS-DMA form (round 1's), for A/B
+        hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 11, 8>), grid, block, 0, stream, b);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
+#endif
     if (var >= 1 && var <= 3 && abl == 0 && stagger == 1) {
         if (var == 1) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 1>), grid, block, 0, stream, b);
         else if (var == 2) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 2>), grid, block, 0, stream, b);
