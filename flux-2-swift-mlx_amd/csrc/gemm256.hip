@@ -150,12 +150,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
                 soff[kd][j] = (uint32_t)(src[kd][j] - ((kd == KIND_A0 || kd == KIND_A1) ? gA : gW));
     }
     const uint32_t lds_wave_s = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem + wid * 1024);
+    // (M0 is not saved / restored: nothing else in this kernel uses it — gfx950 LDS instructions do not read M0, and the .s of every
+    // instantiation has no other reference to it; tools/check_m0.sh greps for that after a compiler change)
 #define G2_DMA_ASM(voff_, sbase_, m0_)                                                                                  \
-    {                                                                                                                   \
-        unsigned keep__;                                                                                                \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(keep__) : "v"(voff_), "s"(m0_), "s"(sbase_) : "memory");                                   \
-    }
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(voff_), "s"(m0_), "s"(sbase_) : "memory");
     const long long ksA = p.a_kstride ? p.a_kstride : 128, ksB = p.w_kstride ? p.w_kstride : 128;
     const int lds_wave = wid * 1024;  // + j*8192 + slot*SLOT_BYTES + stage*STAGE2_BYTES
     const int nk = p.K / TILE_K;
