@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
         if (!(VAR & 1)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         G2_STAMP(dg_r)                                           \
         G2_SYNC()                                                \
-        if (VAR & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+        if ((VAR & 1) && !(VAR & 16)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
         G2_STAMP(dg_w1)                                          \
     }
 #define G2_PHASE_END()                                                          \
@@ -817,17 +817,21 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
     if (trace_now && hipMalloc((void**)&b.trace, trace_n * 8) != hipSuccess) b.trace = nullptr;
 
     const bool fp8 = probs[0].fp8 != 0;
-#define G2_GO_NI(FP8_)                                                                                                  \
+#define G2_GO_NI(FP8_, VAR_)                                                                                                  \
     switch (ni) {                                                                                                       \
-        case 7: hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, FP8_, 3, 7>), dim3(tiles[0] + tiles[1]), dim3(512), 0, stream, b); break; \
-        case 6: hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, FP8_, 3, 6>), dim3(tiles[0] + tiles[1]), dim3(512), 0, stream, b); break; \
-        case 5: hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, FP8_, 3, 5>), dim3(tiles[0] + tiles[1]), dim3(512), 0, stream, b); break; \
-        default: hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, FP8_, 3, 8>), dim3(tiles[0] + tiles[1]), dim3(512), 0, stream, b); break; \
+        case 7: hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, FP8_, VAR_, 7>), dim3(tiles[0] + tiles[1]), dim3(512), 0, stream, b); break; \
+        case 6: hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, FP8_, VAR_, 6>), dim3(tiles[0] + tiles[1]), dim3(512), 0, stream, b); break; \
+        case 5: hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, FP8_, VAR_, 5>), dim3(tiles[0] + tiles[1]), dim3(512), 0, stream, b); break; \
+        default: hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, FP8_, VAR_, 8>), dim3(tiles[0] + tiles[1]), dim3(512), 0, stream, b); break; \
     }
+    // VAR 19 = one counted vmcnt per K-tile (bit 1), the fragment-read wait behind the phase's first barrier (bit 0) left to
+    // hipcc's counted lgkmcnt waits in front of each MFMA pair (bit 4: +1-1.7 % over an explicit lgkmcnt(0), r02_d_gemm_lgkm_ab.log)
     if (fp8) {
-        G2_GO_NI(true)
+        G2_GO_NI(true, 19)
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
+    const dim3 grid(tiles[0] + tiles[1]), block(512);
+#ifdef FLUX2MI_DEV   // every schedule variant, timing-only ablation and diagnostic build below exists in libflux2mi_dev.so only
     static const int abl = [] {
         const char* e = F2_DEV_ENV("FLUX2MI_GEMM_ABLATE");
         return e ? atoi(e) : 0;
@@ -836,13 +840,12 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
         const char* e = F2_DEV_ENV("FLUX2MI_GEMM_STAGGER");
         return e ? atoi(e) : 1;
     }();
-    const dim3 grid(tiles[0] + tiles[1]), block(512);
     // schedule variant (see VAR on the kernel): default 3 = one counted vmcnt per K-tile (measured +7 %
     // over a wait in every phase: linear1 0.649 -> 0.605 ms, 8192^3 1224 -> 1326 TF on one box) and
     // the fragment-read wait behind the phase's first barrier (+0..1 %)
     static const int var = [] {
         const char* e = F2_DEV_ENV("FLUX2MI_GEMM_VAR");
-        return e ? atoi(e) : 3;
+        return e ? atoi(e) : 19;
     }();
     if (abl == 32 || abl == 64) {
         if (abl == 32) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 32, false, false, false, 3>), grid, block, 0, stream, b);
@@ -853,7 +856,10 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
         hipLaunchKernelGGL((gemm_bf16_256x256_kernel<false, 0, false, false, false, 2>), grid, block, 0, stream, b);
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
-#ifdef FLUX2MI_DEV
+    if (var == 3 && abl == 0 && stagger == 1 && ni == 8) {    // explicit lgkmcnt(0) behind the phase's first barrier (round 1's form)
+        hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 3, 8>), grid, block, 0, stream, b);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
     if (var == 7 && abl == 0 && stagger == 1 && ni == 8) {    // software-pipelined fragment reads (A/B)
         hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 7, 8>), grid, block, 0, stream, b);
         return hipGetLastError() == hipSuccess ? 0 : 2;
@@ -862,58 +868,62 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
         hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 11, 8>), grid, block, 0, stream, b);
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
-#endif
-    if (var >= 1 && var <= 3 && abl == 0 && stagger == 1) {
-        if (var == 1) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 1>), grid, block, 0, stream, b);
-        else if (var == 2) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 2>), grid, block, 0, stream, b);
-        else { G2_GO_NI(false) }
-        if (b.trace) {
-            std::vector<unsigned long long> h(trace_n);
-            (void)hipStreamSynchronize(stream);
-            (void)hipMemcpy(h.data(), b.trace, trace_n * 8, hipMemcpyDeviceToHost);
-            (void)hipFree(b.trace);
-            if (FILE* f = fopen(trace_path, "wb")) { fwrite(h.data(), 8, trace_n, f); fclose(f); }
+    if (!(((var >= 1 && var <= 3) || var == 19) && abl == 0 && stagger == 1)) {
+        static const int diag = [] {
+            const char* e = F2_DEV_ENV("FLUX2MI_GEMM_DIAG");
+            return e ? atoi(e) : 0;
+        }();
+        if (diag && nprob == 1 && probs[0].epi == EPI_F32) {
+            // segment-share diagnostic: per-wave cycle sums for (reads+DMA issue, barrier 1, MFMA+vmcnt, barrier 2)
+            static unsigned long long* dbg = nullptr;
+            const size_t n = (size_t)grid.x * 8 * 4;
+            if (!dbg) (void)hipMalloc((void**)&dbg, 4096 * 8 * 4 * 8);
+            if (dbg && grid.x <= 4096) {
+                b.p[0].C2 = dbg;
+                (void)hipMemsetAsync(dbg, 0, n * 8, stream);
+                if (abl == 8) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 8, false, true>), grid, block, 0, stream, b);
+                else hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, true>), grid, block, 0, stream, b);
+                std::vector<unsigned long long> h(n);
+                (void)hipMemcpyAsync(h.data(), dbg, n * 8, hipMemcpyDeviceToHost, stream);
+                (void)hipStreamSynchronize(stream);
+                double s[2][4] = {{0}};
+                for (size_t w = 0; w < (size_t)grid.x * 8; ++w)
+                    for (int k = 0; k < 4; ++k) s[(w & 7) >> 2][k] += (double)(k == 3 ? (h[w * 4 + k] & 0xffffffffull) : h[w * 4 + k]);
+                double dma[2] = {0, 0};
+                for (size_t w = 0; w < (size_t)grid.x * 8; ++w) dma[(w & 7) >> 2] += (double)(h[w * 4 + 3] >> 32);
+                const double nw = (double)grid.x * 4;
+                const int nkt = probs[0].K / 64;
+                for (int g = 0; g < 2; ++g)
+                    fprintf(stderr, "[gemm diag] group %d per K-tile cycles: dma-issue %.0f  reads+lgkm-wait %.0f  barrier1 %.0f  mfma+vmcnt %.0f  barrier2 %.0f  (total %.0f)\n", g,
+                            dma[g] / nw / nkt, s[g][0] / nw / nkt, s[g][1] / nw / nkt, s[g][2] / nw / nkt, s[g][3] / nw / nkt,
+                            (s[g][0] + s[g][1] + s[g][2] + s[g][3]) / nw / nkt);
+                return 0;
+            }
         }
+        if (abl == 1) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 1>), grid, block, 0, stream, b);
+        else if (abl == 2) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 2>), grid, block, 0, stream, b);
+        else if (abl == 3) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 3>), grid, block, 0, stream, b);
+        else if (abl == 4) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 4>), grid, block, 0, stream, b);
+        else if (abl == 17) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 17>), grid, block, 0, stream, b);
+        else if (stagger == 2) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<false, 0, true>), grid, block, 0, stream, b);
+        else if (stagger) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0>), grid, block, 0, stream, b);
+        else hipLaunchKernelGGL((gemm_bf16_256x256_kernel<false, 0>), grid, block, 0, stream, b);
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
-    static const int diag = [] {
-        const char* e = F2_DEV_ENV("FLUX2MI_GEMM_DIAG");
-        return e ? atoi(e) : 0;
-    }();
-    if (diag && nprob == 1 && probs[0].epi == EPI_F32) {
-        // segment-share diagnostic: per-wave cycle sums for (reads+DMA issue, barrier 1, MFMA+vmcnt, barrier 2)
-        static unsigned long long* dbg = nullptr;
-        const size_t n = (size_t)grid.x * 8 * 4;
-        if (!dbg) (void)hipMalloc((void**)&dbg, 4096 * 8 * 4 * 8);
-        if (dbg && grid.x <= 4096) {
-            b.p[0].C2 = dbg;
-            (void)hipMemsetAsync(dbg, 0, n * 8, stream);
-            if (abl == 8) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 8, false, true>), grid, block, 0, stream, b);
-            else hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, true>), grid, block, 0, stream, b);
-            std::vector<unsigned long long> h(n);
-            (void)hipMemcpyAsync(h.data(), dbg, n * 8, hipMemcpyDeviceToHost, stream);
-            (void)hipStreamSynchronize(stream);
-            double s[2][4] = {{0}};
-            for (size_t w = 0; w < (size_t)grid.x * 8; ++w)
-                for (int k = 0; k < 4; ++k) s[(w & 7) >> 2][k] += (double)(k == 3 ? (h[w * 4 + k] & 0xffffffffull) : h[w * 4 + k]);
-            double dma[2] = {0, 0};
-            for (size_t w = 0; w < (size_t)grid.x * 8; ++w) dma[(w & 7) >> 2] += (double)(h[w * 4 + 3] >> 32);
-            const double nw = (double)grid.x * 4;
-            const int nkt = probs[0].K / 64;
-            for (int g = 0; g < 2; ++g)
-                fprintf(stderr, "[gemm diag] group %d per K-tile cycles: dma-issue %.0f  reads+lgkm-wait %.0f  barrier1 %.0f  mfma+vmcnt %.0f  barrier2 %.0f  (total %.0f)\n", g,
-                        dma[g] / nw / nkt, s[g][0] / nw / nkt, s[g][1] / nw / nkt, s[g][2] / nw / nkt, s[g][3] / nw / nkt,
-                        (s[g][0] + s[g][1] + s[g][2] + s[g][3]) / nw / nkt);
-            return 0;
-        }
+    if (var == 1 || var == 2) {
+        if (var == 1) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 1>), grid, block, 0, stream, b);
+        else hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0, false, false, false, 2>), grid, block, 0, stream, b);
+        return hipGetLastError() == hipSuccess ? 0 : 2;
     }
-    if (abl == 1) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 1>), grid, block, 0, stream, b);
-    else if (abl == 2) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 2>), grid, block, 0, stream, b);
-    else if (abl == 3) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 3>), grid, block, 0, stream, b);
-    else if (abl == 4) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 4>), grid, block, 0, stream, b);
-    else if (abl == 17) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 17>), grid, block, 0, stream, b);
-    else if (stagger == 2) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<false, 0, true>), grid, block, 0, stream, b);
-    else if (stagger) hipLaunchKernelGGL((gemm_bf16_256x256_kernel<true, 0>), grid, block, 0, stream, b);
-    else hipLaunchKernelGGL((gemm_bf16_256x256_kernel<false, 0>), grid, block, 0, stream, b);
+#endif
+    (void)grid; (void)block;
+    G2_GO_NI(false, 19)
+    if (b.trace) {
+        std::vector<unsigned long long> h(trace_n);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h.data(), b.trace, trace_n * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(b.trace);
+        if (FILE* f = fopen(trace_path, "wb")) { fwrite(h.data(), 8, trace_n, f); fclose(f); }
+    }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
