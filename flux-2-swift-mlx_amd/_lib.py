@@ -164,6 +164,7 @@ PROTOTYPES = {
     "flux2mi_prof_begin": (_I, [_P, _I]),
     "flux2mi_prof_end": (_I, [_P, _PI, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "flux2mi_op_gemm_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I]),
+    "flux2mi_op_gemm_bf16_out_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I]),
     "flux2mi_op_gemm_bf16_ex": (_I, [_P, _P, _I, C.c_longlong, _P, _I, C.c_longlong, _P, _I, _I, _I]),
     "flux2mi_op_gemm_fp8": (_I, [_P, _P, _P, _P, _I, _I, _I]),
     "flux2mi_op_gemm_gate_resid": (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),

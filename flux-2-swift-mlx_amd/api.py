@@ -318,6 +318,17 @@ class Context:
         self._exit()
         return out
 
+    def op_gemm_bf16_out_bf16(self, a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        a, w = _req(a, torch.bfloat16, "A"), _req(w, torch.bfloat16, "W")
+        m, k = a.shape
+        n = w.shape[0]
+        if out is None:
+            out = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+        self._enter()
+        check(lib().flux2mi_op_gemm_bf16_out_bf16(self.handle, _ptr(a), _ptr(w), _ptr(out), m, n, k))
+        self._exit()
+        return out
+
     def op_gemm_gate_resid(self, a: torch.Tensor, w: torch.Tensor, gate: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         """x f32 [M,N] += gate[N] * (a @ w.T), in place; returns x."""
         a, w = _req(a, torch.bfloat16, "A"), _req(w, torch.bfloat16, "W")

@@ -1181,6 +1181,18 @@ extern "C" int flux2mi_op_gemm_bf16(flux2mi_ctx* ctx, const void* A, const void*
     return FLUX2MI_OK;
 }
 
+// The same product rounded once to bf16 [M,N] (what the block GEMMs of the model store): the like-for-like form for the
+// vendor comparison of tools/gemm_bench.py (hipBLASLt writes bf16 too) and for tests of the EPI_BF16 store path.
+extern "C" int flux2mi_op_gemm_bf16_out_bf16(flux2mi_ctx* ctx, const void* A, const void* W, void* C, int M, int N, int K) {
+    F2_REQUIRE(ctx && A && W && C && M > 0 && N > 0 && K > 0, FLUX2MI_ERR_INVALID_ARG, "op_gemm_bf16_out_bf16: bad argument");
+    GemmProblem p = mk(reinterpret_cast<const uint16_t*>(A), K, reinterpret_cast<const uint16_t*>(W), K, C, N, M, N, K, EPI_BF16);
+    prof_before(ctx, PROF_DIT_GEMM);
+    const int r = launch_gemm(ctx->stream, &p, 1);
+    prof_after(ctx, PROF_DIT_GEMM, 2.0 * M * (double)N * K);
+    F2_LAUNCH(r, "op_gemm_bf16_out_bf16");
+    return FLUX2MI_OK;
+}
+
 // C = A W^T with explicit operand strides: lda / ldw in elements, a_kstride / w_kstride = bytes between consecutive
 // 128-byte K-tile pieces of a row (0 = contiguous rows).  Layout experiments of tools/gemm_bench.py (256x256 kernel only).
 extern "C" int flux2mi_op_gemm_bf16_ex(flux2mi_ctx* ctx, const void* A, int lda, long long a_kstride, const void* W, int ldw,

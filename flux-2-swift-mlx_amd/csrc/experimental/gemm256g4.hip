@@ -57,7 +57,7 @@ __device__ __forceinline__ void g4_swap32(uint32_t& a, uint32_t& b) {
 
 // DIAG: timing-only build of the loop with s_memtime stamps around the waits and the barrier (never the shipped path)
 // ABL (timing only, wrong results): bit 0 no fragment reads, bit 1 no LDS writes, bit 2 no global loads in the steady loop
-template <bool DIAG, int ABL = 0, bool DMA = false>
+template <bool DIAG, int ABL = 0, int DMA = 0>   // DMA: 0 register staging, 1 global_load_lds, 2 buffer_load .. lds (MUBUF, SRD + SGPR K offset)
 __global__ __launch_bounds__(256, 1) void gemm_bf16_256x256_g4_kernel(GemmBatch batch) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE];  // 128 KB, the only LDS object
 
@@ -176,7 +176,20 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_256x256_g4_kernel(GemmBatch 
 
     const uint32_t m0_wave = __builtin_amdgcn_readfirstlane(lds_base + wid * 1024);   // + j*4096 + part + stage
 #define G4_SETM0(mm_, off_) asm volatile("s_add_u32 m0, %0, %1" ::"s"(mm_), "i"(off_) : "memory");
-#define G4_GLDS(voff_, sb_) asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff_), "s"(sb_) : "memory");
+    typedef int g4_i32x4 __attribute__((ext_vector_type(4)));
+    auto mk_srd = [](const uint8_t* base) {   // raw buffer, stride 0, num_records = 4 GiB - 1, gfx9 word3
+        const unsigned long long a = (unsigned long long)base;
+        g4_i32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+        r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffff));
+        r[2] = -1;
+        r[3] = 0x00020000;
+        return r;
+    };
+    const g4_i32x4 sa_srd = mk_srd(gA), sw_srd = mk_srd(gW);
+#define G4_GLDS(voff_, sb_)                                                                                                    \
+    { if (DMA == 2) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff_), "s"(sb_##_srd), "s"(kof) : "memory"); \
+      else asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff_), "s"(sb_) : "memory"); }
     // odd body of the DMA form: 16 reads, then the 16 LDS-DMA pieces of K-tile u+2 (M0 written one MFMA ahead of each)
 #define G4_DMA2(fc_a, fc_b, g_, IS, va_, oa_, vb_, ob_, sa_, sb_)                                   \
     G4_GROUP(fc_a, fc_b, g_, if (IS) G4_SETM0(mm, oa_), if (IS) G4_GLDS(va_, sa_), G4_NONE, G4_NONE,       \
@@ -213,7 +226,132 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_256x256_g4_kernel(GemmBatch 
         G4_GROUP(fc_a, fc_b, 7, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE)                            \
     }
     unsigned long long tr_c0 = 0, tr_r0 = 0, tr_c1 = 0, tr_r1 = 0;
-    if (DMA) {
+    // ---- DMA == 3: one body per K-tile, the fragment reads bunched at its two ends so that a stage is free early and every
+    // LDS-DMA piece has more than a K-tile to land:
+    //   S0 (64 MFMAs on K-step 0 of tile u): gaps 0-15 read K-step 1 of tile u <- stage u&1; gap 21: lgkmcnt(0) + barrier B1 (every
+    //      wave has read all of stage u&1: WAR); groups 3-7: 10 pieces of tile u+2 -> stage u&1
+    //   S1 (64 MFMAs on K-step 1): groups 0-2: the other 6 pieces; group 5: vmcnt(16) (tile u+1's pieces, issued during tile u-1,
+    //      have landed; this tile's 16 stay in flight) + barrier B2 (RAW); groups 6-7 read K-step 0 of tile u+1 <- stage (u+1)&1
+#define G4_V_S0(IS, sa_, sw_)                                                                                                     \
+    {                                                                                                                             \
+        G4_GROUP(fa0, fb0, 0, G4_DSR(fa1[0], ha, 0), G4_DSR(fb1[0], hb, 0), G4_DSR(fa1[1], ha, 2048), G4_DSR(fb1[1], hb, 2048),     \
+                 G4_DSR(fa1[2], ha, 4096), G4_DSR(fb1[2], hb, 4096), G4_DSR(fa1[3], ha, 6144), G4_DSR(fb1[3], hb, 6144))           \
+        G4_GROUP(fa0, fb0, 1, G4_DSR(fa1[4], ha, 8192), G4_DSR(fb1[4], hb, 8192), G4_DSR(fa1[5], ha, 10240), G4_DSR(fb1[5], hb, 10240), \
+                 G4_DSR(fa1[6], ha, 12288), G4_DSR(fb1[6], hb, 12288), G4_DSR(fa1[7], ha, 14336), G4_DSR(fb1[7], hb, 14336))       \
+        G4_GROUP(fa0, fb0, 2, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE,                                                         \
+                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");, G4_NONE, G4_NONE)                                 \
+        G4_DMA2(fa0, fb0, 3, IS, voffA[0], 0 * 4096, voffA[1], 1 * 4096, sa_, sa_)                                                 \
+        G4_DMA2(fa0, fb0, 4, IS, voffA[2], 2 * 4096, voffA[3], 3 * 4096, sa_, sa_)                                                 \
+        G4_DMA2(fa0, fb0, 5, IS, voffA[4], 4 * 4096, voffA[5], 5 * 4096, sa_, sa_)                                                 \
+        G4_DMA2(fa0, fb0, 6, IS, voffA[6], 6 * 4096, voffA[7], 7 * 4096, sa_, sa_)                                                 \
+        G4_DMA2(fa0, fb0, 7, IS, voffW[0], PART + 0 * 4096, voffW[1], PART + 1 * 4096, sw_, sw_)                                   \
+    }
+#define G4_V_S1(IS, RD, sw_)                                                                                                      \
+    {                                                                                                                             \
+        G4_DMA2(fa1, fb1, 0, IS, voffW[2], PART + 2 * 4096, voffW[3], PART + 3 * 4096, sw_, sw_)                                   \
+        G4_DMA2(fa1, fb1, 1, IS, voffW[4], PART + 4 * 4096, voffW[5], PART + 5 * 4096, sw_, sw_)                                   \
+        G4_DMA2(fa1, fb1, 2, IS, voffW[6], PART + 6 * 4096, voffW[7], PART + 7 * 4096, sw_, sw_)                                   \
+        G4_GROUP(fa1, fb1, 3, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE)                              \
+        G4_GROUP(fa1, fb1, 4, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE)                              \
+        G4_GROUP(fa1, fb1, 5, if (IS) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");                               \
+                 else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");,                                                \
+                 G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE)                                                    \
+        G4_GROUP(fa1, fb1, 6, if (RD) G4_DSR(fa0[0], ha2, 0), if (RD) G4_DSR(fb0[0], hb2, 0), if (RD) G4_DSR(fa0[1], ha2, 2048),   \
+                 if (RD) G4_DSR(fb0[1], hb2, 2048), if (RD) G4_DSR(fa0[2], ha2, 4096), if (RD) G4_DSR(fb0[2], hb2, 4096),          \
+                 if (RD) G4_DSR(fa0[3], ha2, 6144), if (RD) G4_DSR(fb0[3], hb2, 6144))                                              \
+        G4_GROUP(fa1, fb1, 7, if (RD) G4_DSR(fa0[4], ha2, 8192), if (RD) G4_DSR(fb0[4], hb2, 8192), if (RD) G4_DSR(fa0[5], ha2, 10240), \
+                 if (RD) G4_DSR(fb0[5], hb2, 10240), if (RD) G4_DSR(fa0[6], ha2, 12288), if (RD) G4_DSR(fb0[6], hb2, 12288),        \
+                 if (RD) G4_DSR(fa0[7], ha2, 14336), if (RD) G4_DSR(fb0[7], hb2, 14336))                                            \
+    }
+    // ---- DMA == 4: the DMA == 3 body with the 16 pieces spread evenly over gaps 25-125 of the 128 (one every ~6.6 MFMAs, the
+    // last three behind B2 between the fragment reads), so that the CU's L2 -> LDS stream never pauses: vmcnt(13) at B2
+#define G4_OFF(n_) ((n_) < 8 ? (n_) * 4096 : PART + ((n_) - 8) * 4096)
+#define G4_P(n_) if (is) G4_SETM0(mm, G4_OFF(n_))
+#define G4_QA(n_) if (is) G4_GLDS(voffA[n_], sa)
+#define G4_QW(n_) if (is) G4_GLDS(voffW[n_], sw)
+#define G4_E_S0(IS)                                                                                                               \
+    {                                                                                                                             \
+        G4_GROUP(fa0, fb0, 0, G4_DSR(fa1[0], ha, 0), G4_DSR(fb1[0], hb, 0), G4_DSR(fa1[1], ha, 2048), G4_DSR(fb1[1], hb, 2048),     \
+                 G4_DSR(fa1[2], ha, 4096), G4_DSR(fb1[2], hb, 4096), G4_DSR(fa1[3], ha, 6144), G4_DSR(fb1[3], hb, 6144))           \
+        G4_GROUP(fa0, fb0, 1, G4_DSR(fa1[4], ha, 8192), G4_DSR(fb1[4], hb, 8192), G4_DSR(fa1[5], ha, 10240), G4_DSR(fb1[5], hb, 10240), \
+                 G4_DSR(fa1[6], ha, 12288), G4_DSR(fb1[6], hb, 12288), G4_DSR(fa1[7], ha, 14336), G4_DSR(fb1[7], hb, 14336))       \
+        G4_GROUP(fa0, fb0, 2, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE,                                                         \
+                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");, G4_NONE, G4_NONE)                                 \
+        G4_GROUP(fa0, fb0, 3, G4_NONE, G4_P(0), G4_QA(0), G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_P(1))                             \
+        G4_GROUP(fa0, fb0, 4, G4_QA(1), G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_P(2), G4_QA(2))                            \
+        G4_GROUP(fa0, fb0, 5, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_P(3), G4_QA(3), G4_NONE, G4_NONE)                             \
+        G4_GROUP(fa0, fb0, 6, G4_NONE, G4_NONE, G4_NONE, G4_P(4), G4_QA(4), G4_NONE, G4_NONE, G4_NONE)                             \
+        G4_GROUP(fa0, fb0, 7, G4_NONE, G4_P(5), G4_QA(5), G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_P(6))                             \
+    }
+#define G4_E_S1(IS, RD)                                                                                                           \
+    {                                                                                                                             \
+        G4_GROUP(fa1, fb1, 0, G4_QA(6), G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_P(7), G4_QA(7))                            \
+        G4_GROUP(fa1, fb1, 1, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_P(8), G4_QW(0), G4_NONE)                             \
+        G4_GROUP(fa1, fb1, 2, G4_NONE, G4_NONE, G4_NONE, G4_P(9), G4_QW(1), G4_NONE, G4_NONE, G4_NONE)                             \
+        G4_GROUP(fa1, fb1, 3, G4_NONE, G4_NONE, G4_P(10), G4_QW(2), G4_NONE, G4_NONE, G4_NONE, G4_NONE)                            \
+        G4_GROUP(fa1, fb1, 4, G4_P(11), G4_QW(3), G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_NONE, G4_P(12))                           \
+        G4_GROUP(fa1, fb1, 5, G4_QW(4), G4_NONE, G4_NONE, G4_NONE,                                                                 \
+                 if (IS) asm volatile("s_waitcnt vmcnt(13)\n\ts_barrier" ::: "memory");                                            \
+                 else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");,                                                \
+                 G4_NONE, G4_NONE, G4_NONE)                                                                                        \
+        G4_GROUP(fa1, fb1, 6, if (RD) G4_DSR(fa0[0], ha2, 0) G4_P(13), if (RD) G4_DSR(fb0[0], hb2, 0) G4_QW(5),                     \
+                 if (RD) G4_DSR(fa0[1], ha2, 2048), if (RD) G4_DSR(fb0[1], hb2, 2048), if (RD) G4_DSR(fa0[2], ha2, 4096),          \
+                 if (RD) G4_DSR(fb0[2], hb2, 4096), if (RD) G4_DSR(fa0[3], ha2, 6144) G4_P(14), if (RD) G4_DSR(fb0[3], hb2, 6144) G4_QW(6)) \
+        G4_GROUP(fa1, fb1, 7, if (RD) G4_DSR(fa0[4], ha2, 8192), if (RD) G4_DSR(fb0[4], hb2, 8192), if (RD) G4_DSR(fa0[5], ha2, 10240), \
+                 if (RD) G4_DSR(fb0[5], hb2, 10240) G4_P(15), if (RD) G4_DSR(fa0[6], ha2, 12288) G4_QW(7), if (RD) G4_DSR(fb0[6], hb2, 12288), \
+                 if (RD) G4_DSR(fa0[7], ha2, 14336), if (RD) G4_DSR(fb0[7], hb2, 14336))                                            \
+    }
+    if (DMA == 3 || DMA == 4) {
+        {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                if (st < nk) {
+                    const uint8_t* a0 = gA + st * 128, *w0 = gW + st * 128;
+                    const uint32_t mm2 = m0_wave + (uint32_t)(st * STAGE);
+#define G4_PRO(va_, off_, sbase_) { unsigned keep__; asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\ts_mov_b32 m0, %0" : "=&s"(keep__) : "v"(va_), "s"(mm2), "i"(off_), "s"(sbase_) : "memory"); }
+                    G4_PRO(voffA[0], 0 * 4096, a0) G4_PRO(voffA[1], 1 * 4096, a0) G4_PRO(voffA[2], 2 * 4096, a0) G4_PRO(voffA[3], 3 * 4096, a0)
+                    G4_PRO(voffA[4], 4 * 4096, a0) G4_PRO(voffA[5], 5 * 4096, a0) G4_PRO(voffA[6], 6 * 4096, a0) G4_PRO(voffA[7], 7 * 4096, a0)
+                    G4_PRO(voffW[0], PART + 0 * 4096, w0) G4_PRO(voffW[1], PART + 1 * 4096, w0) G4_PRO(voffW[2], PART + 2 * 4096, w0) G4_PRO(voffW[3], PART + 3 * 4096, w0)
+                    G4_PRO(voffW[4], PART + 4 * 4096, w0) G4_PRO(voffW[5], PART + 5 * 4096, w0) G4_PRO(voffW[6], PART + 6 * 4096, w0) G4_PRO(voffW[7], PART + 7 * 4096, w0)
+#undef G4_PRO
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const uint32_t ha = a_frag + ch0, hb = b_frag + ch0;
+            G4_DSR(fa0[0], ha, 0) G4_DSR(fa0[1], ha, 2048) G4_DSR(fa0[2], ha, 4096) G4_DSR(fa0[3], ha, 6144)
+            G4_DSR(fa0[4], ha, 8192) G4_DSR(fa0[5], ha, 10240) G4_DSR(fa0[6], ha, 12288) G4_DSR(fa0[7], ha, 14336)
+            G4_DSR(fb0[0], hb, 0) G4_DSR(fb0[1], hb, 2048) G4_DSR(fb0[2], hb, 4096) G4_DSR(fb0[3], hb, 6144)
+            G4_DSR(fb0[4], hb, 8192) G4_DSR(fb0[5], hb, 10240) G4_DSR(fb0[6], hb, 12288) G4_DSR(fb0[7], hb, 14336)
+        }
+        if (batch.trace) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_c0), "=s"(tr_r0)::"memory");
+        // steady state with compile-time flags (a run-time `if` around an asm statement is a scalar branch in an MFMA gap)
+#define G4_V_ITER(FLAGS)                                                                                            \
+        {                                                                                                           \
+            const uint32_t st_cur = (uint32_t)((u & 1) * STAGE), st_nxt = (uint32_t)(((u + 1) & 1) * STAGE);        \
+            FLAGS                                                                                                   \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+            const uint32_t ha = a_frag + st_cur + ch1, hb = b_frag + st_cur + ch1;                                  \
+            const uint32_t ha2 = a_frag + st_nxt + ch0, hb2 = b_frag + st_nxt + ch0;                                \
+            const uint32_t mm = m0_wave + st_cur;                                                                   \
+            const uint8_t* sa = gA + (size_t)(u + 2) * 128;                                                         \
+            const uint8_t* sw = gW + (size_t)(u + 2) * 128;                                                         \
+            const uint32_t kof = (uint32_t)(u + 2) * 128u;                                                          \
+            (void)kof; (void)mm; (void)sa; (void)sw;                                                                \
+            if (DMA == 4) {                                                                                         \
+                G4_E_S0(is)                                                                                         \
+                G4_E_S1(is, rd)                                                                                     \
+            } else {                                                                                                \
+                G4_V_S0(is, sa, sw)                                                                                 \
+                G4_V_S1(is, rd, sw)                                                                                 \
+            }                                                                                                       \
+        }
+        int u = 0;
+        for (; u + 2 < nk; ++u) G4_V_ITER(constexpr bool is = !(ABL & 4); constexpr bool rd = true;)
+        for (; u < nk; ++u) G4_V_ITER(constexpr bool is = false; const bool rd = u + 1 < nk;)
+#undef G4_V_ITER
+    } else if (DMA) {
         // ---- LDS-DMA form.  K-tile u+2 -> stage u&1: 12 pieces in body(2u+1) (behind the barrier that frees the stage), the last
         // 4 in body(2u+2); all 16 are waited for (vmcnt(0)) at the top of body(2u+3), a K-tile and a half after the first was issued.
         {
@@ -251,6 +389,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_256x256_g4_kernel(GemmBatch 
                 const uint32_t ha = a_frag + st_cur + ch1, hb = b_frag + st_cur + ch1;
                 const uint32_t mm = m0_wave + st_nxt;
                 const uint8_t* sw = gW + (size_t)(u + 1) * 128;
+                const uint32_t kof = (uint32_t)(u + 1) * 128u;
                 G4_BODY_DMA_EVEN(is_even && !(ABL & 4), fa0, fb0, fa1, fb1, sw)
             }
             {   // body 2u+1
@@ -261,6 +400,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_256x256_g4_kernel(GemmBatch 
                 const uint8_t* sa = gA + (size_t)(u + 2) * 128;
                 const uint8_t* sw = gW + (size_t)(u + 2) * 128;
                 const bool rd = u + 1 < nk;
+                const uint32_t kof = (uint32_t)(u + 2) * 128u;
                 G4_BODY_DMA(rd, is_odd && !(ABL & 4), fa1, fb1, fa0, fb0, sa, sw)
             }
         }
@@ -395,6 +535,33 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_256x256_g4_kernel(GemmBatch 
                 }
             }
         }
+    } else if (epi == EPI_BF16) {
+        // 16-byte stores: the lane pairs (fq, fq^1) exchange halves so that each lane owns 8 consecutive columns of one block pair
+        uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+        const bool fast = (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && n0 + TN <= p.N;
+        const int wcol = n0 + wn * 128 + (fq & 1) * 16 + (fq >> 1) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = row_base + i * 16;
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                const f32x4 vx = acc[i][2 * jp] * p.alpha, vy = acc[i][2 * jp + 1] * p.alpha;
+                if (fast) {
+                    uint32_t x0 = pack_bf16x2(vx[0], vx[1]), x1 = pack_bf16x2(vx[2], vx[3]);
+                    uint32_t y0 = pack_bf16x2(vy[0], vy[1]), y1 = pack_bf16x2(vy[2], vy[3]);
+                    g4_swap16(x0, y0);
+                    g4_swap16(x1, y1);
+                    if (row < p.M) *reinterpret_cast<uint4*>(C + (size_t)row * p.ldc + wcol + jp * 32) = make_uint4(x0, x1, y0, y1);
+                } else if (row < p.M) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c0 = col_base + (2 * jp) * 16 + r, c1 = c0 + 16;
+                        if (c0 < p.N) C[(size_t)row * p.ldc + c0] = f32_to_bf16_bits(vx[r]);
+                        if (c1 < p.N) C[(size_t)row * p.ldc + c1] = f32_to_bf16_bits(vy[r]);
+                    }
+                }
+            }
+        }
     } else if (epi == EPI_GATE_RESID) {
         float* C = reinterpret_cast<float*>(p.C);
         const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
@@ -459,8 +626,14 @@ int launch_gemm256_g4(hipStream_t stream, const GemmProblem* probs, int nprob) {
     else if (abl == 4) hipLaunchKernelGGL((gemm_bf16_256x256_g4_kernel<false, 4>), grid, block, 0, stream, b);
     else if (abl == 6) hipLaunchKernelGGL((gemm_bf16_256x256_g4_kernel<false, 6>), grid, block, 0, stream, b);
     else if (abl == 7) hipLaunchKernelGGL((gemm_bf16_256x256_g4_kernel<false, 7>), grid, block, 0, stream, b);
-    else if (abl == 100) hipLaunchKernelGGL((gemm_bf16_256x256_g4_kernel<false, 0, true>), grid, block, 0, stream, b);
-    else if (abl == 104) hipLaunchKernelGGL((gemm_bf16_256x256_g4_kernel<false, 4, true>), grid, block, 0, stream, b);
+    else if (abl == 100) hipLaunchKernelGGL((gemm_bf16_256x256_g4_kernel<false, 0, 1>), grid, block, 0, stream, b);
+    else if (abl == 104) hipLaunchKernelGGL((gemm_bf16_256x256_g4_kernel<false, 4, 1>), grid, block, 0, stream, b);
+    else if (abl == 300) hipLaunchKernelGGL((gemm_bf16_256x256_g4_kernel<false, 0, 3>), grid, block, 0, stream, b);
+    else if (abl == 304) hipLaunchKernelGGL((gemm_bf16_256x256_g4_kernel<false, 4, 3>), grid, block, 0, stream, b);
+    else if (abl == 400) hipLaunchKernelGGL((gemm_bf16_256x256_g4_kernel<false, 0, 4>), grid, block, 0, stream, b);
+    else if (abl == 404) hipLaunchKernelGGL((gemm_bf16_256x256_g4_kernel<false, 4, 4>), grid, block, 0, stream, b);
+    else if (abl == 200) hipLaunchKernelGGL((gemm_bf16_256x256_g4_kernel<false, 0, 2>), grid, block, 0, stream, b);
+    else if (abl == 204) hipLaunchKernelGGL((gemm_bf16_256x256_g4_kernel<false, 4, 2>), grid, block, 0, stream, b);
     else
 #endif
     hipLaunchKernelGGL((gemm_bf16_256x256_g4_kernel<false>), grid, block, 0, stream, b);

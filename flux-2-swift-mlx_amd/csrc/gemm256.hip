@@ -758,16 +758,29 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
 
 }  // namespace
 
-// returns 0 ok / 2 launch error; the caller has validated the problems
-int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
-    GemmBatch b;
-    b.nprob = nprob;
-    // Tile height by wave quantisation: rounds of 256 workgroups x relative tile cost (+2 % per row block dropped for
-    // the lower arithmetic intensity); ties keep the taller tile.  FLUX2MI_GEMM_NI=8 forces 256 rows (A/B runs).
+// Tile height by wave quantisation (both 256x256 kernels): rounds of 256 workgroups x relative tile cost (+2 % per row block
+// dropped for the lower arithmetic intensity); ties keep the taller tile.  FLUX2MI_GEMM_NI=8 forces 256 rows (dev A/B runs).
+int gemm256_pick_ni(const GemmProblem* probs, int nprob) {
     static const int ni_force = [] {
         const char* e = F2_DEV_ENV("FLUX2MI_GEMM_NI");
         return e ? atoi(e) : 0;
     }();
+    if (ni_force >= 5 && ni_force <= 8) return ni_force;
+    int ni = 8;
+    double best = 1e30;
+    for (int c = 8; c >= 5; --c) {
+        int tot = 0;
+        for (int i = 0; i < nprob; ++i) tot += ((probs[i].M + 32 * c - 1) / (32 * c)) * ((probs[i].N + 255) / 256);
+        const double cost = (double)((tot + 255) / 256) * (c / 8.0) * (1.0 + 0.02 * (8 - c));
+        if (cost < best * 0.97) { best = cost; ni = c; }   // a shorter tile must win by 3 %
+    }
+    return ni;
+}
+
+// returns 0 ok / 2 launch error; the caller has validated the problems
+int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
+    GemmBatch b;
+    b.nprob = nprob;
     auto count_tiles = [&](int ni, int* per) {
         int tot = 0;
         for (int i = 0; i < nprob; ++i) {
@@ -780,17 +793,7 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {
     // the ablation / diagnostic / schedule-variant instantiations only exist for the 256-row tile
     static const bool dev_env = F2_DEV_ENV("FLUX2MI_GEMM_ABLATE") || F2_DEV_ENV("FLUX2MI_GEMM_VAR") || F2_DEV_ENV("FLUX2MI_GEMM_STAGGER") ||
                                 F2_DEV_ENV("FLUX2MI_GEMM_DIAG");
-    int ni = 8;
-    if (dev_env) ni = 8;
-    else if (ni_force >= 5 && ni_force <= 8) ni = ni_force;
-    else {
-        double best = 1e30;
-        for (int c = 8; c >= 5; --c) {
-            const int tot = count_tiles(c, nullptr);
-            const double cost = (double)((tot + 255) / 256) * (c / 8.0) * (1.0 + 0.02 * (8 - c));
-            if (cost < best * 0.97) { best = cost; ni = c; }   // a shorter tile must win by 3 %
-        }
-    }
+    const int ni = dev_env ? 8 : gemm256_pick_ni(probs, nprob);
     int tiles[2] = {0, 0};
     for (int i = 0; i < nprob; ++i) {
         b.p[i] = probs[i];

@@ -1,0 +1,541 @@
+// gemm256s.hip — the large-tile bf16 GEMM with ONE WAVE PER SIMD: 256x256x64 tile, 4 waves of 128x128, the accumulators
+// in AGPRs, operands by LDS-DMA, every instruction of the K loop hand-placed (inline asm in issue order).
+//
+// Same contract, tile order and epilogues as gemm256.hip (C = A W^T, W [out,in]); it replaces that 8-wave kernel for the
+// bf16 problems (the fp8 instantiation stays there).  Why (measured, profiles/r02_f_*): per K-tile the 8-wave form reads
+// 192 KB of fragments from LDS and crosses 8 barriers; with 128x128 wave tiles it is 128 KB and 2 barriers, and with one
+// wave per SIMD the MFMAs issue back to back (16 cycles each) with the auxiliary instructions in the gaps: 2180-2290
+// shader cycles per 64-deep K-tile against 2048 of pure MFMA issue, where the 8-wave kernel needs 2650.
+//
+// Geometry
+//   * 256 threads = 4 waves as 2 (M) x 2 (N); wave tile (16 NI) x 128 = NI x 8 accumulator blocks of 16x16 (NI = 8: 256
+//     AGPRs); MFMA 16x16x32 with the W fragment as the A operand, so a lane holds 4 consecutive output columns.
+//   * LDS = 2 stages x [256 A rows | 256 W rows] x 128 B = 128 KB.  16-B chunk c of row r sits at c ^ ((r >> 1) & 7);
+//     LDS-DMA writes lane-linear, so the swizzle is applied to the per-lane SOURCE address (and to the fragment reads).
+//   * a K-tile is 16 LDS-DMA pieces per wave (global_load_lds_dwordx4, 1 KB each: 8 rows x 128 B; scalar base + 32-bit
+//     lane offset); piece j of wave w covers rows (4j + w) 8 .. + 8 of its part.  Tile heights 224 / 192 / 160 (NI 7 / 6 /
+//     5: wave quantisation, see gemm256.hip) keep the LDS image; for NI <= 6 the two A pieces no wave reads are skipped.
+//
+// Schedule of one K-tile u (T = 16 NI MFMAs per wave; fragments of BOTH K-steps live in registers, so a stage is free
+// after the first reads of the iteration and every piece has more than a K-tile to land):
+//   S0, MFMAs on K-step 0:  gaps 0 .. R-1: read K-step 1 of tile u <- stage u&1   (R = NI + 8 fragment reads)
+//                           gap R+5: lgkmcnt(0) + barrier B1 — every wave has read all of stage u&1 (WAR)
+//   from B1+3 to T-2:       the NP pieces of tile u+2 -> stage u&1, one every ~6 MFMAs (M0 written one gap ahead), so the
+//                           CU's L2 -> LDS stream never pauses and never bursts
+//   S1, MFMAs on K-step 1:  gap B2: vmcnt(c) + barrier — tile u+1's pieces (issued during tile u-1) have landed, the c
+//                           pieces of this iteration issued so far stay in flight (RAW)
+//                           gaps B2+2 ..: read K-step 0 of tile u+1 <- stage (u+1)&1, done 6 gaps before the end
+//   top of the next iteration: lgkmcnt(0).
+// The steady-state body is instantiated with compile-time flags: a run-time `if` around an asm statement is a scalar
+// branch in an MFMA gap (measured: 2630 cycles per K-tile with them, 2180 without).
+#include "dev.h"
+#include "kernels.h"
+#include <utility>
+
+namespace {
+
+constexpr int TN = 256;
+constexpr int PART = 256 * 128;   // 32 KB: the A rows or the W rows of a stage
+constexpr int STAGE = 2 * PART;   // 64 KB
+
+__device__ __forceinline__ void tile_coords_s(int local, int ntiles, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = local & 7, within = local >> 3;
+    const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    constexpr int GM = 6;
+    const int per_group = GM * tiles_n;
+    const int g = idx / per_group;
+    const int first_m = g * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int in_g = idx - g * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+}
+
+// v_permlane16_swap_b32 / v_permlane32_swap_b32: see gemm256.hip
+__device__ __forceinline__ void s_swap16(uint32_t& a, uint32_t& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void s_swap32(uint32_t& a, uint32_t& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+
+template <int NI>
+struct Sched {
+    static constexpr int G = NI * 8;                 // MFMAs (= gaps) per K-step
+    static constexpr int T = 2 * G;
+    static constexpr int R = NI + 8;                 // fragment reads per K-step
+    static constexpr int B1 = R + 5;
+    static constexpr int RD1 = T - R - 6;            // first gap of the next tile's K-step-0 reads
+    static constexpr int B2 = RD1 - 2;
+    static constexpr int NPA = NI <= 6 ? 6 : 8;      // live A pieces per wave (rows (j & 3) 32 + .. >= 16 NI are never read)
+    static constexpr int NP = NPA + 8;
+    static constexpr int Q0 = B1 + 3, Q1 = T - 2;
+    static constexpr int q_gap(int n) { return Q0 + (n * (Q1 - Q0) + (NP - 1) / 2) / (NP - 1); }
+    static constexpr int piece_at_q(int gap) {
+        for (int n = 0; n < NP; ++n)
+            if (q_gap(n) == gap) return n;
+        return -1;
+    }
+    static constexpr int piece_at_p(int gap) { return piece_at_q(gap + 1); }
+    static constexpr int before_b2() {   // B2's wait comes first in its gap
+        int c = 0;
+        for (int n = 0; n < NP; ++n) c += q_gap(n) < B2 ? 1 : 0;
+        return c;
+    }
+    static constexpr int a_j(int n) { return NPA == 8 ? n : n + (n >= 3 ? 1 : 0); }   // NPA 6: j = 0,1,2,4,5,6
+    static constexpr bool spaced() {
+        for (int n = 0; n + 1 < NP; ++n)
+            if (q_gap(n + 1) < q_gap(n) + 2) return false;
+        return true;
+    }
+    static_assert(B1 < Q0 && B2 > B1 && RD1 + R <= T - 6 + 0 && spaced(), "schedule");
+};
+
+template <int I> using ic = std::integral_constant<int, I>;
+template <bool B> using bc = std::integral_constant<bool, B>;
+// f(ic<0>{}), f(ic<1>{}), ... in order
+template <class F, int... I>
+__device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, I...>) {
+    (f(ic<I>{}), ...);
+}
+#define GS_INLINE __attribute__((always_inline))
+
+template <int NI>
+__global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE];  // 128 KB, the only LDS object
+    using S = Sched<NI>;
+    constexpr int BMT = 32 * NI, WROWS = 16 * NI;
+
+    const int bid = blockIdx.x;
+    const int pi = (batch.nprob > 1 && bid >= batch.tile_start1) ? 1 : 0;
+    const GemmProblem& p = batch.p[pi];
+    const int local = bid - (pi ? batch.tile_start1 : 0);
+    const int tiles_m = (p.M + BMT - 1) / BMT, tiles_n = (p.N + TN - 1) / TN;
+    int tm, tn;
+    tile_coords_s(local, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BMT, n0 = tn * TN;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wid = t >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    // ---- LDS-DMA sources: piece j of a part -> rows (4j + wid) 8 + (lane >> 3), LDS chunk lane & 7 <- global chunk
+    // (lane & 7) ^ ((row >> 1) & 7).  A part row r belongs to wave-row r >> 7: tile row (r & 127) + (r >> 7) WROWS.
+    uint32_t voffA[8], voffW[8];
+    {
+        const int wr8 = wid * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((wr8 >> 1) & 7);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = j * 32 + wr8;
+            const int arow = (r & 127) + (r >> 7) * WROWS;
+            voffA[j] = (uint32_t)(((size_t)min(m0 + arow, p.M - 1) * p.lda + chunk * 8) * 2);
+            voffW[j] = (uint32_t)(((size_t)min(n0 + r, p.N - 1) * p.ldw + chunk * 8) * 2);
+        }
+    }
+    const uint8_t* gA = reinterpret_cast<const uint8_t*>(p.A);
+    const uint8_t* gW = reinterpret_cast<const uint8_t*>(p.W);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    const uint32_t m0_wave = __builtin_amdgcn_readfirstlane(lds_base + wid * 1024);   // + j*4096 + part + stage
+    const int nk = p.K / 64;
+
+    f32x4 acc[NI][8];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment reads: lane (frow, fq) reads row (block*16 + frow), chunk (4h + fq) ^ ((frow >> 1) & 7) of K-step h
+    const int frow = lane & 15, fq = lane >> 4;
+    const int sw = (frow >> 1) & 7;
+    const uint32_t a_frag = lds_base + (wm * 128 + frow) * 128;
+    const uint32_t b_frag = lds_base + PART + (wn * 128 + frow) * 128;
+    const uint32_t ch0 = ((0 + fq) ^ sw) << 4, ch1 = ((4 + fq) ^ sw) << 4;
+
+    bf16x8 fa0[NI], fb0[8], fa1[NI], fb1[8];
+
+#define GS_DSR(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "i"(off_) : "memory")
+    // read r of a K-step: A0, B0, A1, B1, .., A(NI-1), B(NI-1), B(NI), .., B7
+    auto frag_read = [&](auto rc, bf16x8 (&fa)[NI], bf16x8 (&fb)[8], uint32_t ha, uint32_t hb) GS_INLINE {
+        constexpr int r = decltype(rc)::value;
+        (void)fa; (void)fb; (void)ha; (void)hb;
+        if constexpr (r < 2 * NI) {
+            if constexpr ((r & 1) == 0) GS_DSR(fa[r / 2], ha, (r / 2) * 2048);
+            else GS_DSR(fb[r / 2], hb, (r / 2) * 2048);
+        } else {
+            GS_DSR(fb[r - NI], hb, (r - NI) * 2048);
+        }
+    };
+    // piece n of a K-tile: M0 <- LDS destination (P), then the DMA (Q); A pieces first
+    auto piece_p = [&](auto nc, uint32_t mm) GS_INLINE {
+        constexpr int n = decltype(nc)::value;
+        constexpr int off = n < S::NPA ? S::a_j(n) * 4096 : PART + (n - S::NPA) * 4096;
+        asm volatile("s_add_u32 m0, %0, %1" ::"s"(mm), "i"(off) : "memory");
+    };
+    auto piece_q = [&](auto nc, const uint8_t* sa, const uint8_t* sw_) GS_INLINE {
+        constexpr int n = decltype(nc)::value;
+        (void)voffA; (void)voffW;   // named outside `if constexpr`, or the generic lambda does not capture them
+        if constexpr (n < S::NPA) asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voffA[S::a_j(n)]), "s"(sa) : "memory");
+        else asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voffW[n - S::NPA]), "s"(sw_) : "memory");
+    };
+
+    // ---- prologue: K-tiles 0 and 1 -> stages 0 and 1; K-step 0 of tile 0 -> (fa0, fb0)
+    {
+        auto fill_all = [&](uint32_t mm, const uint8_t* sa, const uint8_t* sw_) GS_INLINE {
+            for_seq([&](auto nc) GS_INLINE {
+                piece_p(nc, mm);
+                asm volatile("s_nop 0" ::: "memory");
+                piece_q(nc, sa, sw_);
+            }, std::make_integer_sequence<int, S::NP>{});
+        };
+        fill_all(m0_wave, gA, gW);
+        if (nk > 1) {
+            fill_all(m0_wave + (uint32_t)STAGE, gA + 128, gW + 128);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(S::NP) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");
+        const uint32_t ha = a_frag + ch0, hb = b_frag + ch0;
+        for_seq([&](auto rc) GS_INLINE { frag_read(rc, fa0, fb0, ha, hb); }, std::make_integer_sequence<int, S::R>{});
+    }
+
+    // ---- one K-tile.  IS: the pieces of tile u+2 are issued; RD: the next tile's first fragments are read
+    auto ktile = [&](auto is_c, auto rd_c, int u) GS_INLINE {
+        constexpr bool IS = decltype(is_c)::value, RD = decltype(rd_c)::value;
+        const uint32_t st_cur = (uint32_t)((u & 1) * STAGE), st_nxt = (uint32_t)(((u + 1) & 1) * STAGE);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint32_t ha = a_frag + st_cur + ch1, hb = b_frag + st_cur + ch1;
+        const uint32_t ha2 = a_frag + st_nxt + ch0, hb2 = b_frag + st_nxt + ch0;
+        const uint32_t mm = m0_wave + st_cur;
+        const uint8_t* sa = gA + (size_t)(u + 2) * 128;
+        const uint8_t* sw_ = gW + (size_t)(u + 2) * 128;
+        auto gap = [&](auto gc) GS_INLINE {
+            constexpr int I = decltype(gc)::value;
+            (void)acc; (void)fa0; (void)fb0; (void)fa1; (void)fb1; (void)ha; (void)hb; (void)ha2; (void)hb2; (void)mm; (void)sa; (void)sw_;
+            constexpr int step = I / S::G, g = (I % S::G) / 8, j = I % 8;
+            // W fragment as the A operand: acc[i][j] rows = output columns j*16 + fq*4 + r, lanes = output rows i*16 + frow
+            if constexpr (step == 0)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[g][j]) : "v"(fb0[j]), "v"(fa0[g]));
+            else
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[g][j]) : "v"(fb1[j]), "v"(fa1[g]));
+            if constexpr (I < S::R) frag_read(ic<I>{}, fa1, fb1, ha, hb);
+            if constexpr (I == S::B1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (I == S::B2) {
+                if constexpr (IS) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(S::before_b2()) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            if constexpr (IS && S::piece_at_p(I) >= 0) piece_p(ic<S::piece_at_p(I)>{}, mm);
+            if constexpr (IS && S::piece_at_q(I) >= 0) piece_q(ic<S::piece_at_q(I)>{}, sa, sw_);
+            if constexpr (RD && I >= S::RD1 && I < S::RD1 + S::R) frag_read(ic<I - S::RD1>{}, fa0, fb0, ha2, hb2);
+        };
+        for_seq(gap, std::make_integer_sequence<int, S::T>{});
+    };
+    int u = 0;
+    for (; u + 2 < nk; ++u) ktile(bc<true>{}, bc<true>{}, u);
+    if (u + 1 < nk) { ktile(bc<false>{}, bc<true>{}, u); ++u; }
+    ktile(bc<false>{}, bc<false>{}, u);
+#undef GS_DSR
+    // MFMA result -> first non-MFMA reader: hipcc pads nothing behind inline asm (guide §5.7 item 2)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+    // ---- epilogue (the code of gemm256.hip's, with a wave's 128 columns taken as two 64-column halves h = 0, 1:
+    // its `wn` is wn*2 + h here and its acc[i][j] is acc[i][4h + j]).  Lane (frow, fq) holds, for output row
+    // m0 + wm*WROWS + i*16 + frow, the FOUR CONSECUTIVE columns n0 + wn*128 + j*16 + fq*4 + r of block j = 0..7.
+    const int row_base = m0 + wm * WROWS + frow;
+    int epi = p.epi;
+    if (epi == EPI_QKV_MLP) epi = (n0 >= p.n_split) ? EPI_SWIGLU : EPI_BF16;
+    if (p.qk_qw != nullptr && epi == EPI_BF16 && n0 < p.qk_cols) {
+        // ---- fused QK RMSNorm + RoPE (Flux2Attention.swift:137-157).  A 256-column tile is two heads and a wave holds all
+        // 128 columns of one: the sum of squares is the lane's 32 values + the 4 fq lanes of a row (two lane exchanges).
+        const bool is_k = n0 >= (p.qk_cols >> 1);
+        const uint16_t* wv = (is_k ? p.qk_kw : p.qk_qw) + fq * 4;
+        const float qm = is_k ? 1.0f : p.qk_qmul;
+        // the lane's columns inside the head: j*16 + fq*4 + r = axis j >> 1, pair (j & 1)*8 + fq*2 + (r >> 1) of that axis:
+        // four frequencies per lane, in revolutions (v_sin_f32 / v_cos_f32 take x / 2pi)
+        float wrev[2][2];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+                wrev[jb][pr] = __builtin_amdgcn_exp2f(-(float)(jb * 8 + fq * 2 + pr) * p.qk_l2t16) * 0.15915494309189535f;
+        uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+        const int wcol = n0 + wn * 128 + (fq & 1) * 16 + (fq >> 1) * 8;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row = row_base + i * 16;
+            const float4 ps = *reinterpret_cast<const float4*>(p.qk_pos + (size_t)(p.qk_row0 + min(row, p.M - 1)) * 4);
+            float t2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t2 += acc[i][j][r] * acc[i][j][r];
+            t2 += __shfl_xor(t2, 16);
+            t2 += __shfl_xor(t2, 32);
+            const float rinv = rsqrtf(t2 * (1.0f / 128.0f) + 1e-6f);
+            uint32_t pk[8][2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint2 uw = *reinterpret_cast<const uint2*>(wv + j * 16);
+                const float w0 = lo_bf16(uw.x) * qm, w1 = hi_bf16(uw.x) * qm, w2 = lo_bf16(uw.y) * qm, w3 = hi_bf16(uw.y) * qm;
+                const float pos = (j >> 1) == 0 ? ps.x : (j >> 1) == 1 ? ps.y : (j >> 1) == 2 ? ps.z : ps.w;
+                const float f0 = __builtin_amdgcn_fractf(pos * wrev[j & 1][0]), f1 = __builtin_amdgcn_fractf(pos * wrev[j & 1][1]);
+                const float c0 = __builtin_amdgcn_cosf(f0), s0 = __builtin_amdgcn_sinf(f0);
+                const float c1 = __builtin_amdgcn_cosf(f1), s1 = __builtin_amdgcn_sinf(f1);
+                const float a0 = acc[i][j][0] * rinv * w0, a1 = acc[i][j][1] * rinv * w1;
+                const float a2 = acc[i][j][2] * rinv * w2, a3 = acc[i][j][3] * rinv * w3;
+                pk[j][0] = pack_bf16x2(a0 * c0 - a1 * s0, a1 * c0 + a0 * s0);
+                pk[j][1] = pack_bf16x2(a2 * c1 - a3 * s1, a3 * c1 + a2 * s1);
+            }
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                s_swap16(pk[2 * jp][0], pk[2 * jp + 1][0]);
+                s_swap16(pk[2 * jp][1], pk[2 * jp + 1][1]);
+                if (row < p.M)
+                    *reinterpret_cast<uint4*>(C + (size_t)row * p.ldc + wcol + jp * 32) =
+                        make_uint4(pk[2 * jp][0], pk[2 * jp][1], pk[2 * jp + 1][0], pk[2 * jp + 1][1]);
+            }
+        }
+        return;
+    }
+    for_seq([&](auto hc) GS_INLINE {
+        constexpr int h = decltype(hc)::value;
+        (void)acc;
+        const int wnv = wn * 2 + h;               // the 64-column group of this half
+        const int col_base = n0 + wnv * 64 + fq * 4;
+        if (epi == EPI_F32) {
+            float* C = reinterpret_cast<float*>(p.C);
+            const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int row = row_base + i * 16;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = col_base + j * 16;
+                        float* dst = C + (size_t)row * p.ldc + col;
+                        if (vec_ok && col + 3 < p.N) {
+                            *reinterpret_cast<f32x4*>(dst) = acc[i][4 * h + j] * p.alpha;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (col + r < p.N) dst[r] = acc[i][4 * h + j][r] * p.alpha;
+                        }
+                    }
+                }
+            }
+        } else if (epi == EPI_BF16) {
+            uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+            const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 7) == 0;
+            if ((batch.flags & 1) && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && n0 + TN <= p.N) {
+                // 16-byte stores: half the store instructions of the 8-byte form below.  col_perm16: the four-column
+                // groups of a 16-group go fq 0,2,1,3, so the 16-byte runs pair fq with fq^2 (lanes l, l^32): after the
+                // exchange lanes fq 0,1 hold block 2jp at (fq&1)*8 and lanes fq 2,3 block 2jp+1
+                const int wcol = p.col_perm16 ? n0 + wnv * 64 + (fq >> 1) * 16 + (fq & 1) * 8
+                                              : n0 + wnv * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int row = row_base + i * 16;
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) {
+                        const f32x4 vx = acc[i][4 * h + 2 * jp] * p.alpha, vy = acc[i][4 * h + 2 * jp + 1] * p.alpha;
+                        uint32_t x0 = pack_bf16x2(vx[0], vx[1]), x1 = pack_bf16x2(vx[2], vx[3]);
+                        uint32_t y0 = pack_bf16x2(vy[0], vy[1]), y1 = pack_bf16x2(vy[2], vy[3]);
+                        if (p.col_perm16) {
+                            s_swap32(x0, y0);
+                            s_swap32(x1, y1);
+                        } else {
+                            s_swap16(x0, y0);
+                            s_swap16(x1, y1);
+                        }
+                        if (row < p.M)
+                            *reinterpret_cast<uint4*>(C + (size_t)row * p.ldc + wcol + jp * 32) = make_uint4(x0, x1, y0, y1);
+                    }
+                }
+            } else
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int row = row_base + i * 16;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // col = the output column (bounds), scol = where it is stored (col_perm16: a valid key of a
+                        // partial last group may land past N, inside the padded row)
+                        const int col = col_base + j * 16;
+                        const int scol = p.col_perm16 ? n0 + wnv * 64 + j * 16 + ((fq & 1) * 2 + (fq >> 1)) * 4 : col;
+                        uint16_t* dst = C + (size_t)row * p.ldc + scol;
+                        const f32x4 v = acc[i][4 * h + j] * p.alpha;
+                        if (vec_ok && col + 3 < p.N) {
+                            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (col + r < p.N) dst[r] = f32_to_bf16_bits(v[r]);
+                        }
+                    }
+                }
+            }
+        } else if (epi == EPI_GATE_RESID) {
+            float* C = reinterpret_cast<float*>(p.C);
+            const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+            f32x4 g[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = col_base + j * 16 + r;
+                    g[j][r] = (col < p.N) ? p.vec[col] : 0.f;
+                }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int row = row_base + i * 16;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = col_base + j * 16;
+                        float* dst = C + (size_t)row * p.ldc + col;
+                        if (vec_ok && col + 3 < p.N) {
+                            f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+                            *d4 = *d4 + g[j] * acc[i][4 * h + j];
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (col + r < p.N) dst[r] = dst[r] + g[j][r] * acc[i][4 * h + j][r];
+                        }
+                    }
+                }
+            }
+        } else if (epi == EPI_SWIGLU) {
+            // weight rows are interleaved in blocks of 32 (gate | value) inside each 64-column group:
+            // gate = accumulator blocks 4h + 0,1, value = blocks 4h + 2,3 of the same lane
+            uint16_t* C = reinterpret_cast<uint16_t*>(p.C2);
+            const int start = (p.epi == EPI_QKV_MLP) ? p.n_split : 0;
+            const int hbase = ((n0 + wnv * 64 - start) >> 1) + fq * 4;
+            const int hidden = (p.N - start) >> 1;
+            const bool vec_ok = (p.ldc2 & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 7) == 0;
+            if ((batch.flags & 1) && (p.ldc2 & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && n0 + TN <= p.N) {
+                const int wh = ((n0 + wnv * 64 - start) >> 1) + (fq & 1) * 16 + (fq >> 1) * 8;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int row = row_base + i * 16;
+                    float ox[4], oy[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ox[r] = silu_f(acc[i][4 * h + 0][r]) * acc[i][4 * h + 2][r];
+                        oy[r] = silu_f(acc[i][4 * h + 1][r]) * acc[i][4 * h + 3][r];
+                    }
+                    uint32_t x0 = pack_bf16x2(ox[0], ox[1]), x1 = pack_bf16x2(ox[2], ox[3]);
+                    uint32_t y0 = pack_bf16x2(oy[0], oy[1]), y1 = pack_bf16x2(oy[2], oy[3]);
+                    s_swap16(x0, y0);
+                    s_swap16(x1, y1);
+                    if (row < p.M) *reinterpret_cast<uint4*>(C + (size_t)row * p.ldc2 + wh) = make_uint4(x0, x1, y0, y1);
+                }
+            } else
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int row = row_base + i * 16;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int hh = hbase + j * 16;
+                        uint16_t* dst = C + (size_t)row * p.ldc2 + hh;
+                        float o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = silu_f(acc[i][4 * h + j][r]) * acc[i][4 * h + j + 2][r];
+                        if (vec_ok && hh + 3 < hidden) {
+                            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (hh + r < hidden) dst[r] = f32_to_bf16_bits(o[r]);
+                        }
+                    }
+                }
+            }
+        } else {  // EPI_BIAS_BF16
+            uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+            const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 7) == 0 &&
+                                (p.resid == nullptr || ((p.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.resid) & 7) == 0));
+            f32x4 bsv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = col_base + j * 16 + r;
+                    bsv[j][r] = (p.vec != nullptr && col < p.N) ? p.vec[col] : 0.f;
+                }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int row = row_base + i * 16;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = col_base + j * 16;
+                        uint16_t* dst = C + (size_t)row * p.ldc + col;
+                        f32x4 v = acc[i][4 * h + j] * p.alpha + bsv[j];
+                        if (vec_ok && col + 3 < p.N) {
+                            if (p.resid) {
+                                const uint2 rv = *reinterpret_cast<const uint2*>(p.resid + (size_t)row * p.ldr + col);
+                                v[0] += bf16_bits_to_f32((uint16_t)(rv.x & 0xffff)); v[1] += bf16_bits_to_f32((uint16_t)(rv.x >> 16));
+                                v[2] += bf16_bits_to_f32((uint16_t)(rv.y & 0xffff)); v[3] += bf16_bits_to_f32((uint16_t)(rv.y >> 16));
+                            }
+                            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (col + r < p.N) {
+                                    float x = v[r];
+                                    if (p.resid) x += bf16_bits_to_f32(p.resid[(size_t)row * p.ldr + col + r]);
+                                    dst[r] = f32_to_bf16_bits(x);
+                                }
+                        }
+                    }
+                }
+            }
+        }
+    }, std::make_integer_sequence<int, 2>{});
+}
+
+}  // namespace
+
+int gemm256_pick_ni(const GemmProblem* probs, int nprob);   // gemm256.hip: tile height by wave quantisation
+
+// true when this kernel takes the launch: bf16 operands in plain row-major rows, 32-bit source offsets
+bool gemm256s_eligible(const GemmProblem* probs, int nprob) {
+    for (int i = 0; i < nprob; ++i) {
+        const GemmProblem& q = probs[i];
+        if (q.fp8 || q.a_kstride || q.w_kstride || q.K % 64 != 0) return false;
+        if ((unsigned long long)q.M * (unsigned long long)q.lda * 2 >= (1ull << 32) || (unsigned long long)q.N * (unsigned long long)q.ldw * 2 >= (1ull << 32)) return false;
+    }
+    return true;
+}
+
+// returns 0 ok / 1 unsupported problem / 2 launch error; the caller has validated the problems
+int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
+    GemmBatch b;
+    b.nprob = nprob;
+    const int ni = gemm256_pick_ni(probs, nprob);
+    int tiles[2] = {0, 0};
+    for (int i = 0; i < nprob; ++i) {
+        b.p[i] = probs[i];
+        const GemmProblem& q = probs[i];   // fused QK norm + RoPE: whole heads per tile, 16-byte row stores
+        if (q.qk_qw && (!q.qk_kw || !q.qk_pos || q.qk_cols % 512 != 0 || q.qk_cols > q.N || (q.N & 255) || (q.ldc & 7) ||
+                        (reinterpret_cast<uintptr_t>(q.C) & 15) || (q.epi != EPI_BF16 && q.epi != EPI_QKV_MLP) ||
+                        (q.epi == EPI_QKV_MLP && q.qk_cols > q.n_split)))
+            return 1;
+        tiles[i] = ((q.M + 32 * ni - 1) / (32 * ni)) * ((q.N + TN - 1) / TN);
+    }
+    if (nprob == 1) b.p[1] = probs[0];
+    b.tile_start1 = tiles[0];
+    b.flags = 1;   // 16-byte bf16 / SwiGLU epilogue stores
+    b.trace = nullptr;
+    const dim3 grid(tiles[0] + tiles[1]), block(256);
+    switch (ni) {
+        case 7: hipLaunchKernelGGL((gemm256s_kernel<7>), grid, block, 0, stream, b); break;
+        case 6: hipLaunchKernelGGL((gemm256s_kernel<6>), grid, block, 0, stream, b); break;
+        case 5: hipLaunchKernelGGL((gemm256s_kernel<5>), grid, block, 0, stream, b); break;
+        default: hipLaunchKernelGGL((gemm256s_kernel<8>), grid, block, 0, stream, b); break;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}

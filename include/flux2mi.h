@@ -424,6 +424,8 @@ int flux2mi_prof_end(flux2mi_ctx* ctx, int* n_launches, double* total_ms, double
 /* Standalone op entry points (tests / microbenchmarks; same kernels the forward uses). */
 /* C[M,N] (f32) = A[M,K] (bf16) * W[N,K]^T (bf16) */
 int flux2mi_op_gemm_bf16(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K);
+/* the same product stored as bf16 [M,N] (one rounding of the f32 accumulator), as the model's block GEMMs store it */
+int flux2mi_op_gemm_bf16_out_bf16(flux2mi_ctx* ctx, const void* A, const void* W, void* C, int M, int N, int K);
 /* the same product with explicit operand layouts (microbenchmarks of operand layouts): lda / ldw in elements,
  * a_kstride / w_kstride = bytes between consecutive 128-byte K pieces of a row (0 = contiguous rows) */
 int flux2mi_op_gemm_bf16_ex(flux2mi_ctx* ctx, const void* A, int lda, long long a_kstride, const void* W, int ldw,

@@ -50,13 +50,21 @@ def time_fn(fn, iters=10):
 def main():
     ctx = Context(0)
     check = "--check" in sys.argv
+    rounds = 3
     print(f"FLUX2MI_GEMM={os.environ.get('FLUX2MI_GEMM', '(auto)')}")
     for M, N, K, name in (SHAPES_9B if "--9b" in sys.argv else SHAPES):
         a = torch.randn((M, K), device="cuda").to(torch.bfloat16)
         w = (torch.randn((N, K), device="cuda") * 0.05).to(torch.bfloat16)
-        with torch.cuda.stream(ctx.stream):
-            ms = time_fn(lambda: ctx.op_gemm_bf16(a, w))
-        ms_t = time_fn(lambda: torch.matmul(a, w.t()))
+        wt = w.t()
+        c16 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        ct = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        t32, t16, tt = [], [], []
+        for _ in range(rounds):   # interleaved, so that a clock / thermal drift hits all three alike
+            with torch.cuda.stream(ctx.stream):
+                t32.append(time_fn(lambda: ctx.op_gemm_bf16(a, w)))
+                t16.append(time_fn(lambda: ctx.op_gemm_bf16_out_bf16(a, w, c16)))
+            tt.append(time_fn(lambda: torch.matmul(a, wt, out=ct)))
+        ms, ms16, ms_t = sorted(t32)[rounds // 2], sorted(t16)[rounds // 2], sorted(tt)[rounds // 2]
         fl = 2.0 * M * N * K
         if "--fp8" in sys.argv:   # GEMM kernel alone (HIP events inside the library), quantisation passes excluded
             for _ in range(3):
@@ -67,11 +75,13 @@ def main():
             n, pms, _ = ctx.prof_end()
             ms8 = pms / n
             print(f"{name:16s} fp8 e4m3 kernel {ms8:7.3f} ms {fl / ms8 / 1e9:7.1f} TF", flush=True)
-        line = f"{name:16s} M{M} N{N} K{K}: ours {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF | hipBLASLt {ms_t:7.3f} ms {fl / ms_t / 1e9:7.1f} TF"
+        line = (f"{name:16s} M{M} N{N} K{K}: ours f32 C {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF | ours bf16 C {ms16:7.3f} ms {fl / ms16 / 1e9:7.1f} TF"
+                f" | hipBLASLt bf16 C {ms_t:7.3f} ms {fl / ms_t / 1e9:7.1f} TF | ours/vendor {ms_t / ms16:5.3f}")
         if check:
             out = ctx.op_gemm_bf16(a, w)
             ref = torch.matmul(a.float(), w.float().t())
             line += f" | rel {float((out - ref).norm() / ref.norm()):.2e}"
+            line += f" bf16-out == round(f32-out): {bool(torch.equal(ctx.op_gemm_bf16_out_bf16(a, w), out.to(torch.bfloat16)))}"
         print(line, flush=True)
 
 

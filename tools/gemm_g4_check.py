@@ -13,6 +13,9 @@ SHAPES = [(4608, 27648, 3072, "linear1"), (4608, 3072, 12288, "linear2"), (4608,
           (4608, 3072, 3072, "proj"), (4608, 18432, 3072, "mlp_in"), (8192, 8192, 8192, "square8k"), (4096, 4096, 4096, "square4k")]
 
 
+BF16 = "--bf16" in sys.argv
+
+
 def child(variant):
     import torch
     import flux2mi
@@ -24,8 +27,10 @@ def child(variant):
                         (4608, 3072, 3072), (513, 256, 2048), (255, 1024, 64)]:
             a = torch.randn((M, K), generator=g).to(torch.bfloat16).cuda()
             w = (torch.randn((N, K), generator=g) * 0.05).to(torch.bfloat16).cuda()
-            out = ctx.op_gemm_bf16(a, w)
+            out = ctx.op_gemm_bf16_out_bf16(a, w).float() if BF16 else ctx.op_gemm_bf16(a, w)
             ref = a.float() @ w.float().t()
+            if BF16:
+                ref = ref.to(torch.bfloat16).float()
             err = float((out - ref).norm() / ref.norm())
             bad = int((~torch.isfinite(out)).sum())
             print(f"check {variant} M{M} N{N} K{K}: rel {err:.2e} nonfinite {bad}", flush=True)
@@ -35,12 +40,14 @@ def child(variant):
         w = torch.randint(-3, 4, (3072, 3072)).to(torch.bfloat16).cuda()
         ref = a.float() @ w.float().t()
         for it in range(20):
-            assert torch.equal(ctx.op_gemm_bf16(a, w), ref), it
+            assert torch.equal(ctx.op_gemm_bf16_out_bf16(a, w).float() if BF16 else ctx.op_gemm_bf16(a, w), ref.to(torch.bfloat16).float() if BF16 else ref), it
         print(f"check {variant}: exact-data x20 ok", flush=True)
     for M, N, K, name in SHAPES:
         a = torch.randn((M, K), device="cuda").to(torch.bfloat16)
         w = (torch.randn((N, K), device="cuda") * 0.05).to(torch.bfloat16)
-        fn = (lambda: torch.matmul(a, w.t())) if variant == "blaslt" else (lambda: ctx.op_gemm_bf16(a, w))
+        c16 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        wt = w.t()
+        fn = (lambda: torch.matmul(a, wt, out=c16)) if variant == "blaslt" else ((lambda: ctx.op_gemm_bf16_out_bf16(a, w, c16)) if BF16 else (lambda: ctx.op_gemm_bf16(a, w)))
         ts = []
         for r in range(5):
             with torch.cuda.stream(ctx.stream):
@@ -63,4 +70,4 @@ if __name__ == "__main__":
     else:
         for v, env in (("v2-8wave", {"FLUX2MI_GEMM_V": "2"}), ("v6-g4", {"FLUX2MI_GEMM_V": "6"}), ("blaslt", {})):
             e = dict(os.environ, FLUX2MI_LIB="libflux2mi_dev.so", FLUX2MI_GEMM="256", **env)
-            subprocess.run([sys.executable, __file__, "--variant", v] + [x for x in sys.argv[1:] if x == "--check"], env=e, check=False)
+            subprocess.run([sys.executable, __file__, "--variant", v] + [x for x in sys.argv[1:] if x in ("--check", "--bf16")], env=e, check=False)
