@@ -398,6 +398,16 @@ class Context:
         self._exit()
         return out
 
+    def op_attention_prescaled(self, qkv: torch.Tensor, heads: int, score_bound_log2: float) -> torch.Tensor:
+        """qkv bf16 [S, 3*heads*128] with q already multiplied by log2(e)/sqrt(128); the blocks' form of the attention."""
+        qkv = _req(qkv, torch.bfloat16, "qkv")
+        s = qkv.shape[0]
+        out = torch.empty((s, heads * 128), dtype=torch.bfloat16, device=qkv.device)
+        self._enter()
+        check(lib().flux2mi_op_attention_prescaled(self.handle, _ptr(qkv), _ptr(out), s, heads, float(score_bound_log2)))
+        self._exit()
+        return out
+
 
 def _set_tensors(fn, handle, tensors: Dict[str, torch.Tensor]):
     for name, t in tensors.items():

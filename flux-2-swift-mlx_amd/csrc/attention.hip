@@ -467,6 +467,9 @@ __global__ __launch_bounds__(NW * 64) void attn_combine_kernel(uint16_t* __restr
 
 }  // namespace
 
+int launch_attention64(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
+                       int ldo, int Sq, int S, int heads);   // attention64.hip
+
 // p >= 2^(-2 bound): 2 * 40 stays far inside the f32 / bf16 exponent range
 bool attention_uses_fixed_offset(float score_bound_log2) {
     static const int fixm_on = [] {   // FLUX2MI_ATTN_FIXM=0 keeps the running maximum everywhere (dev A/B runs)
@@ -527,6 +530,15 @@ int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, i
     }
 #endif
     (void)split_ws; (void)n_cu;
+    // the fixed-offset form on pre-scaled Q with whole KV tiles: the one-wave-per-SIMD kernel (attention64.hip).
+    // FLUX2MI_ATTN64=0 with the dev library keeps the kernel below (A/B runs)
+    if (fx == 2 && !nw_env) {
+        static const bool a64_off = [] { const char* e = F2_DEV_ENV("FLUX2MI_ATTN64"); return e && atoi(e) == 0; }();
+        if (!a64_off) {
+            const int r64 = launch_attention64(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads);
+            if (r64 != 1) return r64;
+        }
+    }
     const dim3 grid(qblocks, heads), block(nw * 64);
 #define ATTN_GO(NW_, FX_) hipLaunchKernelGGL((attn_fwd_kernel<false, NW_, FX_>), grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, scale_log2e, S, 1, score_bound_log2, 0)
     if (nw == 8) { if (fx == 2) ATTN_GO(8, 2); else if (fx) ATTN_GO(8, 1); else ATTN_GO(8, 0); }

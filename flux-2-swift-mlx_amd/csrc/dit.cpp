@@ -1264,6 +1264,25 @@ extern "C" int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv_in, void* 
     return FLUX2MI_OK;
 }
 
+// The form the model's blocks run (dit.cpp attention_block): q arrives multiplied by log2(e)/sqrt(128) (the norm + RoPE step folds
+// it in before q's one rounding to bf16) and |q.k| <= score_bound_log2 in that domain, so the softmax may use a fixed zero offset
+// (attention.hip / attention64.hip).  score_bound_log2 <= 0 or > 40 falls back to the running maximum on the pre-scaled q.
+extern "C" int flux2mi_op_attention_prescaled(flux2mi_ctx* ctx, const void* qkv_in, void* out, int S, int heads, float score_bound_log2) {
+    F2_REQUIRE(ctx && qkv_in && out && S > 0 && heads > 0, FLUX2MI_ERR_INVALID_ARG, "op_attention_prescaled: bad argument");
+    const int d = heads * 128, s_pad = attn_s_pad(S);
+    F2_TRY(ctx->scratch.reserve((size_t)heads * 128 * s_pad * 2 + 256 * 4));
+    uint16_t* vt = ctx->scratch.as<uint16_t>();
+    F2_CHECK_HIP(hipMemsetAsync(vt, 0, (size_t)heads * 128 * s_pad * 2, ctx->stream));
+    F2_LAUNCH(launch_v_transpose_only(ctx->stream, reinterpret_cast<const uint16_t*>(qkv_in), 3 * d, S, heads, vt, s_pad), "v_transpose");
+    const uint16_t* q = reinterpret_cast<const uint16_t*>(qkv_in);
+    prof_before(ctx, PROF_ATTENTION);
+    const int r = launch_attention(ctx->stream, q, q + d, 3 * d, vt, s_pad, reinterpret_cast<uint16_t*>(out), d, S, S, heads, score_bound_log2, true,
+                                   nullptr, 0);
+    prof_after(ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
+    F2_LAUNCH(r, "op_attention_prescaled");
+    return FLUX2MI_OK;
+}
+
 // ------------------------------------------------------------------ per-op parity entry points (HBM-bound kernels)
 // SURVEY §8c gives LayerNorm+modulate / RMSNorm+RoPE / GroupNorm their own tolerance (<= 4e-3 vs the fp32 oracle): these
 // run exactly the kernels the forward runs, on caller buffers.

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_256x256_g4_kernel(GemmBatch 
 #define G4_BARRIER() __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); G4_STAMP(dg_bar)
 
     const uint32_t m0_wave = __builtin_amdgcn_readfirstlane(lds_base + wid * 1024);   // + j*4096 + part + stage
-#define G4_SETM0(mm_, off_) asm volatile("s_add_u32 m0, %0, %1" ::"s"(mm_), "i"(off_) : "memory");
+#define G4_SETM0(mm_, off_) asm volatile("s_add_u32 m0, %0, %1" ::"s"(mm_), "i"(off_) : "memory", "scc");
     typedef int g4_i32x4 __attribute__((ext_vector_type(4)));
     auto mk_srd = [](const uint8_t* base) {   // raw buffer, stride 0, num_records = 4 GiB - 1, gfx9 word3
         const unsigned long long a = (unsigned long long)base;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_256x256_g4_kernel(GemmBatch 
                 if (st < nk) {
                     const uint8_t* a0 = gA + st * 128, *w0 = gW + st * 128;
                     const uint32_t mm2 = m0_wave + (uint32_t)(st * STAGE);
-#define G4_PRO(va_, off_, sbase_) { unsigned keep__; asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\ts_mov_b32 m0, %0" : "=&s"(keep__) : "v"(va_), "s"(mm2), "i"(off_), "s"(sbase_) : "memory"); }
+#define G4_PRO(va_, off_, sbase_) { unsigned keep__; asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\ts_mov_b32 m0, %0" : "=&s"(keep__) : "v"(va_), "s"(mm2), "i"(off_), "s"(sbase_) : "memory", "scc"); }
                     G4_PRO(voffA[0], 0 * 4096, a0) G4_PRO(voffA[1], 1 * 4096, a0) G4_PRO(voffA[2], 2 * 4096, a0) G4_PRO(voffA[3], 3 * 4096, a0)
                     G4_PRO(voffA[4], 4 * 4096, a0) G4_PRO(voffA[5], 5 * 4096, a0) G4_PRO(voffA[6], 6 * 4096, a0) G4_PRO(voffA[7], 7 * 4096, a0)
                     G4_PRO(voffW[0], PART + 0 * 4096, w0) G4_PRO(voffW[1], PART + 1 * 4096, w0) G4_PRO(voffW[2], PART + 2 * 4096, w0) G4_PRO(voffW[3], PART + 3 * 4096, w0)
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_256x256_g4_kernel(GemmBatch 
                 if (st < nk) {
                     const uint8_t* a0 = gA + st * 128, *w0 = gW + st * 128;
                     const uint32_t mm2 = m0_wave + (uint32_t)(st * STAGE);
-#define G4_PRO(va_, off_, sbase_) { unsigned keep__; asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\ts_mov_b32 m0, %0" : "=&s"(keep__) : "v"(va_), "s"(mm2), "i"(off_), "s"(sbase_) : "memory"); }
+#define G4_PRO(va_, off_, sbase_) { unsigned keep__; asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\ts_mov_b32 m0, %0" : "=&s"(keep__) : "v"(va_), "s"(mm2), "i"(off_), "s"(sbase_) : "memory", "scc"); }
                     G4_PRO(voffA[0], 0 * 4096, a0) G4_PRO(voffA[1], 1 * 4096, a0) G4_PRO(voffA[2], 2 * 4096, a0) G4_PRO(voffA[3], 3 * 4096, a0)
                     G4_PRO(voffA[4], 4 * 4096, a0) G4_PRO(voffA[5], 5 * 4096, a0) G4_PRO(voffA[6], 6 * 4096, a0) G4_PRO(voffA[7], 7 * 4096, a0)
                     G4_PRO(voffW[0], PART + 0 * 4096, w0) G4_PRO(voffW[1], PART + 1 * 4096, w0) G4_PRO(voffW[2], PART + 2 * 4096, w0) G4_PRO(voffW[3], PART + 3 * 4096, w0)

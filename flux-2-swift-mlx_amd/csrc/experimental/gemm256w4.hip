@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_256x256_w4_kernel(GemmBatch 
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i_][j_]) : "v"(fa_[i_]), "v"(fb_[j_]));
     // M0 (LDS-DMA destination) is written one MFMA ahead of the DMA that reads it (the MFMA is
     // the required wait state); nothing else in this kernel uses M0.
-#define W4_SETM0(mm_, off_) asm volatile("s_add_u32 m0, %0, %1" ::"s"(mm_), "i"(off_) : "memory");
+#define W4_SETM0(mm_, off_) asm volatile("s_add_u32 m0, %0, %1" ::"s"(mm_), "i"(off_) : "memory", "scc");
 #define W4_GLDS(voff_, sb_) asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff_), "s"(sb_) : "memory");
     // group g = the 8 MFMAs of accumulator row g with at most ONE other instruction per MFMA gap:
     // prefetch of fragments g of the next sub-step (2 ds_read_b128) and DMA piece g (s_add m0 + load).

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     auto piece_p = [&](auto nc, uint32_t mm) GS_INLINE {
         constexpr int n = decltype(nc)::value;
         constexpr int off = n < S::NPA ? S::a_j(n) * 4096 : PART + (n - S::NPA) * 4096;
-        asm volatile("s_add_u32 m0, %0, %1" ::"s"(mm), "i"(off) : "memory");
+        asm volatile("s_add_u32 m0, %0, %1" ::"s"(mm), "i"(off) : "memory", "scc");   // s_add writes SCC: hipcc may hold a loop condition there
     };
     auto piece_q = [&](auto nc, const uint8_t* sa, const uint8_t* sw_) GS_INLINE {
         constexpr int n = decltype(nc)::value;

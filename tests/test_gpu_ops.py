@@ -377,3 +377,33 @@ def test_attention_growing_maxima(ctx, S, heads):
     assert rel_l2(out, ref) < 1e-2
     # bit-reproducible
     assert torch.equal(out, ctx.op_attention(qkv.cuda(), heads))
+
+
+@pytest.mark.parametrize("S,heads", [(64, 1), (128, 2), (192, 3), (256, 2), (320, 1), (448, 2), (704, 3), (1216, 2), (200, 2), (1153, 1)])
+def test_attention_prescaled_fixed_offset(ctx, S, heads):
+    """The form the blocks run (flux2mi_op_attention_prescaled): q pre-multiplied by log2(e)/sqrt(128), unit-RMS q / k rows as the
+    QK RMSNorm leaves them, softmax against a fixed zero offset.  Key counts that are multiples of 64 take the one-wave-per-SIMD
+    kernel (attention64.hip) — 1, 2, 3 tiles (prologue / tail paths only), 4-7 (one trip of the three-tile loop + 0-3 tail tiles),
+    11, 19 — the others the 8-wave kernel; both against the oracle's softmax on the un-scaled q (rel-L2 <= 1e-2), bit-reproducible,
+    and within bf16 rounding of the running-maximum path on the same operands."""
+    import math
+    g = torch.Generator().manual_seed(S * 7 + heads)
+    d = heads * 128
+    x = torch.randn((S, 3 * d), generator=g)
+    q = x[:, :d].view(S, heads, 128)
+    k = x[:, d:2 * d].view(S, heads, 128)
+    q = q / q.pow(2).mean(-1, keepdim=True).sqrt()
+    k = k / k.pow(2).mean(-1, keepdim=True).sqrt()
+    k[S // 2] *= 1.5                       # one dominant key per head (still inside the bound below)
+    c = math.log2(math.e) / math.sqrt(128.0)
+    qkv = torch.cat([(q * c).reshape(S, d), k.reshape(S, d), x[:, 2 * d:]], dim=1).to(torch.bfloat16)
+    bound = 1.5 * 128.0 * c                # |q.k| <= 128 * 1.5 for these rows, in the log2 domain
+    out = ctx.op_attention_prescaled(qkv.cuda(), heads, bound)
+    qs, ks, vs = qkv.float().split(d, dim=1)
+    hv = lambda t: t.reshape(1, S, heads, 128).permute(0, 2, 1, 3)
+    ref = R.sdpa(hv(qs / c), hv(ks), hv(vs)).permute(0, 2, 1, 3).reshape(S, d)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 1e-2
+    assert torch.equal(out, ctx.op_attention_prescaled(qkv.cuda(), heads, bound))
+    online = ctx.op_attention_prescaled(qkv.cuda(), heads, 0.0)    # no bound: running maximum on the same pre-scaled q
+    assert rel_l2(out, online.float()) < 6e-3
