@@ -285,10 +285,10 @@ class Context:
         check(lib().flux2mi_prof_begin(self.handle, kernel_class))
 
     PROF_KERNELS = {
-        0: "gemm_bf16_256x256_kernel (single_blocks.linear1: [S,d] x [9d,d]^T as two launches: [q|k] with fused RMSNorm+RoPE "
-           "+ SwiGLU rows, and V^T = W_v x^T)",
-        1: "gemm_bf16_256x256_kernel / gemm_bf16_128x128_kernel (every DiT GEMM)",
-        2: "attn_fwd_kernel (joint attention)",
+        0: "gemm256s_kernel (single_blocks.linear1: [S,d] x [9d,d]^T as two launches: [q|k] with fused RMSNorm+RoPE "
+           "+ SwiGLU rows, and V^T = W_v x^T; fp8 weights: gemm_bf16_256x256_kernel<FP8>)",
+        1: "gemm256s_kernel / gemm_bf16_256x256_kernel<FP8> / gemm_bf16_128x128_kernel (every DiT GEMM)",
+        2: "attn64_kernel / attn_fwd_kernel (joint attention)",
         3: "conv2d_g128_kernel / conv2d_kernel (VAE convolutions)",
     }
 

@@ -21,7 +21,9 @@
 //   V(i+1), issued more than an iteration earlier, have landed in every wave; the 8 pieces of the current window stay in flight
 #include "dev.h"
 #include "kernels.h"
+#include <stdio.h>
 #include <utility>
+#include <vector>
 
 namespace {
 
@@ -58,7 +60,7 @@ struct Flags {};
 
 __global__ __launch_bounds__(256, 1) void attn64_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, int ldqk,
                                                         const uint16_t* __restrict__ vt, int s_pad, uint16_t* __restrict__ out,
-                                                        int ldo, int Sq, int S) {
+                                                        int ldo, int Sq, int S, unsigned long long* trace) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[3 * KT + 3 * VT];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -282,6 +284,9 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const uint16_t* __restri
     // Between the code regions below hipcc may re-assign registers (copies at the region's end): every fragment read and every
     // MFMA result must have landed before such a copy reads it.  Not needed inside the main loop (no copies there: checked in the ISA).
     auto drain = [&]() A64_INLINE { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); };
+    // dev diagnostic (trace != nullptr, FLUX2MI_ATTN_TRACE with the dev library): shader-clock and 100 MHz stamps around the tile loop
+    unsigned long long tr_c0 = 0, tr_r0 = 0;
+    if (trace) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_c0), "=s"(tr_r0)::"memory");
     // iteration -1: QK^T of tile 0 only.  Its pieces 5-7 belong to [K(2), V(1)], 0-4 to [K(3), V(2)].
     iter(bc<true>{}, bc<false>{}, ic<2>{}, -1);
     drain();
@@ -301,6 +306,15 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const uint16_t* __restri
     // MFMA result -> first non-MFMA reader; every DMA piece has landed before the workgroup leaves
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
+    if (trace) {
+        unsigned long long c1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+        if (lane == 0) {
+            unsigned long long* dst = trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wid) * 2;
+            dst[0] = c1 - tr_c0;
+            dst[1] = r1 - tr_r0;
+        }
+    }
     // ---- normalise and store.  o[qb][db][r]: d = db*32 + (r & 3) + 8 (r >> 2) + 4 hi, query = q0 + qb*32 + l31
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -332,6 +346,22 @@ int launch_attention64(hipStream_t stream, const uint16_t* q, const uint16_t* k,
     if (S % BKV != 0 || S < BKV || Sq <= 0) return 1;
     if ((unsigned long long)S * (unsigned long long)ldqk * 2 >= (1ull << 31) || (unsigned long long)HD * (unsigned long long)s_pad * 2 >= (1ull << 31)) return 1;
     const dim3 grid((Sq + 255) / 256, heads), block(256);
-    hipLaunchKernelGGL(attn64_kernel, grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S);
+    unsigned long long* trace = nullptr;
+    static const char* trace_env = F2_DEV_ENV("FLUX2MI_ATTN_TRACE");
+    static int seen = 0;
+    const size_t tn = (size_t)grid.x * grid.y * 4 * 2;
+    if (trace_env && ++seen % 8 == 0 && hipMalloc((void**)&trace, tn * 8) != hipSuccess) trace = nullptr;
+    hipLaunchKernelGGL(attn64_kernel, grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, trace);
+    if (trace) {
+        std::vector<unsigned long long> h(tn);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h.data(), trace, tn * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(trace);
+        double cyc = 0, rt = 0;
+        for (size_t w = 0; w < tn / 2; ++w) { cyc += (double)h[2 * w]; rt += (double)h[2 * w + 1]; }
+        const double tiles = (double)(tn / 2) * (S / BKV + 1);
+        fprintf(stderr, "[attn64 trace] S %d heads %d: %.0f shader cycles per KV tile (64 MFMAs), in-loop clock %.0f MHz, %.3f us per tile\n", S, heads,
+                cyc / tiles, cyc / rt * 100.0, rt / tiles * 0.01);
+    }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

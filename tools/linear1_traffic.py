@@ -16,12 +16,13 @@ def per_dispatch(d, counter):
     return rows
 
 def linear1_pairs(rows):
-    """value sums of (main, vt) pairs: a gemm dispatch of 1728*512 threads followed by the next gemm dispatch"""
+    """value sums of (main, vt) pairs: a 256x256 GEMM dispatch of 1728 workgroups followed by the next GEMM dispatch
+    (gemm256s_kernel: 256 threads per workgroup; the round-1 / early round-2 gemm_bf16_256x256_kernel: 512)"""
     out = []
-    gemm = [r for r in rows if "gemm_bf16_256x256_kernel" in r[1]]
+    gemm = [r for r in rows if "gemm256s_kernel" in r[1] or "gemm_bf16_256x256_kernel" in r[1]]
     for a, b in zip(gemm, gemm[1:]):
-        if a[2] == 1728 * 512:
-            out.append((a[3], b[3], b[2]))
+        if a[2] in (1728 * 256, 1728 * 512):
+            out.append((a[3], b[3], b[2] // (a[2] // 1728)))
     return out
 
 fetch = linear1_pairs(per_dispatch(sys.argv[1], "FETCH_SIZE"))
@@ -32,7 +33,7 @@ w_main = sum(x[0] for x in write) / len(write); w_vt = sum(x[1] for x in write) 
 S, d = 4608, 3072
 alg = (S * d * 2 + 8 * d * d * 2 + S * 2 * d * 2 + S * 3 * d * 2) + (S * d * 2 + d * d * 2 + S * d * 2)   # A + W + outputs, both launches
 res = {
-    "kernel": "gemm_bf16_256x256_kernel, single_blocks.linear1 = [q|k|mlp] launch (1728 x 512) + V^T launch (%d x 512)" % (fetch[0][2] // 512),
+    "kernel": "gemm256s_kernel, single_blocks.linear1 = [q|k|mlp] launch (1728 workgroups) + V^T launch (%d workgroups)" % fetch[0][2],
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/one_forward.py klein-4b 2; average of %d linear1 pairs" % len(fetch),
     "fetch_size_kb": {"main": f_main, "vt": f_vt}, "write_size_kb": {"main": w_main, "vt": w_vt},
     "correction": "gfx950: FETCH_SIZE counts 128-B read requests as 64 B for 16-B/lane streams (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE exact",

@@ -1,0 +1,21 @@
+#!/bin/bash
+# end-of-round measurement batch on ONE box: bench (bf16 with cpu_baseline, fp8), the other configurations, kernel stats, PMC traffic
+# passes for roofline.traffic.  Outputs under gpurun_out/rm/ (copied into profiles/ by hand).
+set -o pipefail
+O=gpurun_out/rm; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python bench.py --steps 5 --warmup 1 > $O/bench.json.log 2>$O/bench.err || exit 1
+tail -1 $O/bench.json.log | cut -c1-400
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline --weights fp8 > $O/bench_fp8.json.log 2>>$O/bench.err || exit 1
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline --attn-softmax online > $O/bench_online_softmax.json.log 2>>$O/bench.err || exit 1
+python tools/run_configs.py A D D8 C E K T > $O/configs.jsonl 2>>$O/bench.err || exit 1
+tail -8 $O/configs.jsonl | cut -c1-200
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/prof.log 2>&1 || exit 1
+find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 tools/one_forward.py klein-4b 2 > $O/fetch.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 tools/one_forward.py klein-4b 2 > $O/write.log 2>&1 || exit 1
+python3 tools/pmc_summary.py $O/fetch > $O/pmc_fetch_size.txt
+python3 tools/pmc_summary.py $O/write > $O/pmc_write_size.txt
+python3 tools/linear1_traffic.py $O/fetch $O/write $O/linear1_traffic.json | tail -5
+rm -rf $O/prof/*/*kernel_trace.csv $O/fetch $O/write
+echo done
