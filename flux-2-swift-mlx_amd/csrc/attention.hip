@@ -468,7 +468,9 @@ __global__ __launch_bounds__(NW * 64) void attn_combine_kernel(uint16_t* __restr
 }  // namespace
 
 int launch_attention64(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
-                       int ldo, int Sq, int S, int heads);   // attention64.hip
+                       int ldo, int Sq, int S, int heads);   // attention64.hip (MFMA 32x32x16)
+int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
+                        int ldo, int Sq, int S, int heads);  // attention64b.hip (MFMA 16x16x32)
 
 // p >= 2^(-2 bound): 2 * 40 stays far inside the f32 / bf16 exponent range
 bool attention_uses_fixed_offset(float score_bound_log2) {
@@ -533,9 +535,10 @@ int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, i
     // the fixed-offset form on pre-scaled Q with whole KV tiles: the one-wave-per-SIMD kernel (attention64.hip).
     // FLUX2MI_ATTN64=0 with the dev library keeps the kernel below (A/B runs)
     if (fx == 2 && !nw_env) {
-        static const bool a64_off = [] { const char* e = F2_DEV_ENV("FLUX2MI_ATTN64"); return e && atoi(e) == 0; }();
-        if (!a64_off) {
-            const int r64 = launch_attention64(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads);
+        static const int a64 = [] { const char* e = F2_DEV_ENV("FLUX2MI_ATTN64"); return e ? atoi(e) : 2; }();   // dev: 0 = the kernel below, 1 = the 32x32x16 form
+        if (a64 != 0) {
+            const int r64 = a64 == 1 ? launch_attention64(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads)
+                                     : launch_attention64b(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads);
             if (r64 != 1) return r64;
         }
     }

@@ -1,0 +1,361 @@
+// attention64b.hip — attention64.hip's structure (one wave per SIMD, 4 waves x 64 query rows, LDS-DMA rings, hand-placed tile
+// loop) on v_mfma_f32_16x16x32_bf16 instead of 32x32x16.
+//
+// Why: at 88 % MFMA issue efficiency attention64 is power-bound (in-loop clock 1.67 GHz), and register-only streams on these
+// boxes sustain 1.94 PF with the 16x16x32 shape against 1.71 PF with 32x32x16 under the same softmax fillers
+// (csrc/experimental/mfma_power_probe.hip, profiles/r02_g_mfma_power_probe.log): the larger shape costs ~13 % more energy per FLOP.
+//
+// Operand geometry (lane = (c16 = lane & 15, g4 = lane >> 4)):
+//   S^T tile = K fragment (A: 16 key rows x 32 d) x Q fragment (B: 32 d x 16 queries): lane holds S[q = c16][4 key rows 4 g4 + r].
+//   The key rows of a K fragment are a free choice (any LDS row per lane): fragment kb = 2 st + u, row m <-> key
+//   32 st + 16 (m >> 3) + 8 u + 4 ((m >> 2) & 1) + (m & 3).  With it the 8 values a lane owns per 32-key step st (rows 4 g4 + r of
+//   fragments u = 0, 1) are exactly the keys of ONE 16-byte chunk of the V^T image as attention.hip's producers write it (keys of
+//   every 16-group permuted to 8h + 4a + b): chunk 4 st + g4.  So P^T (B operand of O^T += V^T P^T) is built in the lane from its own
+//   S registers, the V^T fragment (A: 16 d rows x 32 keys) is one ds_read_b128, and no producer changes.
+//   K tile in LDS: [64 keys][256 B], chunk c of row r at c ^ ((r & 7) | ((r >> 4) & 1) << 3) (the 16 rows of a fragment get 16
+//   different keys); V^T tile: [128 d][128 B], chunk c at c ^ ((r >> 1) & 7), as in attention64.hip.
+// Per wave: O^T 8 x 4 accumulators (128 AGPRs), K fragments of a tile (64 AGPRs), Q blocks 0, 1 (32 AGPRs), Q blocks 2, 3 (32 VGPRs),
+// S 4 x 4 (64 VGPRs), P 2 x 4 (32), V^T fragments of a tile (64).
+// One iteration i = 136 MFMAs (16 cycles each): QK^T of tile i+1 for query blocks 0, 1 (gaps 0-31) and 2, 3 (32-63), PV of tile i
+// for blocks 0, 1 (64-99) and 2, 3 (100-135).  An MFMA holds the vector issue for 8 of its 16 cycles, so a gap takes ONE v_exp_f32
+// or two 4-cycle instructions, and 64 row-sum adds per tile do not fit (measured: 2585 cycles per tile with them, every odd gap
+// over budget).  The row sums therefore ride on the matrix pipe: per 32-key step and query block one more MFMA whose A operand is
+// all ones gives sum_k P^T[k][q] in every row of a 16x16 accumulator — the sum of the SAME bf16 P that multiplies V, reduced across
+// the lanes for free (8 MFMAs per tile instead of 64 v_add_f32 + the final cross-lane sums).  exp2 on the even gaps (blocks 0, 1:
+// 34-96; blocks 2, 3: 98-134 and 0-24 of the next iteration), packs / fragment reads / DMA on the odd ones.
+#include "dev.h"
+#include "kernels.h"
+#include <stdio.h>
+#include <utility>
+#include <vector>
+
+namespace {
+
+constexpr int HD = 128, BKV = 64;
+constexpr int KT = BKV * HD * 2;     // 16 KB
+constexpr int VT = HD * BKV * 2;     // 16 KB
+constexpr int VRING = 3 * KT;        // LDS: K ring (3 slots), then V ring (3 slots) = 96 KB
+
+template <int I> using ic = std::integral_constant<int, I>;
+template <bool B> using bc = std::integral_constant<bool, B>;
+template <class F, int... I>
+__device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, I...>) {
+    (f(ic<I>{}), ...);
+}
+#define B64_INLINE __attribute__((always_inline))
+#define B64_USE (void)o; (void)s; (void)p; (void)kf; (void)vf; (void)qf; (void)lacc; (void)ones; (void)kfa; (void)vfa;
+
+// ---- the schedule (gap = the slot behind MFMA number g of the iteration; >= T: the same slot of the NEXT iteration)
+// softmax element e of a half (query blocks 2H, 2H+1): e = st*16 + qh*8 + u*4 + r -> s[2 st + u][2H + qh][r]; pack c = e / 2
+constexpr int T = 136;                                   // 64 QK^T + 2 x (2 steps x (16 PV + 2 row-sum)) MFMAs
+constexpr int x0_gap(int e) { return 34 + 2 * e; }       // 34..96
+constexpr int c0_gap(int c) { return 101 + 2 * c; }      // 101..131: P blocks 0, 1 are free once PV(i) blocks 0, 1 are done (gap 99)
+constexpr int x1_gap(int e) { return e < 19 ? 98 + 2 * e : T + 2 * (e - 19); }          // 98..134, then 0..24
+constexpr int c1_gap(int c) { return c < 9 ? T + 1 + 2 * c : T + 2 * c + 1; }          // 1..31 of the next iteration: before QK^T(i+2) reaches S blocks 2, 3 at gap 32
+constexpr int kr_gap(int n) { return 65 + 2 * n; }       // K fragment n = 4 ks + kb of tile i+2 (its register was last read at gap 33 + 2n)
+constexpr int vr_gap(int n) { return 103 + 18 * (n / 8) + 2 * (n % 8); }               // V^T fragment n = 8 st + db of tile i+1 (last read at 101 + 18 st + 2 db)
+constexpr int dma_gap(int pc) { return pc < 4 ? 71 + 16 * pc : T + 7 + 16 * (pc - 4); }   // K pieces of tile i+4 here, V^T pieces of tile i+2 in the next window
+constexpr int BAR_GAP = 64;
+// immediate offsets of the fragments inside a tile image
+constexpr int kimm(int n) { return ((n % 4) / 2) * 8192 + ((n % 4) % 2) * 2048; }   // K fragment kb = n % 4 = 2 st + u: rows 32 st + 8 u
+constexpr int vimm(int n) { return (n % 8) * 2048; }                                // d block n % 8
+static_assert(x1_gap(31) == T + 24 && c1_gap(15) == T + 31 && vr_gap(15) == 135 && kr_gap(15) == 95 && c0_gap(15) == 131, "schedule");
+
+__global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, int ldqk,
+                                                         const uint16_t* __restrict__ vt, int s_pad, uint16_t* __restrict__ out,
+                                                         int ldo, int Sq, int S, unsigned long long* trace) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[3 * KT + 3 * VT];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int head = blockIdx.y, q0 = blockIdx.x * 256 + wid * 64;
+    const int nt = S / BKV;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = qb*16 + c16][d = 32 ks + 8 g4 + j]; loaded by asm straight into
+    // their registers (blocks 0, 1 in AGPRs, 2, 3 in VGPRs); the loads are older than every DMA piece: the prologue's vmcnt covers them
+    bf16x8 qf[4][4];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+        const uint16_t* qp = q + (size_t)min(q0 + qb * 16 + c16, Sq - 1) * ldqk + head * HD + g4 * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (qb < 2) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(qf[qb][ks]) : "v"(qp), "i"(ks * 64) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qf[qb][ks]) : "v"(qp), "i"(ks * 64) : "memory");
+        }
+    }
+
+    // ---- LDS-DMA sources.  K piece j of wave w: rows 16 j + 4 w + (lane >> 4), LDS chunk lane & 15 <- global chunk (lane & 15) ^ f(row),
+    // f(row) = (row & 7) | ((row >> 4) & 1) << 3; V^T piece j: rows 32 j + 8 w + (lane >> 3), LDS chunk lane & 7 <- global chunk
+    // (lane & 7) ^ ((row >> 1) & 7)
+    uint32_t voffK[4], voffV[4];
+    {
+        const int kr = wid * 4 + (lane >> 4), vr = wid * 8 + (lane >> 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int krow = j * 16 + kr, vrow = j * 32 + vr;
+            const int fk = (krow & 7) | (((krow >> 4) & 1) << 3);
+            voffK[j] = (uint32_t)krow * (uint32_t)ldqk * 2u + (uint32_t)(((lane & 15) ^ fk) << 4);
+            voffV[j] = (uint32_t)vrow * (uint32_t)s_pad * 2u + (uint32_t)(((lane & 7) ^ ((vrow >> 1) & 7)) << 4);
+        }
+    }
+    const uint8_t* kb8 = reinterpret_cast<const uint8_t*>(k + head * HD);
+    const uint8_t* vb8 = reinterpret_cast<const uint8_t*>(vt + (size_t)head * HD * s_pad);
+    const uint32_t k_tile_bytes = (uint32_t)BKV * (uint32_t)ldqk * 2u;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    const uint32_t m0_wave = __builtin_amdgcn_readfirstlane(lds_base + wid * 1024);
+
+    // ---- fragment read addresses (slot 0).  K fragment (kb = 2 st + u, ks): row 32 st + 8 u + [16 (c16 >> 3) + 4 ((c16 >> 2) & 1) + (c16 & 3)],
+    // chunk (4 ks + g4) ^ c16 (f(row) of that row IS c16).  V^T fragment (db, st): row db*16 + c16, chunk (4 st + g4) ^ ((c16 >> 1) & 7).
+    uint32_t kfa[4], vfa[2];
+    {
+        const int krow = 16 * (c16 >> 3) + 4 * ((c16 >> 2) & 1) + (c16 & 3);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kfa[ks] = lds_base + krow * 256 + (((ks * 4 + g4) ^ c16) << 4);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) vfa[st] = lds_base + VRING + c16 * 128 + (((st * 4 + g4) ^ ((c16 >> 1) & 7)) << 4);
+    }
+
+    f32x4 o[8][4];               // O^T accumulators [d block][query block]
+#pragma unroll
+    for (int db = 0; db < 8; ++db)
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 s[4][4];               // scores [K fragment kb = 2 st + u][query block]
+    u32x4 p[2][4];               // P^T operands [k-step of 32 keys][query block]
+    bf16x8 kf[16], vf[16];       // K fragments n = 4 ks + kb (AGPRs), V^T fragments n = 8 st + db
+    f32x4 lacc[4];               // row sums: every row of the accumulator holds sum_k P[q = c16][k] (A operand = ones)
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) lacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    asm volatile("" : "+v"(ones));   // one register tuple, not re-materialised in the loop
+
+    typedef int b64_i32x4 __attribute__((ext_vector_type(4)));
+    auto mk_srd = [](const uint8_t* base) {   // raw buffer, stride 0, num_records = 4 GiB - 1, gfx9 word3
+        const unsigned long long a = (unsigned long long)base;
+        b64_i32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+        r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffff));
+        r[2] = -1;
+        r[3] = 0x00020000;
+        return r;
+    };
+    const b64_i32x4 k_srd = mk_srd(kb8), v_srd = mk_srd(vb8);
+    // piece pc (0-3: K piece j = pc, 4-7: V^T piece j = pc - 4): M0 <- LDS destination in ring slot `slot`, then the DMA
+    auto dma_m0 = [&](auto pc_c, auto slot_c) B64_INLINE {
+        constexpr int pc = decltype(pc_c)::value, slot = decltype(slot_c)::value;
+        constexpr int off = pc < 4 ? slot * KT + pc * 4096 : VRING + slot * VT + (pc - 4) * 4096;
+        (void)m0_wave;
+        asm volatile("s_add_u32 m0, %0, %1" ::"s"(m0_wave), "i"(off) : "memory", "scc");
+    };
+    auto dma_m0_rt = [&](auto pc_c, uint32_t slot) B64_INLINE {
+        constexpr int pc = decltype(pc_c)::value;
+        (void)m0_wave;
+        const uint32_t mm = pc < 4 ? m0_wave + slot * KT + pc * 4096 : m0_wave + VRING + slot * VT + (pc - 4) * 4096;
+        asm volatile("s_mov_b32 m0, %0" ::"s"(mm) : "memory");
+    };
+    auto dma_go = [&](auto pc_c, uint32_t tile_off) B64_INLINE {
+        constexpr int pc = decltype(pc_c)::value;
+        (void)voffK; (void)voffV; (void)k_srd; (void)v_srd;
+        if constexpr (pc < 4) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voffK[pc]), "s"(k_srd), "s"(tile_off) : "memory");
+        else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voffV[pc - 4]), "s"(v_srd), "s"(tile_off) : "memory");
+    };
+    auto koff = [&](int x) B64_INLINE { return (uint32_t)min(x, nt - 1) * k_tile_bytes; };
+    auto voff = [&](int x) B64_INLINE { return (uint32_t)min(x, nt - 1) * (uint32_t)(BKV * 2); };
+
+#define B64_DSR(dst_, cons_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : cons_(dst_) : "v"(addr_), "i"(off_) : "memory")
+
+    // ---- prologue: K(0) -> fragments; [K(1), V(0)] and the K pieces of K(2) in flight (what iterations -3 and -2 would have issued)
+    {
+        for_seq([&](auto pc) B64_INLINE {
+            dma_m0(pc, ic<0>{});
+            asm volatile("s_nop 0" ::: "memory");
+            dma_go(pc, koff(0));
+        }, std::make_integer_sequence<int, 4>{});
+        for_seq([&](auto pc) B64_INLINE {
+            constexpr int pp = decltype(pc)::value;
+            dma_m0(pc, ic<(pp < 4 ? 1 : 0)>{});
+            asm volatile("s_nop 0" ::: "memory");
+            dma_go(pc, pp < 4 ? koff(1) : voff(0));
+        }, std::make_integer_sequence<int, 8>{});
+        for_seq([&](auto pc) B64_INLINE {
+            dma_m0(pc, ic<2>{});
+            asm volatile("s_nop 0" ::: "memory");
+            dma_go(pc, koff(2));
+        }, std::make_integer_sequence<int, 4>{});
+        asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");   // the Q fragments and K(0) have landed everywhere
+        for_seq([&](auto nc) B64_INLINE {
+            constexpr int n = decltype(nc)::value;
+            B64_USE
+            B64_DSR(kf[n], "=a", kfa[n / 4], kimm(n));
+        }, std::make_integer_sequence<int, 16>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    // ---- one iteration i: QK^T of tile i+1 (HAS_QK), PV of tile i (HAS_PV); R = i mod 3 (2 for i = -1), -1 = run-time ring slots
+    auto iter = [&](auto qk_c, auto pv_c, auto r_c, int i) B64_INLINE {
+        constexpr bool HAS_QK = decltype(qk_c)::value, HAS_PV = decltype(pv_c)::value;
+        constexpr int R = decltype(r_c)::value;
+        constexpr bool CT = R >= 0;
+        constexpr int kslot = CT ? ((R + 2) % 3) * KT : 0;       // K(i+2): fragment reads at gaps 65..95
+        constexpr int vslot = CT ? ((R + 1) % 3) * VT : 0;       // V(i+1): gaps 103..135
+        constexpr int vslot_prev = CT ? ((R + 3) % 3) * VT : 0;  // (no V^T fragment read crosses the iteration in this schedule)
+        const uint32_t ri = (uint32_t)((i + 3) % 3);
+        const uint32_t kslot_rt = CT ? 0u : ((ri + 2) % 3) * KT, vslot_rt = CT ? 0u : ((ri + 1) % 3) * VT, vslot_prev_rt = CT ? 0u : ri * VT;
+        // V^T pieces (gaps 7..55) of V(i+2) -> slot R+2; K pieces (gaps 71..119) of K(i+4) -> slot R+1
+        const uint32_t vA = voff(i + 2), kB = koff(i + 4);
+        auto gap = [&](auto gc) B64_INLINE {
+            constexpr int g = decltype(gc)::value;
+            B64_USE
+            (void)vA; (void)kB; (void)ri; (void)kslot_rt; (void)vslot_rt; (void)vslot_prev_rt;
+            // ---- waits in front of the MFMA
+            if constexpr (g == 0 && HAS_QK) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+            if constexpr (g == 60) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // ---- the MFMA
+            if constexpr (g < 64) {
+                if constexpr (HAS_QK) {
+                    constexpr int H = g / 32, ks = (g % 32) / 8, kb = (g % 8) / 2, qb = 2 * H + g % 2;
+                    if constexpr (qb < 2) {
+                        if constexpr (ks == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "a"(qf[qb][ks]));
+                        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "a"(qf[qb][ks]));
+                    } else {
+                        if constexpr (ks == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "v"(qf[qb][ks]));
+                        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "v"(qf[qb][ks]));
+                    }
+                }
+            } else if constexpr (HAS_PV) {
+                constexpr int H = (g - 64) / 36, st = ((g - 64) % 36) / 18, m = ((g - 64) % 36) % 18;
+                if constexpr (m < 16) {
+                    constexpr int db = m / 2, qb = 2 * H + m % 2;
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(o[db][qb]) : "v"(vf[8 * st + db]), "v"(p[st][qb]));
+                } else {
+                    constexpr int qb = 2 * H + (m - 16);
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(lacc[qb]) : "v"(ones), "v"(p[st][qb]));
+                }
+            }
+            // ---- fillers, in issue order
+            if constexpr (g == BAR_GAP) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            for_seq([&](auto ec) B64_INLINE {
+                constexpr int e = decltype(ec)::value;
+                B64_USE
+                constexpr int st = e / 16, qh = (e / 8) % 2, u = (e / 4) % 2, r = e % 4;
+                // blocks 0, 1 (tile i+1)
+                if constexpr (HAS_QK && x0_gap(e) == g) asm volatile("v_exp_f32 %0, %0" : "+v"(s[2 * st + u][qh][r]));
+                // blocks 2, 3: first part (tile i+1), second part (tile i, started by the previous iteration)
+                if constexpr (HAS_QK && x1_gap(e) == g) asm volatile("v_exp_f32 %0, %0" : "+v"(s[2 * st + u][2 + qh][r]));
+                if constexpr (HAS_PV && x1_gap(e) == g + T) asm volatile("v_exp_f32 %0, %0" : "+v"(s[2 * st + u][2 + qh][r]));
+            }, std::make_integer_sequence<int, 32>{});
+            // bf16 packs: c = st*8 + qh*4 + u*2 + rp -> p[st][qb][u*2 + rp] <- s[2 st + u][qb][2 rp], [2 rp + 1]
+            for_seq([&](auto cc) B64_INLINE {
+                constexpr int c = decltype(cc)::value;
+                B64_USE
+                constexpr int st = c / 8, qh = (c / 4) % 2, u = (c / 2) % 2, rp = c % 2;
+                if constexpr (HAS_QK && c0_gap(c) == g)
+                    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p[st][qh][u * 2 + rp]) : "v"(s[2 * st + u][qh][2 * rp]), "v"(s[2 * st + u][qh][2 * rp + 1]));
+                if constexpr (HAS_PV && c1_gap(c) == g + T)
+                    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p[st][2 + qh][u * 2 + rp]) : "v"(s[2 * st + u][2 + qh][2 * rp]), "v"(s[2 * st + u][2 + qh][2 * rp + 1]));
+            }, std::make_integer_sequence<int, 16>{});
+            // K fragments of tile i+2, V^T fragments of tile i+1
+            for_seq([&](auto nc) B64_INLINE {
+                constexpr int n = decltype(nc)::value;
+                B64_USE (void)kslot_rt; (void)vslot_rt; (void)vslot_prev_rt;
+                if constexpr (HAS_QK && kr_gap(n) == g) { const uint32_t a = kfa[n / 4] + kslot_rt; B64_DSR(kf[n], "=a", a, kslot + kimm(n)); }
+                if constexpr (HAS_QK && vr_gap(n) == g) { const uint32_t a = vfa[n / 8] + vslot_rt; B64_DSR(vf[n], "=v", a, vslot + vimm(n)); }
+                if constexpr (HAS_PV && vr_gap(n) == g + T) { const uint32_t a = vfa[n / 8] + vslot_prev_rt; B64_DSR(vf[n], "=v", a, vslot_prev + vimm(n)); }
+            }, std::make_integer_sequence<int, 16>{});
+            // LDS-DMA: M0 two gaps ahead of the piece
+            for_seq([&](auto pc) B64_INLINE {
+                constexpr int pp = decltype(pc)::value;
+                (void)vA; (void)kB; (void)ri;
+                if constexpr (HAS_QK && pp < 4 && dma_gap(pp) - 2 == g) {
+                    if constexpr (CT) dma_m0(pc, ic<(R + 4) % 3>{});
+                    else dma_m0_rt(pc, (ri + 1) % 3);
+                }
+                if constexpr (HAS_QK && pp < 4 && dma_gap(pp) == g) dma_go(pc, kB);
+                if constexpr (HAS_QK && pp >= 4 && dma_gap(pp) - 2 == g + T) {
+                    if constexpr (CT) dma_m0(pc, ic<(R + 5) % 3>{});
+                    else dma_m0_rt(pc, (ri + 2) % 3);
+                }
+                if constexpr (HAS_QK && pp >= 4 && dma_gap(pp) == g + T) dma_go(pc, vA);
+            }, std::make_integer_sequence<int, 8>{});
+        };
+        for_seq(gap, std::make_integer_sequence<int, T>{});
+    };
+    // Between the code regions below hipcc may re-assign registers (copies at the region's end): every fragment read and every
+    // MFMA result must have landed before such a copy reads it.  Not needed inside the main loop (no copies there: checked in the ISA).
+    auto drain = [&]() B64_INLINE { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); };
+    unsigned long long tr_c0 = 0, tr_r0 = 0;
+    if (trace) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_c0), "=s"(tr_r0)::"memory");
+    iter(bc<true>{}, bc<false>{}, ic<2>{}, -1);
+    drain();
+    int i = 0;
+    for (; i + 3 < nt; i += 3) {      // three tiles per trip: i mod 3 is compile-time inside
+        iter(bc<true>{}, bc<true>{}, ic<0>{}, i);
+        iter(bc<true>{}, bc<true>{}, ic<1>{}, i + 1);
+        iter(bc<true>{}, bc<true>{}, ic<2>{}, i + 2);
+        if (!(i + 6 < nt)) drain();   // last trip: in front of the exit's copies
+    }
+    for (; i + 1 < nt; ++i) {         // at most three more with run-time slots
+        iter(bc<true>{}, bc<true>{}, ic<-1>{}, i);
+        drain();
+    }
+    iter(bc<false>{}, bc<true>{}, ic<-1>{}, i);
+#undef B64_DSR
+    // MFMA result -> first non-MFMA reader; every DMA piece has landed before the workgroup leaves
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    if (trace) {
+        unsigned long long c1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+        if (lane == 0) {
+            unsigned long long* dst = trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wid) * 2;
+            dst[0] = c1 - tr_c0;
+            dst[1] = r1 - tr_r0;
+        }
+    }
+
+    // ---- normalise and store.  o[db][qb][r]: d = db*16 + 4 g4 + r, query = q0 + qb*16 + c16; lacc[qb][*] = the row sum of that query
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+        const float inv = 1.0f / lacc[qb][0];
+        const int qrow = q0 + qb * 16 + c16;
+        if (qrow < Sq) {
+            uint16_t* op = out + (size_t)qrow * ldo + head * HD + g4 * 4;
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                uint2 v;
+                v.x = pack_bf16x2(o[db][qb][0] * inv, o[db][qb][1] * inv);
+                v.y = pack_bf16x2(o[db][qb][2] * inv, o[db][qb][3] * inv);
+                *reinterpret_cast<uint2*>(op + db * 16) = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// 0 launched / 1 not this kernel's case (the caller falls back) / 2 launch error.
+// Requires: q pre-multiplied by scale*log2(e) and the fixed zero offset valid (the caller checks), S % 64 == 0.
+int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
+                        int ldo, int Sq, int S, int heads) {
+    if (S % BKV != 0 || S < BKV || Sq <= 0) return 1;
+    if ((unsigned long long)S * (unsigned long long)ldqk * 2 >= (1ull << 31) || (unsigned long long)HD * (unsigned long long)s_pad * 2 >= (1ull << 31)) return 1;
+    const dim3 grid((Sq + 255) / 256, heads), block(256);
+    unsigned long long* trace = nullptr;
+    static const char* trace_env = F2_DEV_ENV("FLUX2MI_ATTN_TRACE");
+    static int seen = 0;
+    const size_t tn = (size_t)grid.x * grid.y * 4 * 2;
+    if (trace_env && ++seen % 8 == 0 && hipMalloc((void**)&trace, tn * 8) != hipSuccess) trace = nullptr;
+    hipLaunchKernelGGL(attn64b_kernel, grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, trace);
+    if (trace) {
+        std::vector<unsigned long long> h(tn);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h.data(), trace, tn * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(trace);
+        double cyc = 0, rt = 0;
+        for (size_t w = 0; w < tn / 2; ++w) { cyc += (double)h[2 * w]; rt += (double)h[2 * w + 1]; }
+        const double tiles = (double)(tn / 2) * (S / BKV + 1);
+        fprintf(stderr, "[attn64b trace] S %d heads %d: %.0f shader cycles per KV tile (136 MFMAs = 2176), in-loop clock %.0f MHz, %.3f us per tile\n", S, heads,
+                cyc / tiles, cyc / rt * 100.0, rt / tiles * 0.01);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
