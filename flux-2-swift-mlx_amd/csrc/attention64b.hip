@@ -43,7 +43,7 @@ __device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, I...>)
     (f(ic<I>{}), ...);
 }
 #define B64_INLINE __attribute__((always_inline))
-#define B64_USE (void)o; (void)s; (void)p; (void)kf; (void)vf; (void)qf; (void)lacc; (void)ones; (void)kfa; (void)vfa;
+#define B64_USE (void)o; (void)s; (void)p; (void)kf; (void)vf; (void)qf; (void)lacc; (void)ones; (void)ones_last; (void)kfa; (void)vfa;
 
 // ---- the schedule (gap = the slot behind MFMA number g of the iteration; >= T: the same slot of the NEXT iteration)
 // softmax element e of a half (query blocks 2H, 2H+1): e = st*16 + qh*8 + u*4 + r -> s[2 st + u][2H + qh][r]; pack c = e / 2
@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int c16 = lane & 15, g4 = lane >> 4;
     const int head = blockIdx.y, q0 = blockIdx.x * 256 + wid * 64;
-    const int nt = S / BKV;
+    const int nt = (S + BKV - 1) / BKV;   // the last tile may be partial: its missing keys score against key S - 1 again (clamped rows) and are
+                                          // kept out of the row sums by a masked ones operand; V^T is zero there (s_pad >= 64 nt, producers clear it)
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = qb*16 + c16][d = 32 ks + 8 g4 + j]; loaded by asm straight into
     // their registers (blocks 0, 1 in AGPRs, 2, 3 in VGPRs); the loads are older than every DMA piece: the prologue's vmcnt covers them
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
     // ---- LDS-DMA sources.  K piece j of wave w: rows 16 j + 4 w + (lane >> 4), LDS chunk lane & 15 <- global chunk (lane & 15) ^ f(row),
     // f(row) = (row & 7) | ((row >> 4) & 1) << 3; V^T piece j: rows 32 j + 8 w + (lane >> 3), LDS chunk lane & 7 <- global chunk
     // (lane & 7) ^ ((row >> 1) & 7)
-    uint32_t voffK[4], voffV[4];
+    uint32_t voffK[4], voffV[4], kmax[4];   // kmax: the same chunk of the last key row (a partial last tile re-reads row S - 1: finite scores, masked later)
     {
         const int kr = wid * 4 + (lane >> 4), vr = wid * 8 + (lane >> 3);
 #pragma unroll
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
             const int krow = j * 16 + kr, vrow = j * 32 + vr;
             const int fk = (krow & 7) | (((krow >> 4) & 1) << 3);
             voffK[j] = (uint32_t)krow * (uint32_t)ldqk * 2u + (uint32_t)(((lane & 15) ^ fk) << 4);
+            kmax[j] = (uint32_t)(S - 1) * (uint32_t)ldqk * 2u + (uint32_t)(((lane & 15) ^ fk) << 4);
             voffV[j] = (uint32_t)vrow * (uint32_t)s_pad * 2u + (uint32_t)(((lane & 7) ^ ((vrow >> 1) & 7)) << 4);
         }
     }
@@ -125,22 +127,32 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
     f32x4 lacc[4];               // row sums: every row of the accumulator holds sum_k P[q = c16][k] (A operand = ones)
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) lacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 ones;
+    bf16x8 ones, ones_last[2];   // ones_last[st]: 1 for the k-slots of step st whose key exists in the last tile (slot (g4, j) <-> key
+                                 // 32 st + 16 (g4 >> 1) + 8 (j >> 2) + 4 (g4 & 1) + (j & 3)), 0 for the others
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    {
+        const int valid = S - (nt - 1) * BKV;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                ones_last[st][j] = (32 * st + 16 * (g4 >> 1) + 8 * (j >> 2) + 4 * (g4 & 1) + (j & 3)) < valid ? (__bf16)1.0f : (__bf16)0.0f;
+    }
     asm volatile("" : "+v"(ones));   // one register tuple, not re-materialised in the loop
 
     typedef int b64_i32x4 __attribute__((ext_vector_type(4)));
-    auto mk_srd = [](const uint8_t* base) {   // raw buffer, stride 0, num_records = 4 GiB - 1, gfx9 word3
+    auto mk_srd = [](const uint8_t* base, uint32_t num_records) {   // raw buffer, stride 0, gfx9 word3
         const unsigned long long a = (unsigned long long)base;
         b64_i32x4 r;
         r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
         r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffff));
-        r[2] = -1;
+        r[2] = (int)num_records;
         r[3] = 0x00020000;
         return r;
     };
-    const b64_i32x4 k_srd = mk_srd(kb8), v_srd = mk_srd(vb8);
+    // K: the tile offset is added to the lane offset and clamped to the last key row (kmax)
+    const b64_i32x4 k_srd = mk_srd(kb8, 0xffffffffu), v_srd = mk_srd(vb8, 0xffffffffu);
     // piece pc (0-3: K piece j = pc, 4-7: V^T piece j = pc - 4): M0 <- LDS destination in ring slot `slot`, then the DMA
     auto dma_m0 = [&](auto pc_c, auto slot_c) B64_INLINE {
         constexpr int pc = decltype(pc_c)::value, slot = decltype(slot_c)::value;
@@ -156,9 +168,11 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
     };
     auto dma_go = [&](auto pc_c, uint32_t tile_off) B64_INLINE {
         constexpr int pc = decltype(pc_c)::value;
-        (void)voffK; (void)voffV; (void)k_srd; (void)v_srd;
-        if constexpr (pc < 4) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voffK[pc]), "s"(k_srd), "s"(tile_off) : "memory");
-        else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voffV[pc - 4]), "s"(v_srd), "s"(tile_off) : "memory");
+        (void)voffK; (void)voffV; (void)kmax; (void)k_srd; (void)v_srd;
+        if constexpr (pc < 4) {
+            const uint32_t vo = min(voffK[pc] + tile_off, kmax[pc]);
+            asm volatile("buffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(vo), "s"(k_srd) : "memory");
+        } else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voffV[pc - 4]), "s"(v_srd), "s"(tile_off) : "memory");
     };
     auto koff = [&](int x) B64_INLINE { return (uint32_t)min(x, nt - 1) * k_tile_bytes; };
     auto voff = [&](int x) B64_INLINE { return (uint32_t)min(x, nt - 1) * (uint32_t)(BKV * 2); };
@@ -230,7 +244,9 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
                     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(o[db][qb]) : "v"(vf[8 * st + db]), "v"(p[st][qb]));
                 } else {
                     constexpr int qb = 2 * H + (m - 16);
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(lacc[qb]) : "v"(ones), "v"(p[st][qb]));
+                    // the last tile (the only iteration without a QK^T part) sums over its valid keys only
+                    if constexpr (HAS_QK) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(lacc[qb]) : "v"(ones), "v"(p[st][qb]));
+                    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(lacc[qb]) : "v"(ones_last[st]), "v"(p[st][qb]));
                 }
             }
             // ---- fillers, in issue order
@@ -334,10 +350,10 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
 }  // namespace
 
 // 0 launched / 1 not this kernel's case (the caller falls back) / 2 launch error.
-// Requires: q pre-multiplied by scale*log2(e) and the fixed zero offset valid (the caller checks), S % 64 == 0.
+// Requires: q pre-multiplied by scale*log2(e) and the fixed zero offset valid (the caller checks); vt zero beyond key S - 1.
 int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
                         int ldo, int Sq, int S, int heads) {
-    if (S % BKV != 0 || S < BKV || Sq <= 0) return 1;
+    if (S < 1 || Sq <= 0 || s_pad < ((S + BKV - 1) / BKV) * BKV) return 1;
     if ((unsigned long long)S * (unsigned long long)ldqk * 2 >= (1ull << 31) || (unsigned long long)HD * (unsigned long long)s_pad * 2 >= (1ull << 31)) return 1;
     const dim3 grid((Sq + 255) / 256, heads), block(256);
     unsigned long long* trace = nullptr;
@@ -353,7 +369,7 @@ int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k
         (void)hipFree(trace);
         double cyc = 0, rt = 0;
         for (size_t w = 0; w < tn / 2; ++w) { cyc += (double)h[2 * w]; rt += (double)h[2 * w + 1]; }
-        const double tiles = (double)(tn / 2) * (S / BKV + 1);
+        const double tiles = (double)(tn / 2) * ((S + BKV - 1) / BKV + 1);
         fprintf(stderr, "[attn64b trace] S %d heads %d: %.0f shader cycles per KV tile (136 MFMAs = 2176), in-loop clock %.0f MHz, %.3f us per tile\n", S, heads,
                 cyc / tiles, cyc / rt * 100.0, rt / tiles * 0.01);
     }

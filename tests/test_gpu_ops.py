@@ -382,10 +382,10 @@ def test_attention_growing_maxima(ctx, S, heads):
 @pytest.mark.parametrize("S,heads", [(64, 1), (128, 2), (192, 3), (256, 2), (320, 1), (448, 2), (704, 3), (1216, 2), (200, 2), (1153, 1)])
 def test_attention_prescaled_fixed_offset(ctx, S, heads):
     """The form the blocks run (flux2mi_op_attention_prescaled): q pre-multiplied by log2(e)/sqrt(128), unit-RMS q / k rows as the
-    QK RMSNorm leaves them, softmax against a fixed zero offset.  Key counts that are multiples of 64 take the one-wave-per-SIMD
-    kernel (attention64.hip) — 1, 2, 3 tiles (prologue / tail paths only), 4-7 (one trip of the three-tile loop + 0-3 tail tiles),
-    11, 19 — the others the 8-wave kernel; both against the oracle's softmax on the un-scaled q (rel-L2 <= 1e-2), bit-reproducible,
-    and within bf16 rounding of the running-maximum path on the same operands."""
+    QK RMSNorm leaves them, softmax against a fixed zero offset: the one-wave-per-SIMD kernel (attention64b.hip) — 1, 2, 3 KV
+    tiles (prologue / tail paths only), 4-7 (one trip of the three-tile loop + 0-3 tail tiles), 11, 19, and key counts that are not
+    multiples of 64 (200, 1153: clamped K rows + masked row sums in the last tile) — against the oracle's softmax on the un-scaled
+    q (rel-L2 <= 1e-2), bit-reproducible, and within bf16 rounding of the running-maximum path (8-wave kernel) on the same operands."""
     import math
     g = torch.Generator().manual_seed(S * 7 + heads)
     d = heads * 128

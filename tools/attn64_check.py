@@ -8,7 +8,7 @@ import torch
 import flux2mi
 from flux2mi.api import Context
 
-SHAPES = [(64, 1), (128, 2), (192, 1), (256, 3), (704, 2), (768, 24), (4608, 24), (4608, 32), (8704, 24)]
+SHAPES = [(64, 1), (100, 2), (128, 2), (192, 1), (200, 3), (256, 3), (330, 1), (704, 2), (768, 24), (1153, 2), (4112, 24), (4608, 24), (4608, 32), (8704, 24)]
 
 
 def make(S, heads, seed):
