@@ -82,6 +82,51 @@ void run(const char* name, float* out, float* in, unsigned long long* st, int tr
            cyc / (h.size() / 2) / trips, cyc / rt * 100.0);
 }
 
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+// e4m3 operands through the block-scaled 16x16x128 form (unit scales): 4x the FLOPs of a 16x16x32 bf16 MFMA in twice its time
+__global__ __launch_bounds__(256, 1) void probe_fp8(float* out, const float* in, int trips, unsigned long long* stamps) {
+    const int t = threadIdx.x;
+    i32x8 a[4], b[4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 8; ++j) { a[i][j] = (int)(in[(t * 8 + j + i * 3) & 1023] * 100000.f) * 2654435 + t; b[i][j] = (int)(in[(t * 8 + j + i * 5 + 7) & 1023] * 100000.f) * 40503 + 7 * t; }
+    // keep the bytes finite e4m3 values: clear the exponent's top bit of every byte (|x| < 2)
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 8; ++j) { a[i][j] &= 0xBFBFBFBF; b[i][j] &= 0xBFBFBFBF; }
+    f32x4 acc[32];
+    for (int i = 0; i < 32; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    unsigned long long c0, r0, c1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0)::"memory");
+    for (int it = 0; it < trips; ++it) {
+#pragma unroll
+        for (int g = 0; g < 64; ++g)
+            acc[g & 31] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[g & 3], b[(g >> 2) & 3], acc[g & 31], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    }
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+    float l = 0.f;
+    for (int i = 0; i < 32; ++i) for (int r = 0; r < 4; ++r) l += acc[i][r];
+    out[blockIdx.x * 256 + t] = l;
+    if ((t & 63) == 0) { stamps[(blockIdx.x * 4 + (t >> 6)) * 2] = c1 - c0; stamps[(blockIdx.x * 4 + (t >> 6)) * 2 + 1] = r1 - r0; }
+}
+
+void run_fp8(float* out, float* in, unsigned long long* st, int trips, int blocks) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(probe_fp8, dim3(blocks), dim3(256), 0, 0, out, in, trips, st);
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(probe_fp8, dim3(blocks), dim3(256), 0, 0, out, in, trips, st);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(blocks * 8);
+    hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
+    double cyc = 0, rt = 0;
+    for (size_t i = 0; i < h.size() / 2; ++i) { cyc += h[2 * i]; rt += h[2 * i + 1]; }
+    const double flops = (double)blocks * 4 * trips * 64.0 * 2 * 16 * 16 * 128;
+    printf("%-34s %7.3f ms  %7.1f TF/s  %6.0f cycles per 64-MFMA trip (2048 = issue alone)  in-loop clock %5.0f MHz\n", "e4m3 16x16x128 (scaled form) alone", ms / reps,
+           flops * reps / ms / 1e9, cyc / (h.size() / 2) / trips, cyc / rt * 100.0);
+}
+
 int main() {
     const int blocks = 256, trips = 2000;
     float *in, *out; unsigned long long* st;
@@ -95,6 +140,7 @@ int main() {
         run<16, false>("16x16x32 alone", out, in, st, trips, blocks);
         run<32, true>("32x32x16 + softmax fillers", out, in, st, trips, blocks);
         run<16, true>("16x16x32 + softmax fillers", out, in, st, trips, blocks);
+        run_fp8(out, in, st, trips, blocks);
     }
     return 0;
 }

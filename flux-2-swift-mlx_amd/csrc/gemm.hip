@@ -298,6 +298,8 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
             if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.K % 128 != 0 || (p.lda & 15) || (p.ldw & 15) || !p.a_scale || !p.w_scale) return 1;
             if ((p.epi == EPI_SWIGLU || p.epi == EPI_QKV_MLP) && (p.N % 64 != 0 || p.n_split % 256 != 0)) return 1;
         }
+        // the one-wave-per-SIMD kernel (gemm256s.hip); FLUX2MI_GEMM_V with the dev library keeps the 8-wave fp8 kernel (A/B runs)
+        if (gemm256s_eligible(probs, nprob) && !F2_DEV_ENV("FLUX2MI_GEMM_V")) return launch_gemm256s(stream, probs, nprob);
         return launch_gemm256(stream, probs, nprob);
     }
     for (int i = 0; i < nprob; ++i) {
@@ -347,7 +349,7 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
             if (ver == 4) return launch_gemm256_r4(stream, probs, nprob);
             if (ver == 3) return launch_gemm256_w4(stream, probs, nprob);
 #endif
-            // bf16 operands: the one-wave-per-SIMD kernel (gemm256s.hip); fp8 and the strided-layout experiments: the 8-wave one.
+            // the one-wave-per-SIMD kernel (gemm256s.hip); the strided-layout experiments: the 8-wave one.
             // FLUX2MI_GEMM_V=2 with the dev library forces the 8-wave kernel (A/B runs)
             if (gemm256s_eligible(probs, nprob) && !F2_DEV_ENV("FLUX2MI_GEMM_V")) return launch_gemm256s(stream, probs, nprob);
             return launch_gemm256(stream, probs, nprob);

@@ -30,6 +30,7 @@
 // branch in an MFMA gap (measured: 2630 cycles per K-tile with them, 2180 without).
 #include "dev.h"
 #include "kernels.h"
+#include <type_traits>
 #include <utility>
 
 namespace {
@@ -92,6 +93,73 @@ struct Sched {
     static_assert(B1 < Q0 && B2 > B1 && RD1 + R <= T - 6 + 0 && spaced(), "schedule");
 };
 
+// FP8 (e4m3 operands, v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: 32 cycles each, a K-tile = 128 k = NI x 8 MFMAs).
+// A lane's operand is 32 bytes = its two 16-byte fragment reads, so the operands of a whole K-tile are (NI + 8) x 8 VGPRs and cannot be
+// double-buffered.  They are replaced IN PLACE as soon as their last MFMA has issued (an MFMA reads its sources while it issues; the
+// LDS data lands a read latency later):
+//   H0, gaps 0-31: rows 0-3 (column-major).  Gaps 0..2(NI-4)-1 read the A operands of rows 4.. of THIS tile <- stage u&1; B1 behind them
+//       (WAR: every wave has read all of the stage); the pieces of tile u+2 follow, spread to the end of the iteration
+//   H1, gaps 32..: rows 4.. COLUMN-major, so W operand j is free after its (NI-4) MFMAs and is re-read for tile u+1 right behind
+//       them; gap 32: vmcnt(c) + barrier B2 (RAW: tile u+1 has landed); gaps 33-40: the A operands of rows 0-3 of tile u+1
+//   top of the next iteration: a counted lgkmcnt — the youngest reads (W operands first used behind B1) may still be in flight
+template <int NI>
+struct SchedF {
+    static constexpr int G = NI * 8;                  // MFMAs (= 32-cycle gaps) per K-tile
+    static constexpr int H1N = NI - 4;                // rows of the second half
+    static constexpr int RA1 = 2 * H1N;               // reads of A rows 4.. (this tile), gaps 0..RA1-1
+    static constexpr int B1 = RA1 + 4;
+    static constexpr int B2 = 32;
+    static constexpr int RA0 = 33;                    // first of the 8 reads of the next tile's A rows 0-3
+    static constexpr int w_gap(int n) { return (n / 2 == 7) ? G - 1 : 32 + (n / 2 + 1) * H1N - 1 + (n % 2); }   // half n % 2 of W operand n / 2
+    static constexpr int NPA = NI <= 6 ? 6 : 8;
+    static constexpr int NP = NPA + 8;
+    static constexpr int Q0 = B1 + 2, Q1 = G - 2;
+    static constexpr int q_gap(int n) { return Q0 + (n * (Q1 - Q0) + (NP - 1) / 2) / (NP - 1); }
+    static constexpr int piece_at_q(int gap) {
+        for (int n = 0; n < NP; ++n)
+            if (q_gap(n) == gap) return n;
+        return -1;
+    }
+    static constexpr int piece_at_p(int gap) { return piece_at_q(gap + 1); }
+    static constexpr int before_b2() {
+        int c = 0;
+        for (int n = 0; n < NP; ++n) c += q_gap(n) < B2 ? 1 : 0;
+        return c;
+    }
+    static constexpr int a_j(int n) { return NPA == 8 ? n : n + (n >= 3 ? 1 : 0); }
+    static constexpr bool spaced() {
+        for (int n = 0; n + 1 < NP; ++n)
+            if (q_gap(n + 1) < q_gap(n) + 2) return false;
+        return true;
+    }
+    // The wait at the top of an iteration: how many of the previous iteration's next-tile reads, counted from the youngest, may still
+    // be in flight — those whose operand is first used behind B1 (which waits for everything).  Issue order inside a gap: A rows 0-3
+    // (RA0 + n), the NI = 5 leftovers, then W; A rows 0-3 are needed at gaps 0-3, W operand j at gap 4 j (MFMA 4 j issues BEFORE a
+    // filler of the same gap, so "behind B1" is strict).
+    static constexpr int a0_gap(int n) { return RA0 + n < G ? RA0 + n : G - 1; }
+    static constexpr int top_allow() {
+        int allow = 0;
+        // walk the 24 reads from the youngest: key = (gap, class, index); classes: 0 = A in its own gap, 1 = A leftover, 2 = W
+        bool used[24] = {};
+        for (int step = 0; step < 24; ++step) {
+            int best = -1, bg = -1, bc = -1, bi = -1;
+            for (int k = 0; k < 24; ++k) {
+                if (used[k]) continue;
+                const bool is_w = k >= 8;
+                const int g = is_w ? w_gap(k - 8) : a0_gap(k);
+                const int c = is_w ? 2 : (RA0 + k < G ? 0 : 1);
+                const int idx = is_w ? k - 8 : k;
+                if (g > bg || (g == bg && (c > bc || (c == bc && idx > bi)))) { best = k; bg = g; bc = c; bi = idx; }
+            }
+            used[best] = true;
+            const int need = best >= 8 ? 4 * ((best - 8) / 2) : 0;
+            if (need > B1) ++allow; else break;
+        }
+        return allow < 15 ? allow : 15;
+    }
+    static_assert(B1 < Q0 && B1 < B2 && RA1 <= 8 && spaced(), "fp8 schedule");
+};
+
 template <int I> using ic = std::integral_constant<int, I>;
 template <bool B> using bc = std::integral_constant<bool, B>;
 // f(ic<0>{}), f(ic<1>{}), ... in order
@@ -101,10 +169,11 @@ __device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, I...>)
 }
 #define GS_INLINE __attribute__((always_inline))
 
-template <int NI>
+template <int NI, bool FP8 = false>
 __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE];  // 128 KB, the only LDS object
-    using S = Sched<NI>;
+    using S = std::conditional_t<FP8, SchedF<NI>, Sched<NI>>;
+    constexpr int ES = FP8 ? 1 : 2;   // bytes per operand element: the byte geometry of a tile is the same (128-byte rows)
     constexpr int BMT = 32 * NI, WROWS = 16 * NI;
 
     const int bid = blockIdx.x;
@@ -130,15 +199,15 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
         for (int j = 0; j < 8; ++j) {
             const int r = j * 32 + wr8;
             const int arow = (r & 127) + (r >> 7) * WROWS;
-            voffA[j] = (uint32_t)(((size_t)min(m0 + arow, p.M - 1) * p.lda + chunk * 8) * 2);
-            voffW[j] = (uint32_t)(((size_t)min(n0 + r, p.N - 1) * p.ldw + chunk * 8) * 2);
+            voffA[j] = (uint32_t)(((size_t)min(m0 + arow, p.M - 1) * p.lda + chunk * (16 / ES)) * ES);
+            voffW[j] = (uint32_t)(((size_t)min(n0 + r, p.N - 1) * p.ldw + chunk * (16 / ES)) * ES);
         }
     }
     const uint8_t* gA = reinterpret_cast<const uint8_t*>(p.A);
     const uint8_t* gW = reinterpret_cast<const uint8_t*>(p.W);
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
     const uint32_t m0_wave = __builtin_amdgcn_readfirstlane(lds_base + wid * 1024);   // + j*4096 + part + stage
-    const int nk = p.K / 64;
+    const int nk = p.K / (FP8 ? 128 : 64);
 
     f32x4 acc[NI][8];
 #pragma unroll
@@ -180,6 +249,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
         else asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voffW[n - S::NPA]), "s"(sw_) : "memory");
     };
 
+    if constexpr (!FP8) {
     // ---- prologue: K-tiles 0 and 1 -> stages 0 and 1; K-step 0 of tile 0 -> (fa0, fb0)
     {
         auto fill_all = [&](uint32_t mm, const uint8_t* sa, const uint8_t* sw_) GS_INLINE {
@@ -236,14 +306,131 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     for (; u + 2 < nk; ++u) ktile(bc<true>{}, bc<true>{}, u);
     if (u + 1 < nk) { ktile(bc<false>{}, bc<true>{}, u); ++u; }
     ktile(bc<false>{}, bc<false>{}, u);
+    } else {
+    // ==== FP8 K loop (see SchedF)
+    typedef uint32_t gs_u32x8 __attribute__((ext_vector_type(8)));
+    gs_u32x8 wop[8], aop[NI];                       // 32-byte operands; .lo = chunk fq, .hi = chunk 4 + fq of the lane's row, each half written by its own
+                                                    // ds_read_b128 into the SAME register tuple
+    int unit_scale = 0x7F7F7F7F;                    // e8m0 127 = 1.0 in every byte; the real scales are per row / column, in the epilogue
+    asm volatile("" : "+v"(unit_scale));
+    {
+        auto fill_all = [&](uint32_t mm, const uint8_t* sa, const uint8_t* sw_) GS_INLINE {
+            for_seq([&](auto nc) GS_INLINE {
+                piece_p(nc, mm);
+                asm volatile("s_nop 0" ::: "memory");
+                piece_q(nc, sa, sw_);
+            }, std::make_integer_sequence<int, S::NP>{});
+        };
+        fill_all(m0_wave, gA, gW);
+        if (nk > 1) {
+            fill_all(m0_wave + (uint32_t)STAGE, gA + 128, gW + 128);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(S::NP) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");
+        const uint32_t hal = a_frag + ch0, hah = a_frag + ch1, hbl = b_frag + ch0, hbh = b_frag + ch1;
+        for_seq([&](auto ic_) GS_INLINE {
+            constexpr int i = decltype(ic_)::value;
+            (void)aop; (void)hal; (void)hah;
+            GS_DSR(aop[i].lo, hal, i * 2048);
+            GS_DSR(aop[i].hi, hah, i * 2048);
+        }, std::make_integer_sequence<int, 4>{});
+        for_seq([&](auto jc) GS_INLINE {
+            constexpr int j = decltype(jc)::value;
+            (void)wop; (void)hbl; (void)hbh;
+            GS_DSR(wop[j].lo, hbl, j * 2048);
+            GS_DSR(wop[j].hi, hbh, j * 2048);
+        }, std::make_integer_sequence<int, 8>{});
+    }
+    auto ktile8 = [&](auto is_c, auto rd_c, int u) GS_INLINE {
+        constexpr bool IS = decltype(is_c)::value, RD = decltype(rd_c)::value;
+        const uint32_t st_cur = (uint32_t)((u & 1) * STAGE), st_nxt = (uint32_t)(((u + 1) & 1) * STAGE);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(S::top_allow()) : "memory");   // the youngest reads belong to operands first used behind B1
+        const uint32_t hal = a_frag + st_cur + ch0, hah = a_frag + st_cur + ch1;                    // A rows 4.. of this tile
+        const uint32_t hal2 = a_frag + st_nxt + ch0, hah2 = a_frag + st_nxt + ch1;                  // next tile
+        const uint32_t hbl2 = b_frag + st_nxt + ch0, hbh2 = b_frag + st_nxt + ch1;
+        const uint32_t mm = m0_wave + st_cur;
+        const uint8_t* sa = gA + (size_t)(u + 2) * 128;
+        const uint8_t* sw_ = gW + (size_t)(u + 2) * 128;
+        auto gap = [&](auto gc) GS_INLINE {
+            constexpr int I = decltype(gc)::value;
+            (void)acc; (void)wop; (void)aop; (void)unit_scale; (void)hal; (void)hah; (void)hal2; (void)hah2; (void)hbl2; (void)hbh2;
+            (void)mm; (void)sa; (void)sw_;
+            // both halves column-major: W operand j is first needed at gap 4 j, i.e. the later it was re-read the later it is used
+            constexpr int i = I < 32 ? I % 4 : 4 + (I - 32) % S::H1N, j = I < 32 ? I / 4 : (I - 32) / S::H1N;
+            // W operand first: acc[i][j] rows = output columns j*16 + fq*4 + r, lanes = output rows i*16 + frow
+            asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[i][j]) : "v"(wop[j]), "v"(aop[i]), "v"(unit_scale));
+            if constexpr (I < S::RA1) {                      // A rows 4.. of this tile: operand 4 + I / 2, half I % 2
+                constexpr int ai = 4 + I / 2;
+                if constexpr (I % 2 == 0) GS_DSR(aop[ai].lo, hal, ai * 2048);
+                else GS_DSR(aop[ai].hi, hah, ai * 2048);
+            }
+            if constexpr (I == S::B1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (I == S::B2) {
+                if constexpr (IS) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(S::before_b2()) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            if constexpr (IS && S::piece_at_p(I) >= 0) piece_p(ic<S::piece_at_p(I)>{}, mm);
+            if constexpr (IS && S::piece_at_q(I) >= 0) piece_q(ic<S::piece_at_q(I)>{}, sa, sw_);
+            if constexpr (RD && I >= S::RA0 && I < S::RA0 + 8 && I < S::G) {   // the next tile's A rows 0-3 (free behind MFMA 31)
+                constexpr int n = I - S::RA0, ai = n / 2;
+                if constexpr (n % 2 == 0) GS_DSR(aop[ai].lo, hal2, ai * 2048);
+                else GS_DSR(aop[ai].hi, hah2, ai * 2048);
+            }
+            if constexpr (RD && I == S::G - 1 && S::RA0 + 8 > S::G) {          // NI = 5: the reads that did not fit behind gap 32
+                for_seq([&](auto nc) GS_INLINE {
+                    constexpr int n = S::G - S::RA0 + decltype(nc)::value, ai = n / 2;
+                    (void)aop; (void)hal2; (void)hah2;
+                    if constexpr (n % 2 == 0) GS_DSR(aop[ai].lo, hal2, ai * 2048);
+                    else GS_DSR(aop[ai].hi, hah2, ai * 2048);
+                }, std::make_integer_sequence<int, (S::RA0 + 8 > S::G ? S::RA0 + 8 - S::G : 0)>{});
+            }
+            if constexpr (RD) {   // the next tile's W operands, in place, behind the last MFMA of their column
+                for_seq([&](auto nc) GS_INLINE {
+                    constexpr int n = decltype(nc)::value, wj = n / 2;
+                    (void)wop; (void)hbl2; (void)hbh2;
+                    if constexpr (S::w_gap(n) == I) {
+                        if constexpr (n % 2 == 0) GS_DSR(wop[wj].lo, hbl2, wj * 2048);
+                        else GS_DSR(wop[wj].hi, hbh2, wj * 2048);
+                    }
+                }, std::make_integer_sequence<int, 16>{});
+            }
+        };
+        for_seq(gap, std::make_integer_sequence<int, S::G>{});
+    };
+    {
+        int u = 0;
+        for (; u + 2 < nk; ++u) ktile8(bc<true>{}, bc<true>{}, u);
+        if (u + 1 < nk) { ktile8(bc<false>{}, bc<true>{}, u); ++u; }
+        ktile8(bc<false>{}, bc<false>{}, u);
+    }
+    }
 #undef GS_DSR
     // MFMA result -> first non-MFMA reader: hipcc pads nothing behind inline asm (guide §5.7 item 2)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);   // the epilogue's address arithmetic stays behind the K loop (hoisted into the last K-tile it costs the
+                                         // registers the fp8 operands need: spills)
 
     // ---- epilogue (the code of gemm256.hip's, with a wave's 128 columns taken as two 64-column halves h = 0, 1:
     // its `wn` is wn*2 + h here and its acc[i][j] is acc[i][4h + j]).  Lane (frow, fq) holds, for output row
     // m0 + wm*WROWS + i*16 + frow, the FOUR CONSECUTIVE columns n0 + wn*128 + j*16 + fq*4 + r of block j = 0..7.
     const int row_base = m0 + wm * WROWS + frow;
+    if constexpr (FP8) {   // de-quantise: per-row activation scale x per-column weight scale, one column block at a time
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float w4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w4[r] = p.w_scale[min(n0 + wn * 128 + j * 16 + fq * 4 + r, p.N - 1)];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float as = p.a_scale[min(row_base + i * 16, p.M - 1)];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] *= as * w4[r];
+                asm volatile("" : "+a"(acc[i][j]));   // back into its AGPRs: 256 scaled values do not fit the VGPRs next to the epilogue's temporaries
+            }
+        }
+    }
     int epi = p.epi;
     if (epi == EPI_QKV_MLP) epi = (n0 >= p.n_split) ? EPI_SWIGLU : EPI_BF16;
     if (p.qk_qw != nullptr && epi == EPI_BF16 && n0 < p.qk_cols) {
@@ -501,11 +688,11 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
 
 int gemm256_pick_ni(const GemmProblem* probs, int nprob);   // gemm256.hip: tile height by wave quantisation
 
-// true when this kernel takes the launch: bf16 operands in plain row-major rows, 32-bit source offsets
+// true when this kernel takes the launch: bf16 or e4m3 operands in plain row-major rows, 32-bit source offsets
 bool gemm256s_eligible(const GemmProblem* probs, int nprob) {
     for (int i = 0; i < nprob; ++i) {
         const GemmProblem& q = probs[i];
-        if (q.fp8 || q.a_kstride || q.w_kstride || q.K % 64 != 0) return false;
+        if (q.a_kstride || q.w_kstride || q.K % (q.fp8 ? 128 : 64) != 0 || (q.fp8 != 0) != (probs[0].fp8 != 0)) return false;
         if ((unsigned long long)q.M * (unsigned long long)q.lda * 2 >= (1ull << 32) || (unsigned long long)q.N * (unsigned long long)q.ldw * 2 >= (1ull << 32)) return false;
     }
     return true;
@@ -531,6 +718,15 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
     b.flags = 1;   // 16-byte bf16 / SwiGLU epilogue stores
     b.trace = nullptr;
     const dim3 grid(tiles[0] + tiles[1]), block(256);
+    if (probs[0].fp8) {
+        switch (ni) {
+            case 7: hipLaunchKernelGGL((gemm256s_kernel<7, true>), grid, block, 0, stream, b); break;
+            case 6: hipLaunchKernelGGL((gemm256s_kernel<6, true>), grid, block, 0, stream, b); break;
+            case 5: hipLaunchKernelGGL((gemm256s_kernel<5, true>), grid, block, 0, stream, b); break;
+            default: hipLaunchKernelGGL((gemm256s_kernel<8, true>), grid, block, 0, stream, b); break;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
     switch (ni) {
         case 7: hipLaunchKernelGGL((gemm256s_kernel<7>), grid, block, 0, stream, b); break;
         case 6: hipLaunchKernelGGL((gemm256s_kernel<6>), grid, block, 0, stream, b); break;
