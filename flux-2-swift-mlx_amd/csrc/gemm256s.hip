@@ -30,8 +30,10 @@
 // branch in an MFMA gap (measured: 2630 cycles per K-tile with them, 2180 without).
 #include "dev.h"
 #include "kernels.h"
+#include <stdio.h>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 namespace {
 
@@ -249,6 +251,9 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
         else asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voffW[n - S::NPA]), "s"(sw_) : "memory");
     };
 
+    // dev diagnostic (batch.trace, FLUX2MI_GEMM_TRACE with the dev library): shader-clock and 100 MHz stamps around prologue + K loop
+    unsigned long long tr_c0 = 0, tr_r0 = 0;
+    if (batch.trace) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_c0), "=s"(tr_r0)::"memory");
     if constexpr (!FP8) {
     // ---- prologue: K-tiles 0 and 1 -> stages 0 and 1; K-step 0 of tile 0 -> (fa0, fb0)
     {
@@ -409,6 +414,14 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
 #undef GS_DSR
     // MFMA result -> first non-MFMA reader: hipcc pads nothing behind inline asm (guide §5.7 item 2)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    if (batch.trace) {
+        unsigned long long c1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+        if (lane == 0) {
+            unsigned long long* o = batch.trace + ((size_t)bid * 4 + wid) * 4;
+            o[0] = c1 - tr_c0; o[1] = r1 - tr_r0; o[2] = (unsigned long long)nk; o[3] = 0;
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);   // the epilogue's address arithmetic stays behind the K loop (hoisted into the last K-tile it costs the
                                          // registers the fp8 operands need: spills)
 
@@ -718,6 +731,24 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
     b.flags = 1;   // 16-byte bf16 / SwiGLU epilogue stores
     b.trace = nullptr;
     const dim3 grid(tiles[0] + tiles[1]), block(256);
+    static const char* trace_env = F2_DEV_ENV("FLUX2MI_GEMM_TRACE");
+    static int seen = 0;
+    const size_t tn = (size_t)grid.x * 16;
+    if (trace_env && ++seen % 16 == 0 && hipMalloc((void**)&b.trace, tn * 8) != hipSuccess) b.trace = nullptr;
+    struct TraceOut {
+        GemmBatch& b; hipStream_t stream; size_t tn; const GemmProblem* probs;
+        ~TraceOut() {
+            if (!b.trace) return;
+            std::vector<unsigned long long> h(tn);
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(h.data(), b.trace, tn * 8, hipMemcpyDeviceToHost);
+            (void)hipFree(b.trace);
+            double cyc = 0, rt = 0, kt = 0;
+            for (size_t w = 0; w < tn / 4; ++w) { cyc += (double)h[w * 4]; rt += (double)h[w * 4 + 1]; kt += (double)h[w * 4 + 2] + 1.5; }   // + prologue ~1.5 K-tiles
+            fprintf(stderr, "[gemm256s trace] M %d N %d K %d%s: %.0f shader cycles per K-tile (2048 = MFMA issue alone; prologue counted as 1.5), clock %.0f MHz, %.3f us per K-tile\n",
+                    probs[0].M, probs[0].N, probs[0].K, probs[0].fp8 ? " fp8" : "", cyc / kt, cyc / rt * 100.0, rt / kt * 0.01);
+        }
+    } trace_out{b, stream, tn, probs};
     if (probs[0].fp8) {
         switch (ni) {
             case 7: hipLaunchKernelGGL((gemm256s_kernel<7, true>), grid, block, 0, stream, b); break;
