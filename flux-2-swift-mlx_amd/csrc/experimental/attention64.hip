@@ -1,4 +1,5 @@
-// attention64.hip — flash-attention forward with ONE WAVE PER SIMD: workgroup = 4 waves = 256 query rows, 64 rows per wave,
+// attention64.hip — (dev library only: FLUX2MI_ATTN64=1; the product form is attention64b.hip on MFMA 16x16x32)
+// flash-attention forward with ONE WAVE PER SIMD on MFMA 32x32x16: workgroup = 4 waves = 256 query rows, 64 rows per wave,
 // KV tiles of 64 keys by LDS-DMA into 3-deep rings, the whole tile loop hand-placed (inline asm in issue order).
 //
 // Same operation, operand layouts and rounding points as attention.hip's attn_fwd_kernel<false, *, 2> (non-causal, the
@@ -19,8 +20,8 @@
 //   V^T fragments of tile i+1: gaps 50-63, 0, 1 (two gaps behind the last MFMA that reads the register)
 //   LDS-DMA: 8 pieces per wave and tile pair, spread over the iteration; barrier(i) at gap 32 behind vmcnt(8): K(i+2) and
 //   V(i+1), issued more than an iteration earlier, have landed in every wave; the 8 pieces of the current window stay in flight
-#include "dev.h"
-#include "kernels.h"
+#include "../dev.h"
+#include "../kernels.h"
 #include <stdio.h>
 #include <utility>
 #include <vector>

@@ -1,4 +1,6 @@
-// gemm256.hip — the large-tile bf16 GEMM: 256x256x64 tile, 8 waves, LDS-DMA staging that
+// gemm256.hip — the 8-WAVE large-tile GEMM of round 1 / early round 2 (bf16 and fp8): superseded by gemm256s.hip (one wave per SIMD) and
+// built only into libflux2mi_dev.so (FLUX2MI_GEMM_V=2: A/B runs; the strided-operand layout experiments).
+// 256x256x64 tile, 8 waves, LDS-DMA staging that
 // stays in flight across barriers (counted vmcnt), 4 MFMA phases per K-tile.
 //
 // Same contract and epilogues as gemm.hip (C = A W^T, W [out,in]); used for the DiT's large
@@ -23,8 +25,8 @@
 //     raw s_barrier make element phi + 2 — exactly what phase phi + 1 reads — visible.
 //     WAR: a slot is re-filled at least one barrier after the phase that read it.
 //     The last two K-tiles wait vmcnt(0) (nothing younger is issued any more).
-#include "dev.h"
-#include "kernels.h"
+#include "../dev.h"
+#include "../kernels.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -758,24 +760,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmBatch bat
 
 }  // namespace
 
-// Tile height by wave quantisation (both 256x256 kernels): rounds of 256 workgroups x relative tile cost (+2 % per row block
-// dropped for the lower arithmetic intensity); ties keep the taller tile.  FLUX2MI_GEMM_NI=8 forces 256 rows (dev A/B runs).
-int gemm256_pick_ni(const GemmProblem* probs, int nprob) {
-    static const int ni_force = [] {
-        const char* e = F2_DEV_ENV("FLUX2MI_GEMM_NI");
-        return e ? atoi(e) : 0;
-    }();
-    if (ni_force >= 5 && ni_force <= 8) return ni_force;
-    int ni = 8;
-    double best = 1e30;
-    for (int c = 8; c >= 5; --c) {
-        int tot = 0;
-        for (int i = 0; i < nprob; ++i) tot += ((probs[i].M + 32 * c - 1) / (32 * c)) * ((probs[i].N + 255) / 256);
-        const double cost = (double)((tot + 255) / 256) * (c / 8.0) * (1.0 + 0.02 * (8 - c));
-        if (cost < best * 0.97) { best = cost; ni = c; }   // a shorter tile must win by 3 %
-    }
-    return ni;
-}
+int gemm256_pick_ni(const GemmProblem* probs, int nprob);   // gemm256s.hip
 
 // returns 0 ok / 2 launch error; the caller has validated the problems
 int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob) {

@@ -28,7 +28,9 @@
 #include "kernels.h"
 #include <stdlib.h>
 
-int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob);
+#ifdef FLUX2MI_DEV
+int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob);   // experimental/gemm256.hip: the 8-wave kernel
+#endif
 int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob);
 bool gemm256s_eligible(const GemmProblem* probs, int nprob);
 int launch_gemm256_w4(hipStream_t stream, const GemmProblem* probs, int nprob);
@@ -299,8 +301,10 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
             if ((p.epi == EPI_SWIGLU || p.epi == EPI_QKV_MLP) && (p.N % 64 != 0 || p.n_split % 256 != 0)) return 1;
         }
         // the one-wave-per-SIMD kernel (gemm256s.hip); FLUX2MI_GEMM_V with the dev library keeps the 8-wave fp8 kernel (A/B runs)
-        if (gemm256s_eligible(probs, nprob) && !F2_DEV_ENV("FLUX2MI_GEMM_V")) return launch_gemm256s(stream, probs, nprob);
-        return launch_gemm256(stream, probs, nprob);
+#ifdef FLUX2MI_DEV
+        if (F2_DEV_ENV("FLUX2MI_GEMM_V")) return launch_gemm256(stream, probs, nprob);
+#endif
+        return gemm256s_eligible(probs, nprob) ? launch_gemm256s(stream, probs, nprob) : 1;
     }
     for (int i = 0; i < nprob; ++i) {
         const GemmProblem& p = probs[i];
@@ -351,8 +355,11 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
 #endif
             // the one-wave-per-SIMD kernel (gemm256s.hip); the strided-layout experiments: the 8-wave one.
             // FLUX2MI_GEMM_V=2 with the dev library forces the 8-wave kernel (A/B runs)
-            if (gemm256s_eligible(probs, nprob) && !F2_DEV_ENV("FLUX2MI_GEMM_V")) return launch_gemm256s(stream, probs, nprob);
-            return launch_gemm256(stream, probs, nprob);
+#ifdef FLUX2MI_DEV
+            if (F2_DEV_ENV("FLUX2MI_GEMM_V") || !gemm256s_eligible(probs, nprob)) return launch_gemm256(stream, probs, nprob);
+#endif
+            if (gemm256s_eligible(probs, nprob)) return launch_gemm256s(stream, probs, nprob);
+            if (fused_qk) return 1;   // source offsets beyond 32 bits: only the 128x128 kernel below, which has no fused epilogue
         }
     }
     GemmBatch b;

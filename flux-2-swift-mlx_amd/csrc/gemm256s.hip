@@ -1,8 +1,8 @@
 // gemm256s.hip — the large-tile bf16 GEMM with ONE WAVE PER SIMD: 256x256x64 tile, 4 waves of 128x128, the accumulators
 // in AGPRs, operands by LDS-DMA, every instruction of the K loop hand-placed (inline asm in issue order).
 //
-// Same contract, tile order and epilogues as gemm256.hip (C = A W^T, W [out,in]); it replaces that 8-wave kernel for the
-// bf16 problems (the fp8 instantiation stays there).  Why (measured, profiles/r02_f_*): per K-tile the 8-wave form reads
+// Same contract, tile order and epilogues as the 8-wave kernel it replaces (csrc/experimental/gemm256.hip, dev library only):
+// C = A W^T, W [out,in], bf16 or e4m3 (FP8 instantiation) operands.  Why (measured, profiles/r02_f_*): per K-tile the 8-wave form reads
 // 192 KB of fragments from LDS and crosses 8 barriers; with 128x128 wave tiles it is 128 KB and 2 barriers, and with one
 // wave per SIMD the MFMAs issue back to back (16 cycles each) with the auxiliary instructions in the gaps: 2180-2290
 // shader cycles per 64-deep K-tile against 2048 of pure MFMA issue, where the 8-wave kernel needs 2650.
@@ -31,6 +31,7 @@
 #include "dev.h"
 #include "kernels.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -699,7 +700,25 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
 
 }  // namespace
 
-int gemm256_pick_ni(const GemmProblem* probs, int nprob);   // gemm256.hip: tile height by wave quantisation
+// Tile height by wave quantisation (256x256 kernels): rounds of 256 workgroups x relative tile cost (+2 % per row block
+// dropped for the lower arithmetic intensity); ties keep the taller tile.  FLUX2MI_GEMM_NI=8 forces 256 rows (dev A/B runs).
+int gemm256_pick_ni(const GemmProblem* probs, int nprob) {
+    static const int ni_force = [] {
+        const char* e = F2_DEV_ENV("FLUX2MI_GEMM_NI");
+        return e ? atoi(e) : 0;
+    }();
+    if (ni_force >= 5 && ni_force <= 8) return ni_force;
+    int ni = 8;
+    double best = 1e30;
+    for (int c = 8; c >= 5; --c) {
+        int tot = 0;
+        for (int i = 0; i < nprob; ++i) tot += ((probs[i].M + 32 * c - 1) / (32 * c)) * ((probs[i].N + 255) / 256);
+        const double cost = (double)((tot + 255) / 256) * (c / 8.0) * (1.0 + 0.02 * (8 - c));
+        if (cost < best * 0.97) { best = cost; ni = c; }   // a shorter tile must win by 3 %
+    }
+    return ni;
+}
+
 
 // true when this kernel takes the launch: bf16 or e4m3 operands in plain row-major rows, 32-bit source offsets
 bool gemm256s_eligible(const GemmProblem* probs, int nprob) {
