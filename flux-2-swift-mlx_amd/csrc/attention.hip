@@ -472,13 +472,15 @@ int launch_attention64(hipStream_t stream, const uint16_t* q, const uint16_t* k,
 int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
                         int ldo, int Sq, int S, int heads);  // attention64b.hip (MFMA 16x16x32)
 
-// p >= 2^(-2 bound): 2 * 40 stays far inside the f32 / bf16 exponent range
-bool attention_uses_fixed_offset(float score_bound_log2) {
+// Offset = the bound (scores not pre-scaled): p in [2^(-2 bound), 1], bound <= 40 keeps 2^-80 far inside the f32 / bf16 exponent range.
+// Offset = 0 on pre-scaled q (the model's form): p in [2^-bound, 2^bound]; with bound <= 80 a row sum stays below 2^80 S and an
+// accumulator below 2^80 S max|v| (< 2^100 for S < 2^13, |v| < 2^7), a row of all-minimal scores still sums to a normal 2^-80 S.
+bool attention_uses_fixed_offset(float score_bound_log2, bool q_prescaled) {
     static const int fixm_on = [] {   // FLUX2MI_ATTN_FIXM=0 keeps the running maximum everywhere (dev A/B runs)
         const char* e = F2_DEV_ENV("FLUX2MI_ATTN_FIXM");
         return e ? atoi(e) : 1;
     }();
-    return fixm_on && score_bound_log2 > 0.f && score_bound_log2 <= 40.f;
+    return fixm_on && score_bound_log2 > 0.f && score_bound_log2 <= (q_prescaled ? 80.f : 40.f);
 }
 
 // 2 partial slots per piece; <= n_cu pieces of 66 x 512 floats (8-wave workgroups) or <= 2 n_cu pieces of 66 x 256 (4-wave)
@@ -496,7 +498,7 @@ int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, i
     // 8-wave workgroups (one per CU) when the 4-wave grid would be under two full rounds of the 512
     // workgroup slots (Klein-4B: 864): +0.6 % on the step; 4-wave ones are faster on larger grids
     const int nw = nw_env ? nw_env : (((long)((Sq + 127) / 128) * heads < 1024 && Sq >= 1024) ? 8 : 4);
-    const bool fixm = attention_uses_fixed_offset(score_bound_log2);
+    const bool fixm = attention_uses_fixed_offset(score_bound_log2, q_prescaled);
     const int fx = fixm ? (q_prescaled ? 2 : 1) : 0;
     const int qblocks = (Sq + nw * 32 - 1) / (nw * 32);
 #ifdef FLUX2MI_DEV

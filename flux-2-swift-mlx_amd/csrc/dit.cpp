@@ -1103,7 +1103,7 @@ extern "C" int flux2mi_dit_attention_softmax_info(const flux2mi_dit* m, int* n_f
     F2_REQUIRE(m && n_fixed_offset && n_online, FLUX2MI_ERR_INVALID_ARG, "dit_attention_softmax_info: NULL argument");
     F2_REQUIRE(m->finalized, FLUX2MI_ERR_NOT_LOADED, "dit_attention_softmax_info: weights not finalized");
     int fx = 0, on = 0;
-    auto count = [&](float bound) { (m->attn_softmax_mode == 0 && attention_uses_fixed_offset(bound) ? fx : on) += 1; };
+    auto count = [&](float bound) { (m->attn_softmax_mode == 0 && attention_uses_fixed_offset(bound, true) ? fx : on) += 1; };
     for (const auto& b : m->dbl) count(b.score_bound);
     for (const auto& b : m->sgl) count(b.score_bound);
     *n_fixed_offset = fx;
@@ -1266,7 +1266,7 @@ extern "C" int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv_in, void* 
 
 // The form the model's blocks run (dit.cpp attention_block): q arrives multiplied by log2(e)/sqrt(128) (the norm + RoPE step folds
 // it in before q's one rounding to bf16) and |q.k| <= score_bound_log2 in that domain, so the softmax may use a fixed zero offset
-// (attention.hip / attention64.hip).  score_bound_log2 <= 0 or > 40 falls back to the running maximum on the pre-scaled q.
+// (attention.hip / attention64.hip).  score_bound_log2 <= 0 or > 80 falls back to the running maximum on the pre-scaled q.
 extern "C" int flux2mi_op_attention_prescaled(flux2mi_ctx* ctx, const void* qkv_in, void* out, int S, int heads, float score_bound_log2) {
     F2_REQUIRE(ctx && qkv_in && out && S > 0 && heads > 0, FLUX2MI_ERR_INVALID_ARG, "op_attention_prescaled: bad argument");
     const int d = heads * 128, s_pad = attn_s_pad(S);

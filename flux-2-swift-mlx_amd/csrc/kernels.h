@@ -78,12 +78,12 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob);
 // the KV-cache paths launch it per query range, and with S = the key prefix a range may see).
 // score_bound_log2 > 0: the caller guarantees |q.k| / sqrt(128) * log2(e) <= score_bound_log2 for every
 // query/key pair (q, k out of the per-head RMSNorm); the softmax then uses it as a fixed offset instead
-// of tracking row maxima (used when <= 40).  0 = no bound known.
+// of tracking row maxima (used when <= 40, or <= 80 with q_prescaled).  0 = no bound known.
 // q_prescaled: Q already carries the factor log2(e)/sqrt(128) (launch_qk_norm_rope_vt's q_mul), so the scores
 // come out of the MFMA in the log2 domain; with a bound the offset is then taken as ZERO and p = exp2(s)
-// needs no multiply-add at all (p in [2^-40, 2^40]: far inside f32 / bf16 range, any offset cancels in O / l).
+// needs no multiply-add at all (p in [2^-80, 2^80]: inside f32 / bf16 range with room for the sums, any offset cancels in O / l).
 // true when launch_attention takes the fixed-offset softmax for this score bound (log2 domain; 0 = no bound known)
-bool attention_uses_fixed_offset(float score_bound_log2);
+bool attention_uses_fixed_offset(float score_bound_log2, bool q_prescaled = true);
 // split_ws (optional, attention_split_ws_bytes(n_cu) bytes, n_cu = the device's CU count): lets the launcher cut the items of
 // a partial last round along the keys into equal pieces, one per free workgroup slot (attention.hip, AttnSplit).
 size_t attention_split_ws_bytes(int n_cu);

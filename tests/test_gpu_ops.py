@@ -407,3 +407,29 @@ def test_attention_prescaled_fixed_offset(ctx, S, heads):
     assert torch.equal(out, ctx.op_attention_prescaled(qkv.cuda(), heads, bound))
     online = ctx.op_attention_prescaled(qkv.cuda(), heads, 0.0)    # no bound: running maximum on the same pre-scaled q
     assert rel_l2(out, online.float()) < 6e-3
+
+
+def test_attention_prescaled_large_scores(ctx):
+    """Scores near the upper end of the fixed-offset range (|s| up to ~70 in the log2 domain, bound 75 <= 80): p = exp2(s) spans
+    2^-70 .. 2^70 across rows, the softmax is nearly one-hot — still the oracle's result, finite, on the one-wave-per-SIMD kernel."""
+    import math
+    S, heads = 704, 2
+    g = torch.Generator().manual_seed(11)
+    d = heads * 128
+    x = torch.randn((S, 3 * d), generator=g)
+    q = x[:, :d].view(S, heads, 128)
+    k = x[:, d:2 * d].view(S, heads, 128)
+    q = q / q.pow(2).mean(-1, keepdim=True).sqrt()
+    k = k / k.pow(2).mean(-1, keepdim=True).sqrt()
+    k[::7] = q[::7] * 4.4              # aligned keys: q.k / sqrt(128) * log2(e) = 128 * 4.4 * 0.1275 = 71.8
+    k[3::7] = -q[3::7] * 4.4           # and anti-aligned ones
+    c = math.log2(math.e) / math.sqrt(128.0)
+    qkv = torch.cat([(q * c).reshape(S, d), k.reshape(S, d), x[:, 2 * d:]], dim=1).to(torch.bfloat16)
+    out = ctx.op_attention_prescaled(qkv.cuda(), heads, 75.0)
+    qs, ks, vs = qkv.float().split(d, dim=1)
+    smax = float((qs.view(S, heads, 128).permute(1, 0, 2) @ ks.view(S, heads, 128).permute(1, 2, 0)).abs().max())
+    assert 60.0 < smax <= 75.0, smax
+    hv = lambda t: t.reshape(1, S, heads, 128).permute(0, 2, 1, 3)
+    ref = R.sdpa(hv(qs / c), hv(ks), hv(vs)).permute(0, 2, 1, 3).reshape(S, d)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 1e-2
