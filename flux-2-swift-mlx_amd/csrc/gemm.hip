@@ -33,10 +33,7 @@ int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob);   /
 #endif
 int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob);
 bool gemm256s_eligible(const GemmProblem* probs, int nprob);
-int launch_gemm256_w4(hipStream_t stream, const GemmProblem* probs, int nprob);
-int launch_gemm256_r4(hipStream_t stream, const GemmProblem* probs, int nprob);
 #ifdef FLUX2MI_DEV
-int launch_gemm_ws(hipStream_t stream, const GemmProblem* probs, int nprob);
 int launch_gemm256_g4(hipStream_t stream, const GemmProblem* probs, int nprob);
 #endif
 
@@ -349,9 +346,6 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
                 for (int i = 0; i < nprob; ++i) ok = ok && !probs[i].fp8 && (probs[i].epi == EPI_F32 || probs[i].epi == EPI_GATE_RESID || (probs[i].epi == EPI_BF16 && !probs[i].qk_qw && !probs[i].col_perm16)) && !probs[i].a_kstride && !probs[i].w_kstride;
                 if (ok) return launch_gemm256_g4(stream, probs, nprob);
             }
-            if (ver == 5) return launch_gemm_ws(stream, probs, nprob);
-            if (ver == 4) return launch_gemm256_r4(stream, probs, nprob);
-            if (ver == 3) return launch_gemm256_w4(stream, probs, nprob);
 #endif
             // the one-wave-per-SIMD kernel (gemm256s.hip); the strided-layout experiments: the 8-wave one.
             // FLUX2MI_GEMM_V=2 with the dev library forces the 8-wave kernel (A/B runs)
