@@ -430,21 +430,23 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     // its `wn` is wn*2 + h here and its acc[i][j] is acc[i][4h + j]).  Lane (frow, fq) holds, for output row
     // m0 + wm*WROWS + i*16 + frow, the FOUR CONSECUTIVE columns n0 + wn*128 + j*16 + fq*4 + r of block j = 0..7.
     const int row_base = m0 + wm * WROWS + frow;
-    if constexpr (FP8) {   // de-quantise: per-row activation scale x per-column weight scale, one column block at a time
+    // FP8: de-quantise at the point of use (per-row activation scale x per-column weight scale).  The accumulators are never rewritten:
+    // a pass that scales them in place needs new AGPRs while the old values are live, and hipcc then spills accumulators right behind
+    // the asm MFMA that produced them — a store of a register whose MFMA is still in flight.
+    float fs_row[NI];
+    f32x4 fs_col[8];
+    if constexpr (FP8) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float w4[4];
+        for (int i = 0; i < NI; ++i) fs_row[i] = p.a_scale[min(row_base + i * 16, p.M - 1)];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) w4[r] = p.w_scale[min(n0 + wn * 128 + j * 16 + fq * 4 + r, p.N - 1)];
+        for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const float as = p.a_scale[min(row_base + i * 16, p.M - 1)];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] *= as * w4[r];
-                asm volatile("" : "+a"(acc[i][j]));   // back into its AGPRs: 256 scaled values do not fit the VGPRs next to the epilogue's temporaries
-            }
-        }
+            for (int r = 0; r < 4; ++r) fs_col[j][r] = p.w_scale[min(n0 + wn * 128 + j * 16 + fq * 4 + r, p.N - 1)];
     }
+    auto accv = [&](int i, int j) GS_INLINE -> f32x4 {
+        if constexpr (FP8) return acc[i][j] * (fs_col[j] * fs_row[i]);
+        else return acc[i][j];
+    };
     int epi = p.epi;
     if (epi == EPI_QKV_MLP) epi = (n0 >= p.n_split) ? EPI_SWIGLU : EPI_BF16;
     if (p.qk_qw != nullptr && epi == EPI_BF16 && n0 < p.qk_cols) {
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t2 += acc[i][j][r] * acc[i][j][r];
+                for (int r = 0; r < 4; ++r) t2 += accv(i, j)[r] * accv(i, j)[r];
             t2 += __shfl_xor(t2, 16);
             t2 += __shfl_xor(t2, 32);
             const float rinv = rsqrtf(t2 * (1.0f / 128.0f) + 1e-6f);
@@ -484,8 +486,8 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                 const float f0 = __builtin_amdgcn_fractf(pos * wrev[j & 1][0]), f1 = __builtin_amdgcn_fractf(pos * wrev[j & 1][1]);
                 const float c0 = __builtin_amdgcn_cosf(f0), s0 = __builtin_amdgcn_sinf(f0);
                 const float c1 = __builtin_amdgcn_cosf(f1), s1 = __builtin_amdgcn_sinf(f1);
-                const float a0 = acc[i][j][0] * rinv * w0, a1 = acc[i][j][1] * rinv * w1;
-                const float a2 = acc[i][j][2] * rinv * w2, a3 = acc[i][j][3] * rinv * w3;
+                const float a0 = accv(i, j)[0] * rinv * w0, a1 = accv(i, j)[1] * rinv * w1;
+                const float a2 = accv(i, j)[2] * rinv * w2, a3 = accv(i, j)[3] * rinv * w3;
                 pk[j][0] = pack_bf16x2(a0 * c0 - a1 * s0, a1 * c0 + a0 * s0);
                 pk[j][1] = pack_bf16x2(a2 * c1 - a3 * s1, a3 * c1 + a2 * s1);
             }
@@ -517,11 +519,11 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                         const int col = col_base + j * 16;
                         float* dst = C + (size_t)row * p.ldc + col;
                         if (vec_ok && col + 3 < p.N) {
-                            *reinterpret_cast<f32x4*>(dst) = acc[i][4 * h + j] * p.alpha;
+                            *reinterpret_cast<f32x4*>(dst) = accv(i, 4 * h + j) * p.alpha;
                         } else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                if (col + r < p.N) dst[r] = acc[i][4 * h + j][r] * p.alpha;
+                                if (col + r < p.N) dst[r] = accv(i, 4 * h + j)[r] * p.alpha;
                         }
                     }
                 }
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                     const int row = row_base + i * 16;
 #pragma unroll
                     for (int jp = 0; jp < 2; ++jp) {
-                        const f32x4 vx = acc[i][4 * h + 2 * jp] * p.alpha, vy = acc[i][4 * h + 2 * jp + 1] * p.alpha;
+                        const f32x4 vx = accv(i, 4 * h + 2 * jp) * p.alpha, vy = accv(i, 4 * h + 2 * jp + 1) * p.alpha;
                         uint32_t x0 = pack_bf16x2(vx[0], vx[1]), x1 = pack_bf16x2(vx[2], vx[3]);
                         uint32_t y0 = pack_bf16x2(vy[0], vy[1]), y1 = pack_bf16x2(vy[2], vy[3]);
                         if (p.col_perm16) {
@@ -566,7 +568,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                         const int col = col_base + j * 16;
                         const int scol = p.col_perm16 ? n0 + wnv * 64 + j * 16 + ((fq & 1) * 2 + (fq >> 1)) * 4 : col;
                         uint16_t* dst = C + (size_t)row * p.ldc + scol;
-                        const f32x4 v = acc[i][4 * h + j] * p.alpha;
+                        const f32x4 v = accv(i, 4 * h + j) * p.alpha;
                         if (vec_ok && col + 3 < p.N) {
                             *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                         } else {
@@ -598,11 +600,11 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                         float* dst = C + (size_t)row * p.ldc + col;
                         if (vec_ok && col + 3 < p.N) {
                             f32x4* d4 = reinterpret_cast<f32x4*>(dst);
-                            *d4 = *d4 + g[j] * acc[i][4 * h + j];
+                            *d4 = *d4 + g[j] * accv(i, 4 * h + j);
                         } else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                if (col + r < p.N) dst[r] = dst[r] + g[j][r] * acc[i][4 * h + j][r];
+                                if (col + r < p.N) dst[r] = dst[r] + g[j][r] * accv(i, 4 * h + j)[r];
                         }
                     }
                 }
@@ -623,8 +625,8 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                     float ox[4], oy[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        ox[r] = silu_f(acc[i][4 * h + 0][r]) * acc[i][4 * h + 2][r];
-                        oy[r] = silu_f(acc[i][4 * h + 1][r]) * acc[i][4 * h + 3][r];
+                        ox[r] = silu_f(accv(i, 4 * h + 0)[r]) * accv(i, 4 * h + 2)[r];
+                        oy[r] = silu_f(accv(i, 4 * h + 1)[r]) * accv(i, 4 * h + 3)[r];
                     }
                     uint32_t x0 = pack_bf16x2(ox[0], ox[1]), x1 = pack_bf16x2(ox[2], ox[3]);
                     uint32_t y0 = pack_bf16x2(oy[0], oy[1]), y1 = pack_bf16x2(oy[2], oy[3]);
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                         uint16_t* dst = C + (size_t)row * p.ldc2 + hh;
                         float o[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = silu_f(acc[i][4 * h + j][r]) * acc[i][4 * h + j + 2][r];
+                        for (int r = 0; r < 4; ++r) o[r] = silu_f(accv(i, 4 * h + j)[r]) * accv(i, 4 * h + j + 2)[r];
                         if (vec_ok && hh + 3 < hidden) {
                             *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
                         } else {
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                     for (int j = 0; j < 4; ++j) {
                         const int col = col_base + j * 16;
                         uint16_t* dst = C + (size_t)row * p.ldc + col;
-                        f32x4 v = acc[i][4 * h + j] * p.alpha + bsv[j];
+                        f32x4 v = accv(i, 4 * h + j) * p.alpha + bsv[j];
                         if (vec_ok && col + 3 < p.N) {
                             if (p.resid) {
                                 const uint2 rv = *reinterpret_cast<const uint2*>(p.resid + (size_t)row * p.ldr + col);
