@@ -50,8 +50,9 @@ def parse_args(argv=None):
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
                     help="transformer block-GEMM format; the headline (BASELINE.json configs[1]) is bf16")
     ap.add_argument("--attn-softmax", default="auto", choices=["auto", "online"],
-                    help="auto: fixed-offset softmax where the QK-RMSNorm weights bound the scores, running maximum "
-                         "otherwise (what a checkpoint with larger norm scales gets); online: force the running maximum")
+                    help="auto: fixed zero softmax offset where the QK-RMSNorm weights bound the scores, a per-query data "
+                         "offset otherwise (what a checkpoint with larger norm scales gets: exact for any scores); "
+                         "online: force the data-offset form in every block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-class", type=int, default=0, help="kernel class timed with HIP events (0 = linear1 GEMM)")
     ap.add_argument("--dry-run", action="store_true", help="harness self-test on CPU/gloo: no GPU, no compute")

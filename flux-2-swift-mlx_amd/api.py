@@ -286,9 +286,9 @@ class Context:
 
     PROF_KERNELS = {
         0: "gemm256s_kernel (single_blocks.linear1: [S,d] x [9d,d]^T as two launches: [q|k] with fused RMSNorm+RoPE "
-           "+ SwiGLU rows, and V^T = W_v x^T; fp8 weights: gemm_bf16_256x256_kernel<FP8>)",
-        1: "gemm256s_kernel / gemm_bf16_256x256_kernel<FP8> / gemm_bf16_128x128_kernel (every DiT GEMM)",
-        2: "attn64_kernel / attn_fwd_kernel (joint attention)",
+           "+ SwiGLU rows, and V^T = W_v x^T; fp8 weights: gemm256s_kernel<NI, FP8>)",
+        1: "gemm256s_kernel (bf16 / fp8) / gemm_bf16_128x128_kernel (every DiT GEMM)",
+        2: "attn64b_kernel (fixed / per-query data offset) / attn_fwd_kernel (joint attention)",
         3: "conv2d_g128_kernel / conv2d_kernel (VAE convolutions)",
     }
 
@@ -628,8 +628,8 @@ class DiT:
         return int(lib().flux2mi_dit_param_bytes(self.handle))
 
     def set_attention_softmax(self, mode: str):
-        """"auto": fixed-offset softmax in the blocks whose QK-RMSNorm weights bound the scores; "online": running maximum
-        everywhere (what blocks with larger norm scales get anyway)."""
+        """"auto": fixed-offset softmax in the blocks whose QK-RMSNorm weights bound the scores; "online": no bound assumed
+        anywhere — the per-query data-offset form of the same kernel (what blocks with larger norm scales get anyway)."""
         check(lib().flux2mi_dit_set_attention_softmax(self.handle, {"auto": 0, "online": 1}[mode]))
         return self
 

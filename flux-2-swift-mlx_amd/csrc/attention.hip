@@ -470,7 +470,7 @@ __global__ __launch_bounds__(NW * 64) void attn_combine_kernel(uint16_t* __restr
 int launch_attention64(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
                        int ldo, int Sq, int S, int heads);   // experimental/attention64.hip (MFMA 32x32x16; dev library only)
 int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
-                        int ldo, int Sq, int S, int heads);  // attention64b.hip (MFMA 16x16x32)
+                        int ldo, int Sq, int S, int heads, bool data_offset);  // attention64b.hip (MFMA 16x16x32)
 
 // Offset = the bound (scores not pre-scaled): p in [2^(-2 bound), 1], bound <= 40 keeps 2^-80 far inside the f32 / bf16 exponent range.
 // Offset = 0 on pre-scaled q (the model's form): p in [2^-bound, 2^bound]; with bound <= 80 a row sum stays below 2^80 S and an
@@ -534,16 +534,17 @@ int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, i
     }
 #endif
     (void)split_ws; (void)n_cu;
-    // the fixed-offset form on pre-scaled Q with whole KV tiles: the one-wave-per-SIMD kernel (attention64.hip).
+    // pre-scaled Q (the model's form): the one-wave-per-SIMD kernel (attention64b.hip), with the fixed zero offset when the score
+    // bound allows it and with its per-query data offset otherwise (the "online" count of flux2mi_dit_attention_softmax_info).
     // FLUX2MI_ATTN64=0 with the dev library keeps the kernel below (A/B runs)
-    if (fx == 2 && !nw_env) {
+    if (q_prescaled && fx != 1 && !nw_env) {
         static const int a64 = [] { const char* e = F2_DEV_ENV("FLUX2MI_ATTN64"); return e ? atoi(e) : 2; }();   // dev: 0 = the kernel below, 1 = the 32x32x16 form
         if (a64 != 0) {
 #ifdef FLUX2MI_DEV
-            const int r64 = a64 == 1 ? launch_attention64(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads)
-                                     : launch_attention64b(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads);
+            const int r64 = (a64 == 1 && fx == 2) ? launch_attention64(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads)
+                                                  : launch_attention64b(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads, fx != 2);
 #else
-            const int r64 = launch_attention64b(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads);
+            const int r64 = launch_attention64b(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads, fx != 2);
 #endif
             if (r64 != 1) return r64;
         }

@@ -43,7 +43,7 @@ __device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, I...>)
     (f(ic<I>{}), ...);
 }
 #define B64_INLINE __attribute__((always_inline))
-#define B64_USE (void)o; (void)s; (void)p; (void)kf; (void)vf; (void)qf; (void)lacc; (void)ones; (void)ones_last; (void)kfa; (void)vfa;
+#define B64_USE (void)o; (void)s; (void)p; (void)kf; (void)vf; (void)qf; (void)lacc; (void)ones; (void)ones_last; (void)kfa; (void)vfa; (void)negm;
 
 // ---- the schedule (gap = the slot behind MFMA number g of the iteration; >= T: the same slot of the NEXT iteration)
 // softmax element e of a half (query blocks 2H, 2H+1): e = st*16 + qh*8 + u*4 + r -> s[2 st + u][2H + qh][r]; pack c = e / 2
@@ -61,10 +61,19 @@ constexpr int kimm(int n) { return ((n % 4) / 2) * 8192 + ((n % 4) % 2) * 2048; 
 constexpr int vimm(int n) { return (n % 8) * 2048; }                                // d block n % 8
 static_assert(x1_gap(31) == T + 24 && c1_gap(15) == T + 31 && vr_gap(15) == 135 && kr_gap(15) == 95 && c0_gap(15) == 131, "schedule");
 
+// DOFF = false: p = 2^s (the caller guarantees |s| <= 80: attention_uses_fixed_offset).  DOFF = true: any scores.  p = 2^(s - m_q) with a
+// per-query offset m_q = the query's largest score against KV tile 0, subtracted for free as the C operand of the first QK^T MFMA of
+// every S block; nothing else in the tile loop changes.  A softmax only needs ONE offset per row that keeps every p inside the f32
+// range, not the running maximum: m_q <= the row maximum, so nothing that matters underflows, and a row whose later scores exceed
+// m_q by more than 90 (62 in natural units) shows up in its row sum (>= 2^90, inf or NaN), which the ones-MFMA computes anyway: the
+// workgroup then repeats its pass with that query's offset raised (by log2 of the sum, or by 100 when it overflowed).  Exact for any
+// input; the repeat is a safety net that trained attention does not reach.
+template <bool DOFF>
 __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, int ldqk,
                                                          const uint16_t* __restrict__ vt, int s_pad, uint16_t* __restrict__ out,
                                                          int ldo, int Sq, int S, unsigned long long* trace) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[3 * KT + 3 * VT];
+    __shared__ int s_again;               // DOFF: some wave of the workgroup asks for another pass
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int c16 = lane & 15, g4 = lane >> 4;
     const int head = blockIdx.y, q0 = blockIdx.x * 256 + wid * 64;
@@ -117,16 +126,14 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
     }
 
     f32x4 o[8][4];               // O^T accumulators [d block][query block]
-#pragma unroll
-    for (int db = 0; db < 8; ++db)
-#pragma unroll
-        for (int qb = 0; qb < 4; ++qb) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 s[4][4];               // scores [K fragment kb = 2 st + u][query block]
     u32x4 p[2][4];               // P^T operands [k-step of 32 keys][query block]
     bf16x8 kf[16], vf[16];       // K fragments n = 4 ks + kb (AGPRs), V^T fragments n = 8 st + db
     f32x4 lacc[4];               // row sums: every row of the accumulator holds sum_k P[q = c16][k] (A operand = ones)
+    f32x4 negm[4];               // DOFF: -m_q of query (qb, c16) in all four components (the C operand that starts an S block)
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) lacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qb = 0; qb < 4; ++qb) negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (DOFF && t == 0) s_again = 0;
     bf16x8 ones, ones_last[2];   // ones_last[st]: 1 for the k-slots of step st whose key exists in the last tile (slot (g4, j) <-> key
                                  // 32 st + 16 (g4 >> 1) + 8 (j >> 2) + 4 (g4 & 1) + (j & 3)), 0 for the others
 #pragma unroll
@@ -179,6 +186,35 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
 
 #define B64_DSR(dst_, cons_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : cons_(dst_) : "v"(addr_), "i"(off_) : "memory")
 
+    // ---- one iteration i: QK^T of tile i+1 (HAS_QK), PV of tile i (HAS_PV); R = i mod 3 (2 for i = -1), -1 = run-time ring slots
+    // (defined in front of the pass loop; the MFMA of S block (kb, qb), k-step ks, is also what the offset estimate issues)
+    auto qk_mfma = [&](auto kb_c, auto qb_c, auto ks_c, auto off_c) B64_INLINE {
+        constexpr int kb = decltype(kb_c)::value, qb = decltype(qb_c)::value, ks = decltype(ks_c)::value;
+        constexpr bool off = decltype(off_c)::value;   // start the block from -m_q instead of 0
+        B64_USE
+        if constexpr (qb < 2) {
+            if constexpr (ks == 0 && off) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "a"(qf[qb][ks]), "v"(negm[qb]));
+            else if constexpr (ks == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "a"(qf[qb][ks]));
+            else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "a"(qf[qb][ks]));
+        } else {
+            if constexpr (ks == 0 && off) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "v"(qf[qb][ks]), "v"(negm[qb]));
+            else if constexpr (ks == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "v"(qf[qb][ks]));
+            else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "v"(qf[qb][ks]));
+        }
+    };
+    // Between the code regions below hipcc may re-assign registers (copies at the region's end): every fragment read and every
+    // MFMA result must have landed before such a copy reads it.  Not needed inside the main loop (no copies there: checked in the ISA).
+    auto drain = [&]() B64_INLINE { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); };
+    unsigned long long tr_c0 = 0, tr_r0 = 0;
+    if (trace) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_c0), "=s"(tr_r0)::"memory");
+
+  for (int pass = 0;; ++pass) {   // one pass unless DOFF finds a row sum out of range (see the kernel's header)
+#pragma unroll
+    for (int db = 0; db < 8; ++db)
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) lacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     // ---- prologue: K(0) -> fragments; [K(1), V(0)] and the K pieces of K(2) in flight (what iterations -3 and -2 would have issued)
     {
         for_seq([&](auto pc) B64_INLINE {
@@ -205,8 +241,36 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
         }, std::make_integer_sequence<int, 16>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    if constexpr (DOFF) {
+        if (pass == 0) {   // m_q = max over KV tile 0 of the query's scores (S(0) from zero; iteration -1 computes it again from -m_q)
+            for_seq([&](auto gc) B64_INLINE {
+                constexpr int g = decltype(gc)::value;
+                constexpr int H = g / 32, ks = (g % 32) / 8, kb = (g % 8) / 2, qb = 2 * H + g % 2;
+                qk_mfma(ic<kb>{}, ic<qb>{}, ic<ks>{}, bc<false>{});
+            }, std::make_integer_sequence<int, 64>{});
+            drain();
+            // the compiler's own instructions read S only behind the drain: they hang on these (empty) statements' outputs
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) asm volatile("" : "+v"(s[kb][0]), "+v"(s[kb][1]), "+v"(s[kb][2]), "+v"(s[kb][3]));
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb) {
+                float mx = s[0][qb][0];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kb][qb][r]);
+                // the query's 64 keys sit in the four lanes c16 + 16 g4: row swaps instead of LDS shuffles
+                float a = mx, b = mx;
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+                mx = fmaxf(a, b);
+                a = mx; b = mx;
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+                mx = fmaxf(a, b);
+                negm[qb] = f32x4{-mx, -mx, -mx, -mx};
+            }
+        }
+    }
 
-    // ---- one iteration i: QK^T of tile i+1 (HAS_QK), PV of tile i (HAS_PV); R = i mod 3 (2 for i = -1), -1 = run-time ring slots
     auto iter = [&](auto qk_c, auto pv_c, auto r_c, int i) B64_INLINE {
         constexpr bool HAS_QK = decltype(qk_c)::value, HAS_PV = decltype(pv_c)::value;
         constexpr int R = decltype(r_c)::value;
@@ -229,13 +293,7 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
             if constexpr (g < 64) {
                 if constexpr (HAS_QK) {
                     constexpr int H = g / 32, ks = (g % 32) / 8, kb = (g % 8) / 2, qb = 2 * H + g % 2;
-                    if constexpr (qb < 2) {
-                        if constexpr (ks == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "a"(qf[qb][ks]));
-                        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "a"(qf[qb][ks]));
-                    } else {
-                        if constexpr (ks == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "v"(qf[qb][ks]));
-                        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "v"(qf[qb][ks]));
-                    }
+                    qk_mfma(ic<kb>{}, ic<qb>{}, ic<ks>{}, bc<DOFF>{});
                 }
             } else if constexpr (HAS_PV) {
                 constexpr int H = (g - 64) / 36, st = ((g - 64) % 36) / 18, m = ((g - 64) % 36) % 18;
@@ -297,11 +355,6 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
         };
         for_seq(gap, std::make_integer_sequence<int, T>{});
     };
-    // Between the code regions below hipcc may re-assign registers (copies at the region's end): every fragment read and every
-    // MFMA result must have landed before such a copy reads it.  Not needed inside the main loop (no copies there: checked in the ISA).
-    auto drain = [&]() B64_INLINE { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); };
-    unsigned long long tr_c0 = 0, tr_r0 = 0;
-    if (trace) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_c0), "=s"(tr_r0)::"memory");
     iter(bc<true>{}, bc<false>{}, ic<2>{}, -1);
     drain();
     int i = 0;
@@ -316,9 +369,35 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
         drain();
     }
     iter(bc<false>{}, bc<true>{}, ic<-1>{}, i);
-#undef B64_DSR
-    // MFMA result -> first non-MFMA reader; every DMA piece has landed before the workgroup leaves
+    // MFMA result -> first non-MFMA reader; every DMA piece has landed before the workgroup leaves (or starts over)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    // (the accumulators are read by the compiler's instructions only behind that wait: they hang on these empty statements' outputs)
+    asm volatile("" : "+a"(lacc[0]), "+a"(lacc[1]), "+a"(lacc[2]), "+a"(lacc[3]));
+#pragma unroll
+    for (int db = 0; db < 8; ++db) asm volatile("" : "+a"(o[db][0]), "+a"(o[db][1]), "+a"(o[db][2]), "+a"(o[db][3]));
+    if constexpr (!DOFF) break;
+    else {
+        bool bad = false;
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) bad |= !(lacc[qb][0] < 0x1p90f);   // also true for inf / NaN
+        if (__any(bad) && lane == 0) s_again = 1;
+        __syncthreads();
+        const int again = s_again;
+        if (!again || pass >= 12) break;   // 12 repeats raise an offset by >= 1200: beyond that the inputs are not finite numbers
+        __syncthreads();
+        if (t == 0) s_again = 0;
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            const float l = lacc[qb][0];
+            if (!(l < 0x1p90f)) {
+                const float up = (l < 0x1p127f) ? ceilf(__builtin_amdgcn_logf(l)) : 100.0f;   // v_log_f32 = log2
+                negm[qb] = negm[qb] - f32x4{up, up, up, up};
+            }
+        }
+        __syncthreads();
+    }
+  }
+#undef B64_DSR
     if (trace) {
         unsigned long long c1, r1;
         asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
@@ -350,9 +429,10 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
 }  // namespace
 
 // 0 launched / 1 not this kernel's case (the caller falls back) / 2 launch error.
-// Requires: q pre-multiplied by scale*log2(e) and the fixed zero offset valid (the caller checks); vt zero beyond key S - 1.
+// Requires: q pre-multiplied by scale*log2(e); data_offset = false: the fixed zero offset valid (the caller checks), true: any scores;
+// vt zero beyond key S - 1.
 int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
-                        int ldo, int Sq, int S, int heads) {
+                        int ldo, int Sq, int S, int heads, bool data_offset) {
     if (S < 1 || Sq <= 0 || s_pad < ((S + BKV - 1) / BKV) * BKV) return 1;
     if ((unsigned long long)S * (unsigned long long)ldqk * 2 >= (1ull << 31) || (unsigned long long)HD * (unsigned long long)s_pad * 2 >= (1ull << 31)) return 1;
     const dim3 grid((Sq + 255) / 256, heads), block(256);
@@ -361,7 +441,8 @@ int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k
     static int seen = 0;
     const size_t tn = (size_t)grid.x * grid.y * 4 * 2;
     if (trace_env && ++seen % 8 == 0 && hipMalloc((void**)&trace, tn * 8) != hipSuccess) trace = nullptr;
-    hipLaunchKernelGGL(attn64b_kernel, grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, trace);
+    if (data_offset) hipLaunchKernelGGL(attn64b_kernel<true>, grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, trace);
+    else hipLaunchKernelGGL(attn64b_kernel<false>, grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, trace);
     if (trace) {
         std::vector<unsigned long long> h(tn);
         (void)hipStreamSynchronize(stream);

@@ -72,7 +72,7 @@ struct flux2mi_dit {
     std::vector<Buf> bufs;
     std::unordered_map<std::string, Slot> slots;
     bool finalized = false;
-    int attn_softmax_mode = 0;  // 0: fixed-offset softmax where score_bound allows it; 1: running maximum everywhere
+    int attn_softmax_mode = 0;  // 0: fixed-offset softmax where score_bound allows it; 1: no bound assumed anywhere (data-offset form)
     bool lora_merged = false;  // a LoRA was merged into the resident weights (tagged in pre-quantized exports)
     int64_t param_bytes = 0;
 
@@ -902,7 +902,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     }();
     const float q_mul = q_pre ? 1.4426950408889634f / sqrtf(128.0f) : 1.0f;
     auto attend = [&](int layer, uint16_t* o_buf, int ldo, float score_bound) -> int {
-        if (m->attn_softmax_mode == 1) score_bound = 0.f;   // no bound given: launch_attention keeps the running maximum
+        if (m->attn_softmax_mode == 1) score_bound = 0.f;   // no bound given: launch_attention takes the data-offset form
         if (mode == FWD_KV_EXTRACT) {
             F2_CHECK_HIP(hipMemcpy2DAsync(cache->k(layer), (size_t)d * 2, qkv + (size_t)s_txt * 3 * d + d, (size_t)3 * d * 2,
                                           (size_t)d * 2, (size_t)s_ref, hipMemcpyDeviceToDevice, st));
@@ -1090,9 +1090,10 @@ extern "C" int flux2mi_dit_forward(flux2mi_dit* m, const float* latents, int s_i
                             txt_ids, nullptr, out, s_out);
 }
 
-// Which softmax form the attention of each block runs.  The fixed-offset form (attention.hip, FIXM) needs the block's
-// QK-RMSNorm weights to bound the scores: 16.8 max|w_q| max|w_k| <= 40 in the log2 domain; blocks of a checkpoint with
-// larger norm scales keep the running maximum (online softmax), which costs ~11 % more attention time.
+// Which softmax form the attention of each block runs.  The fixed zero offset (attention64b.hip, DOFF = false) needs the block's
+// QK-RMSNorm weights to bound the scores: 16.3 max|w_q| max|w_k| <= 80 in the log2 domain; blocks of a checkpoint with larger
+// norm scales take the per-query data offset of the same kernel (DOFF = true: exact for any scores, +0.4-1.3 % attention time
+// on the 1024^2 shapes, profiles/r02_l_attention_offset_bench.log).
 extern "C" int flux2mi_dit_set_attention_softmax(flux2mi_dit* m, int mode) {
     F2_REQUIRE(m && (mode == 0 || mode == 1), FLUX2MI_ERR_INVALID_ARG, "dit_set_attention_softmax: mode 0 (auto) or 1 (online)");
     m->attn_softmax_mode = mode;
@@ -1266,7 +1267,7 @@ extern "C" int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv_in, void* 
 
 // The form the model's blocks run (dit.cpp attention_block): q arrives multiplied by log2(e)/sqrt(128) (the norm + RoPE step folds
 // it in before q's one rounding to bf16) and |q.k| <= score_bound_log2 in that domain, so the softmax may use a fixed zero offset
-// (attention.hip / attention64.hip).  score_bound_log2 <= 0 or > 80 falls back to the running maximum on the pre-scaled q.
+// (attention.hip / attention64b.hip).  score_bound_log2 <= 0 or > 80: the per-query data-offset form (exact for any scores).
 extern "C" int flux2mi_op_attention_prescaled(flux2mi_ctx* ctx, const void* qkv_in, void* out, int S, int heads, float score_bound_log2) {
     F2_REQUIRE(ctx && qkv_in && out && S > 0 && heads > 0, FLUX2MI_ERR_INVALID_ARG, "op_attention_prescaled: bad argument");
     const int d = heads * 128, s_pad = attn_s_pad(S);

@@ -407,8 +407,9 @@ typedef struct flux2mi_generate_params {
 
 /* Softmax form of the DiT's joint attention (replaces MLXFast.scaledDotProductAttention, Flux2Attention.swift:168,
  * Flux2ParallelAttention.swift:104 — the same softmax either way, any offset cancels in O / l).
- * mode 0 (default): blocks whose QK-RMSNorm weights bound the scores take the fixed-offset form, the others the
- * running-maximum (online) form; mode 1: running maximum everywhere.  _info reports how many blocks take which form. */
+ * mode 0 (default): blocks whose QK-RMSNorm weights bound the scores take the fixed zero offset, the others a per-query
+ * offset taken from the data (exact for any scores; counted as "online"); mode 1: the data-offset form everywhere.
+ * _info reports how many blocks take which form. */
 int flux2mi_dit_set_attention_softmax(flux2mi_dit* dit, int mode);
 int flux2mi_dit_attention_softmax_info(const flux2mi_dit* dit, int* n_fixed_offset, int* n_online);
 

@@ -433,3 +433,69 @@ def test_attention_prescaled_large_scores(ctx):
     ref = R.sdpa(hv(qs / c), hv(ks), hv(vs)).permute(0, 2, 1, 3).reshape(S, d)
     assert torch.isfinite(out).all()
     assert rel_l2(out, ref) < 1e-2
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,heads", [(64, 1), (200, 2), (448, 3), (1153, 2), (4608, 2)])
+def test_attention_prescaled_data_offset(ctx, S, heads):
+    """No usable score bound (bound 0 = unknown, or > 80): the same one-wave-per-SIMD kernel with a per-query offset m_q = the query's
+    largest score in KV tile 0 (attention64b.hip, DOFF) — vs the oracle's softmax (rel-L2 <= 1e-2), bit-reproducible, and the same
+    result whether the bound is missing or merely too large."""
+    import math
+    g = torch.Generator().manual_seed(S * 5 + heads)
+    d = heads * 128
+    x = torch.randn((S, 3 * d), generator=g)
+    q = x[:, :d].view(S, heads, 128)
+    k = x[:, d:2 * d].view(S, heads, 128)
+    q = q / q.pow(2).mean(-1, keepdim=True).sqrt()
+    k = k / k.pow(2).mean(-1, keepdim=True).sqrt()
+    q = q * 4.0                            # |scores| up to 98 in the log2 domain: outside the fixed-offset range (80)
+    k[S // 2] *= 1.5
+    c = math.log2(math.e) / math.sqrt(128.0)
+    qkv = torch.cat([(q * c).reshape(S, d), k.reshape(S, d), x[:, 2 * d:]], dim=1).to(torch.bfloat16)
+    out = ctx.op_attention_prescaled(qkv.cuda(), heads, 0.0)
+    qs, ks, vs = qkv.float().split(d, dim=1)
+    hv = lambda t: t.reshape(1, S, heads, 128).permute(0, 2, 1, 3)
+    ref = R.sdpa(hv(qs / c), hv(ks), hv(vs)).permute(0, 2, 1, 3).reshape(S, d)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 1e-2
+    assert torch.equal(out, ctx.op_attention_prescaled(qkv.cuda(), heads, 0.0))
+    assert torch.equal(out, ctx.op_attention_prescaled(qkv.cuda(), heads, 4.0 * 1.5 * 128.0 * c))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["late_peak", "low_first_tile"])
+def test_attention_prescaled_data_offset_repeated_pass(ctx, case):
+    """The safety net of the data-offset kernel: scores that exceed the KV-tile-0 estimate by > 127 in the log2 domain overflow the
+    row sum, and the workgroup repeats its pass with the offsets of exactly those queries raised (twice or more here: +100 per overflow,
+    then the exact log2 of the sum).  Every second query has no such key (its offset stays), ragged S, three heads."""
+    import math
+    S, heads = 713, 3
+    g = torch.Generator().manual_seed(23)
+    d = heads * 128
+    x = torch.randn((S, 3 * d), generator=g)
+    q = x[:, :d].view(S, heads, 128).clone()
+    k = x[:, d:2 * d].view(S, heads, 128).clone()
+    q = q / q.pow(2).mean(-1, keepdim=True).sqrt()
+    k = k / k.pow(2).mean(-1, keepdim=True).sqrt()
+    u = torch.randn((heads, 128), generator=g)
+    u = u / u.pow(2).mean(-1, keepdim=True).sqrt()
+    q[1::2] = q[1::2] - (q[1::2] * u).sum(-1, keepdim=True) / 128.0 * u   # the others are orthogonal to it
+    q[::2] = q[::2] * 0.25 + u             # every second query carries the common direction u
+    c = math.log2(math.e) / math.sqrt(128.0)
+    if case == "late_peak":
+        k[300] = u * 20.0                  # score ~ +330 (log2 domain) for those queries, ~0 for the others; tile 0 holds ordinary keys
+        k[500] = -u * 20.0
+    else:
+        k[:64] = -u * 20.0 + k[:64] * 0.1  # tile 0 scores ~ -330 for those queries: the estimate sits far below the rest of the row
+    qkv = torch.cat([(q * c).reshape(S, d), k.reshape(S, d), x[:, 2 * d:]], dim=1).to(torch.bfloat16)
+    out = ctx.op_attention_prescaled(qkv.cuda(), heads, 0.0)
+    qs, ks, vs = qkv.float().split(d, dim=1)
+    sc = qs.view(S, heads, 128).permute(1, 0, 2) @ ks.view(S, heads, 128).permute(1, 2, 0)
+    jump = (sc.max(dim=2).values - sc[:, :, :64].max(dim=2).values)
+    assert float(jump.max()) > 250.0 and float(jump[:, 1::2].max()) < 90.0, (float(jump.max()), float(jump[:, 1::2].max()))
+    hv = lambda t: t.reshape(1, S, heads, 128).permute(0, 2, 1, 3)
+    ref = R.sdpa(hv(qs / c), hv(ks), hv(vs)).permute(0, 2, 1, 3).reshape(S, d)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 1e-2
+    assert torch.equal(out, ctx.op_attention_prescaled(qkv.cuda(), heads, 0.0))
+
+
