@@ -431,8 +431,21 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
 // 0 launched / 1 not this kernel's case (the caller falls back) / 2 launch error.
 // Requires: q pre-multiplied by scale*log2(e); data_offset = false: the fixed zero offset valid (the caller checks), true: any scores;
 // vt zero beyond key S - 1.
+// The two instantiations are separate translation units (attention64b_doff.hip includes this file with ATTN64B_DOFF 1): each takes
+// hipcc ~2.5 minutes, side by side in a parallel build.
+#ifndef ATTN64B_DOFF
+#define ATTN64B_DOFF 0
+#endif
+int launch_attention64b_doff(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
+                             int ldo, int Sq, int S, int heads);
+#if ATTN64B_DOFF
+int launch_attention64b_doff(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
+                             int ldo, int Sq, int S, int heads) {
+#else
 int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
                         int ldo, int Sq, int S, int heads, bool data_offset) {
+    if (data_offset) return launch_attention64b_doff(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads);
+#endif
     if (S < 1 || Sq <= 0 || s_pad < ((S + BKV - 1) / BKV) * BKV) return 1;
     if ((unsigned long long)S * (unsigned long long)ldqk * 2 >= (1ull << 31) || (unsigned long long)HD * (unsigned long long)s_pad * 2 >= (1ull << 31)) return 1;
     const dim3 grid((Sq + 255) / 256, heads), block(256);
@@ -441,8 +454,7 @@ int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k
     static int seen = 0;
     const size_t tn = (size_t)grid.x * grid.y * 4 * 2;
     if (trace_env && ++seen % 8 == 0 && hipMalloc((void**)&trace, tn * 8) != hipSuccess) trace = nullptr;
-    if (data_offset) hipLaunchKernelGGL(attn64b_kernel<true>, grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, trace);
-    else hipLaunchKernelGGL(attn64b_kernel<false>, grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, trace);
+    hipLaunchKernelGGL(attn64b_kernel<(ATTN64B_DOFF != 0)>, grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, trace);
     if (trace) {
         std::vector<unsigned long long> h(tn);
         (void)hipStreamSynchronize(stream);
@@ -451,8 +463,8 @@ int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k
         double cyc = 0, rt = 0;
         for (size_t w = 0; w < tn / 2; ++w) { cyc += (double)h[2 * w]; rt += (double)h[2 * w + 1]; }
         const double tiles = (double)(tn / 2) * ((S + BKV - 1) / BKV + 1);
-        fprintf(stderr, "[attn64b trace] S %d heads %d: %.0f shader cycles per KV tile (136 MFMAs = 2176), in-loop clock %.0f MHz, %.3f us per tile\n", S, heads,
-                cyc / tiles, cyc / rt * 100.0, rt / tiles * 0.01);
+        fprintf(stderr, "[attn64b trace%s] S %d heads %d: %.0f shader cycles per KV tile (136 MFMAs = 2176), in-loop clock %.0f MHz, %.3f us per tile\n",
+                ATTN64B_DOFF ? ", data offset" : "", S, heads, cyc / tiles, cyc / rt * 100.0, rt / tiles * 0.01);
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

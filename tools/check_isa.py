@@ -9,7 +9,7 @@
     * exactly the instruction mix the schedule tables describe (MFMA / ds_read / DMA counts per trip)
   and the kernels use no scratch at all; in particular no block that issues an MFMA may touch scratch: a spill store of an accumulator
   placed behind the asm MFMA that writes it stores a register whose result is still in flight.
-Run after any change to those files or to the toolchain (~7 min): python tools/check_isa.py"""
+Run after any change to those files or to the toolchain (~5 min): python tools/check_isa.py"""
 import collections
 import os
 import re
@@ -27,6 +27,12 @@ def compile_s(name):
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-w", "-S", "--offload-device-only",
                     os.path.join(CSRC, name + ".hip"), "-o", dst], check=True)
     return open(dst).read()
+
+
+def compile_many(names):   # side by side (each is minutes of hipcc)
+    import concurrent.futures
+    with concurrent.futures.ThreadPoolExecutor(len(names)) as ex:
+        return list(ex.map(compile_s, names))
 
 
 def kernels(text):
@@ -92,8 +98,8 @@ def main():
         if not found:
             errors.append((kname, "steady-state loop not found"))
     # ---- attention: the three-tile loop of both instantiations (DOFF = false: fixed zero offset, true: per-query data offset)
-    text = compile_s("attention64b")
-    for kname, body in kernels(text):
+    texts = compile_many(["attention64b", "attention64b_doff"])
+    for text, (kname, body) in [(t, kb) for t in texts for kb in kernels(t)]:
         m = re.search(r"attn64b_kernelILb(\d)E", kname)
         if not m:
             continue
