@@ -188,9 +188,12 @@ def main():
         one_batch()
 
     par.barrier()
+    sampler = None
     if not dry:
         torch.cuda.synchronize()
         pipe.ctx.prof_begin(args.prof_class)
+        if rank == 0:
+            sampler = CardSampler(dev.index).start()
     t_start = time.perf_counter()
     ms_denoise = ms_decode = 0.0
     res = None
@@ -203,6 +206,7 @@ def main():
         torch.cuda.synchronize()
     par.barrier()
     elapsed = time.perf_counter() - t_start
+    card = sampler.finish() if sampler is not None else None
     n_launch, prof_ms, prof_flops = (0, 0.0, 0.0) if dry else pipe.ctx.prof_end()
     elapsed = par.all_reduce_max(elapsed, dev)
 
@@ -284,12 +288,67 @@ def main():
         "output_check": {"latents_finite": True, "image_crc32": checksum, "u8_histogram": hist},
         "model_load_s": round(t_load, 2),
         "roofline": roofline,
+        "card": card,
         "cpu_baseline": cpu_baseline,
     }
     if dry:
         out["dry_run"] = True
     print(json.dumps(out), flush=True)
     par.finalize()
+
+
+class CardSampler:
+    """Read-only samples of the card's power and shader clock (amdgpu hwmon sysfs of the PCI device torch calls cuda:<index>) every
+    0.1 s during the timed region, on rank 0: the hot kernels run at the board's power cap, so the clock they get — and with it
+    `roofline.achieved` — differs from box to box.  Everything is optional: missing files give nulls."""
+
+    def __init__(self, dev_index):
+        import glob
+        import threading
+        self.hw = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(dev_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            hits = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            self.hw = hits[0] if hits else None
+        except Exception:
+            self.hw = None
+        self.stop = threading.Event()
+        self.rows = []
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.hw, name)) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError, TypeError):
+            return None
+
+    def _run(self):
+        while not self.stop.is_set():
+            pw = self._read("power1_average")
+            if pw is None:
+                pw = self._read("power1_input")
+            self.rows.append((pw, self._read("freq1_input")))
+            self.stop.wait(0.1)
+
+    def start(self):
+        if self.hw:
+            self.thread.start()
+        return self
+
+    def finish(self):
+        if not self.hw:
+            return None
+        self.stop.set()
+        self.thread.join()
+        pw = sorted(r[0] / 1e6 for r in self.rows if r[0])
+        ck = sorted(r[1] / 1e6 for r in self.rows if r[1])
+        cap = self._read("power1_cap")
+        med = lambda v: round(v[len(v) // 2], 1) if v else None
+        return {"cap_w": round(cap / 1e6, 1) if cap else None, "median_w": med(pw), "max_w": round(pw[-1], 1) if pw else None,
+                "median_sclk_mhz": med(ck), "min_sclk_mhz": round(ck[0], 1) if ck else None, "samples": len(self.rows)}
 
 
 def run_cpu_baseline(P_dev, cfg, syn, H, W, T, s_txt):
