@@ -1091,7 +1091,7 @@ extern "C" int flux2mi_dit_forward(flux2mi_dit* m, const float* latents, int s_i
 }
 
 // Which softmax form the attention of each block runs.  The fixed zero offset (attention64b.hip, DOFF = false) needs the block's
-// QK-RMSNorm weights to bound the scores: 16.3 max|w_q| max|w_k| <= 80 in the log2 domain; blocks of a checkpoint with larger
+// QK-RMSNorm weights to bound the scores: 16.8 max|w_q| max|w_k| <= 80 in the log2 domain; blocks of a checkpoint with larger
 // norm scales take the per-query data offset of the same kernel (DOFF = true: exact for any scores, +0.4-1.3 % attention time
 // on the 1024^2 shapes, profiles/r02_l_attention_offset_bench.log).
 extern "C" int flux2mi_dit_set_attention_softmax(flux2mi_dit* m, int mode) {

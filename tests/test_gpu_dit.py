@@ -320,14 +320,13 @@ def test_kv_fp8_runs_and_matches_emulation(flux2mi, ctx):
     assert rel_l2(h0, o0) < 2e-2 and rel_l2(h1, o1) < 2e-2
 
 
-# ---- attention softmax offset: fixed bound vs running maximum --------------------------------------
-@pytest.mark.parametrize("factor,s_txt,h,w", [(1.0, 16, 128, 128), (1.12, 19, 80, 112), (1.5, 16, 128, 128), (3.0, 19, 80, 112)])
-def test_forward_with_scaled_qk_norm_weights(flux2mi, ctx, factor, s_txt, h, w):
-    """The DiT's attention replaces the running row maximum by a fixed offset when the QK-RMSNorm
-    weights bound the scores tightly enough (16.8 max|w_q| max|w_k| <= 40 in the log2 domain), and
-    keeps the running maximum otherwise.  factor 1.0 / 1.12: fixed-offset path (bound ~31 / ~39, the
-    second just under the switch); 1.5 / 3.0: running-max path with much peakier softmaxes.  All
-    against the oracle, rel-L2 <= 2e-2."""
+# ---- attention softmax offset: fixed zero offset vs per-query data offset ----------------------------
+@pytest.mark.parametrize("factor,s_txt,h,w,fixed", [(1.0, 16, 128, 128, True), (1.5, 19, 80, 112, True), (2.0, 16, 128, 128, False), (4.0, 19, 80, 112, False)])
+def test_forward_with_scaled_qk_norm_weights(flux2mi, ctx, factor, s_txt, h, w, fixed):
+    """The DiT's attention takes a fixed zero softmax offset when the QK-RMSNorm weights bound the pre-scaled scores tightly
+    enough (16.8 max|w_q| max|w_k| <= 80 in the log2 domain), and a per-query offset from the data otherwise (attention64b.hip,
+    DOFF).  The synthetic norm scales are 1 +- 0.1 (max ~1.3): factor 1.0 / 1.5: fixed offset in every block (bounds ~29 / ~65);
+    2.0 / 4.0: data offset in every block (~110 / ~460, much peakier softmaxes).  All against the oracle, rel-L2 <= 2e-2; the library reports which form each block takes."""
     from flux2mi import synthetic as syn
     from flux2mi.api import DiT
     cfg = syn.DIT_PRESETS["tiny"]
@@ -339,11 +338,56 @@ def test_forward_with_scaled_qk_norm_weights(flux2mi, ctx, factor, s_txt, h, w):
     lat = R.pack_patchified_to_sequence(inp["noise"])
     img_ids, txt_ids = R.image_position_ids(h, w), R.text_position_ids(s_txt)
     dit = DiT(ctx, cfg).load(P).finalize()
+    paths = dit.attention_softmax_paths()
     out = dit.forward(lat.cuda(), inp["txt"].cuda(), 0.731, 4.0, img_ids.cuda(), txt_ids.cuda()).cpu()
     dit.close()
     ref = R.dit_forward(P, cfg, lat, inp["txt"].float(), torch.tensor([0.731]), None, img_ids, txt_ids)[0]
+    n_blocks = cfg["n_double"] + cfg["n_single"]
+    assert paths == ({"fixed_offset_blocks": n_blocks, "online_blocks": 0} if fixed else {"fixed_offset_blocks": 0, "online_blocks": n_blocks}), paths
     assert torch.isfinite(out).all()
     assert rel_l2(out, ref) < 2e-2
+
+
+def test_online_mode_forward_and_kv_paths(flux2mi, ctx):
+    """`set_attention_softmax("online")` (bench.py --attn-softmax online): no score bound assumed in any block.  The plain forward at
+    Klein-4B width and the KV extraction / cached passes (query ranges that see a subset of the keys, cached K / V^T) against the
+    oracle, and within bf16 rounding of the default mode on the same weights."""
+    from flux2mi import synthetic as syn
+    from flux2mi.api import DiT, KVCache
+    cfg = dict(dim=3072, heads=24, n_double=1, n_single=1, joint_dim=7680, guidance=False)
+    s_txt, h, w, ref_hw = 64, 256, 256, (16, 16)
+    P = syn.make_dit_weights(cfg, seed=5, std=0.05)
+    inp = syn.make_inputs(cfg, h, w, s_txt=s_txt)
+    lat = R.pack_patchified_to_sequence(inp["noise"])
+    g = torch.Generator().manual_seed(1)
+    s_ref = ref_hw[0] * ref_hw[1]
+    ref = torch.randn((1, s_ref, 128), generator=g)
+    lat2 = lat + 0.3 * torch.randn(lat.shape, generator=g)
+    ref_ids = R.reference_position_ids([ref_hw[0]], [ref_hw[1]])
+    img_ids, txt_ids = R.image_position_ids(h, w), R.text_position_ids(s_txt)
+    o_plain = R.dit_forward(P, cfg, lat, inp["txt"].float(), torch.tensor([0.731]), None, img_ids, txt_ids)[0]
+    o0, cache = R.dit_forward_kv(P, cfg, lat, inp["txt"].float(), torch.tensor([0.8]), None, img_ids, txt_ids, ref_lat=ref, ref_ids=ref_ids)
+    o1, _ = R.dit_forward_kv(P, cfg, lat2, inp["txt"].float(), torch.tensor([0.55]), None, img_ids, txt_ids, cache=cache)
+    d = lambda x: x.cuda()
+    outs = {}
+    for mode in ("auto", "online"):
+        dit = DiT(ctx, cfg).load(P).finalize()
+        dit.set_attention_softmax(mode)
+        n_blocks = cfg["n_double"] + cfg["n_single"]
+        assert dit.attention_softmax_paths() == ({"fixed_offset_blocks": n_blocks, "online_blocks": 0} if mode == "auto"
+                                                 else {"fixed_offset_blocks": 0, "online_blocks": n_blocks})
+        kv = KVCache(dit, s_txt, s_ref)
+        hp = dit.forward(d(lat), d(inp["txt"]), 0.731, 4.0, d(img_ids), d(txt_ids)).cpu()
+        h0 = dit.forward_kv_extract(kv, d(lat), d(ref), d(inp["txt"]), 0.8, 4.0, d(img_ids), d(txt_ids), d(ref_ids)).cpu()
+        h1 = dit.forward_kv_cached(kv, d(lat2), d(inp["txt"]), 0.55, 4.0, d(img_ids), d(txt_ids)).cpu()
+        kv.close()
+        dit.close()
+        outs[mode] = (hp, h0, h1)
+    for got, want in zip(outs["online"], (o_plain, o0[0], o1[0])):
+        assert torch.isfinite(got).all()
+        assert rel_l2(got, want) < 2e-2
+    for a_, b_ in zip(outs["online"], outs["auto"]):
+        assert rel_l2(a_, b_) < 5e-3
 
 
 # ---- edge sizes ------------------------------------------------------------------------------------
