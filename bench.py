@@ -251,9 +251,17 @@ def main():
         if args.model == "klein-4b" and (H, W) == (1024, 1024) and args.weights == "bf16" and os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f)["traffic_bytes_per_launch"]
+        # what the matrix pipe of THIS card sustains at its power cap (register-only MFMA stream, ~0.6 s, after the timed region):
+        # the ceiling a perfect kernel would see here; `peak` stays the data-sheet figure
+        stream_tf = None
+        try:
+            stream_tf = round(pipe.ctx.mfma_stream_tflops(fp8=(args.weights == "fp8")), 1)
+        except Exception as e:   # diagnostic only
+            print(f"[bench] mfma stream probe failed: {e}", file=sys.stderr)
         roofline = {"bound": "mfma", "kernel": pipe.ctx.prof_kernel_name(args.prof_class),
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "mfma_stream": stream_tf, "frac_of_mfma_stream": round(achieved / stream_tf, 4) if stream_tf else None,
                     "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
                     "flops_per_launch": flops_per_launch}
         step_ms = ms_denoise / (K * T)

@@ -161,6 +161,7 @@ PROTOTYPES = {
     "flux2mi_vae_encode": (_I, [_P, _P, _I, _I, _P]),
     "flux2mi_vae_has_encoder": (_I, [_P]),
     "flux2mi_generate": (_I, [_P, _P, _P, C.POINTER(GenerateParams)]),
+    "flux2mi_debug_mfma_stream": (_I, [_P, _I, C.c_double, C.POINTER(C.c_double)]),
     "flux2mi_prof_begin": (_I, [_P, _I]),
     "flux2mi_prof_end": (_I, [_P, _PI, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "flux2mi_op_gemm_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I]),

@@ -295,6 +295,14 @@ class Context:
     def prof_kernel_name(self, kernel_class: int) -> str:
         return self.PROF_KERNELS.get(kernel_class, str(kernel_class))
 
+    def mfma_stream_tflops(self, fp8: bool = False, seconds: float = 0.6) -> float:
+        """The matrix-pipe rate this card sustains on a register-only MFMA stream at its power cap (diagnostic, synchronous)."""
+        v = C.c_double(0.0)
+        self._enter()
+        check(lib().flux2mi_debug_mfma_stream(self.handle, 1 if fp8 else 0, float(seconds), C.byref(v)))
+        self._exit()
+        return v.value
+
     def prof_end(self):
         n, ms, fl = C.c_int(0), C.c_double(0.0), C.c_double(0.0)
         check(lib().flux2mi_prof_end(self.handle, C.byref(n), C.byref(ms), C.byref(fl)))

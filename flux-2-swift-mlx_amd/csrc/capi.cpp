@@ -113,6 +113,20 @@ void prof_after(flux2mi_ctx* ctx, int cls_mask, double flops) {
     p.flops += flops;
 }
 
+extern "C" int flux2mi_debug_mfma_stream(flux2mi_ctx* ctx, int fp8, double seconds, double* tflops) {
+    F2_REQUIRE(ctx && tflops && seconds > 0.0 && seconds <= 10.0 && (fp8 == 0 || fp8 == 1), FLUX2MI_ERR_INVALID_ARG, "debug_mfma_stream: bad args");
+    int n_cu = ctx->n_cu;
+    if (n_cu <= 0) {
+        hipDeviceProp_t pr;
+        F2_CHECK_HIP(hipGetDeviceProperties(&pr, ctx->device));
+        n_cu = pr.multiProcessorCount;
+    }
+    F2_TRY(ctx->scratch.reserve((size_t)n_cu * 256 * sizeof(float)));
+    const int r = launch_mfma_stream(ctx->stream, ctx->scratch.as<float>(), n_cu, fp8 != 0, seconds, tflops);
+    F2_REQUIRE(r == 0, FLUX2MI_ERR_HIP, "debug_mfma_stream: launch failed");
+    return FLUX2MI_OK;
+}
+
 extern "C" int flux2mi_prof_begin(flux2mi_ctx* ctx, int kernel_class) {
     F2_REQUIRE(ctx && kernel_class >= 0 && kernel_class < 8, FLUX2MI_ERR_INVALID_ARG, "prof_begin: bad args");
     ProfState& p = ctx->prof;

@@ -102,6 +102,8 @@ int launch_layernorm_modulate(hipStream_t stream, const float* x, uint16_t* y, i
 int launch_layernorm_modulate_fp8(hipStream_t stream, const float* x, uint8_t* y, float* y_scale, int rows, int dim,
                                   int split, const float* shift0, const float* scale0, const float* shift1,
                                   const float* scale1);
+// Register-only MFMA stream (mfma_stream.hip): the matrix-pipe rate this card sustains at its power cap; diagnostic.
+int launch_mfma_stream(hipStream_t stream, float* out, int workgroups, bool fp8, double seconds, double* tflops);
 // Row-wise dynamic quantisation bf16 [rows, cols] (row stride ld) -> e4m3 [rows, cols] (stride ldq) + scale[rows].
 int launch_quantize_rows_fp8(hipStream_t stream, const uint16_t* x, int ld, uint8_t* q, int ldq, float* scale,
                              int rows, int cols);

@@ -421,6 +421,11 @@ int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae* vae, flux2
  * 1 = all DiT GEMMs, 2 = attention, 3 = VAE conv. */
 int flux2mi_prof_begin(flux2mi_ctx* ctx, int kernel_class);
 int flux2mi_prof_end(flux2mi_ctx* ctx, int* n_launches, double* total_ms, double* flops);
+/* The matrix-pipe rate THIS card sustains (diagnostic; bench.py's roofline.mfma_stream): a register-only stream of the MFMA the
+ * hot kernels use — fp8 = 0: v_mfma_f32_16x16x32_bf16, 1: the e4m3 v_mfma_scale_f32_16x16x128_f8f6f4 — on pseudo-random
+ * operands, one wave per SIMD on every CU, for about `seconds`; *tflops = the rate of the second half.  The hot kernels run at the
+ * board's power cap, so this — not the data-sheet peak — is what a perfect kernel could reach on the box at hand.  Synchronous. */
+int flux2mi_debug_mfma_stream(flux2mi_ctx* ctx, int fp8, double seconds, double* tflops);
 
 /* Standalone op entry points (tests / microbenchmarks; same kernels the forward uses). */
 /* C[M,N] (f32) = A[M,K] (bf16) * W[N,K]^T (bf16) */

@@ -499,3 +499,14 @@ def test_attention_prescaled_data_offset_repeated_pass(ctx, case):
     assert torch.equal(out, ctx.op_attention_prescaled(qkv.cuda(), heads, 0.0))
 
 
+
+
+@pytest.mark.gpu
+def test_mfma_stream_probe(ctx):
+    """flux2mi_debug_mfma_stream (bench.py's roofline.mfma_stream): the register-only MFMA stream reports a rate between a third of
+    the data-sheet peak and the peak itself (bf16 2.5 PF, e4m3 5 PF) — it is a measurement of the card, not a constant."""
+    bf16 = ctx.mfma_stream_tflops(fp8=False, seconds=0.2)
+    fp8 = ctx.mfma_stream_tflops(fp8=True, seconds=0.2)
+    assert 800.0 < bf16 < 2600.0, bf16
+    assert 1600.0 < fp8 < 5200.0, fp8
+    assert fp8 > 1.5 * bf16
