@@ -195,8 +195,14 @@ struct ConvArgs {
     int upsample;           // 1: the conv reads a nearest-2x upsampled view of x (Ho = 2*Hin)
     int downsample;         // 1: stride 2, no top/left padding, one zero row/column at the bottom/right
                             //    (Downsample2D, ResnetBlock.swift:189-214): Ho = Hin/2, ks must be 3
+    const uint16_t* w_phase;  // optional, with upsample = 1 and ks = 3: bf16 [4 phases][Cout_pad][2*2][Cin] from
+                              // launch_upsample_phase_weights — the same convolution as four 2x2 convolutions on x (4/9 of the MACs)
 };
 int launch_conv2d(hipStream_t stream, const ConvArgs& a);
+// A 3x3 convolution of a nearest-2x upsampled image is, per output phase (py, px) = (row & 1, col & 1), a 2x2 convolution of the
+// image itself: the taps that land on the same source pixel add up.  w bf16 OHWI [cout_pad][3][3][cin] -> w_phase bf16
+// [py*2+px][cout_pad][a*2+b][cin], tap (a, b) on source pixel (y + py - 1 + a, x + px - 1 + b); sums in f32, one rounding.
+int launch_upsample_phase_weights(hipStream_t stream, const uint16_t* w, int cout_pad, int cin, uint16_t* w_phase);
 // GroupNorm statistics of NHWC bf16 x -> per-channel affine (a_c, b_c) f32 with
 // y = a_c*x + b_c == GN(x)*gamma + beta  (32 groups, eps 1e-6, f32 statistics; ResnetBlock.swift:9-55).
 int launch_groupnorm_stats(hipStream_t stream, const uint16_t* x, int64_t pixels, int C, int groups,

@@ -58,6 +58,7 @@ struct flux2mi_vae {
     AttnW attn;
     ResnetW up[4][3];
     ConvW upsample[3];
+    DevBuf up_phase[3];                 // the upsample convolutions as four 2x2 convolutions (launch_upsample_phase_weights), built by finalize
     int bn_mean = -1, bn_var = -1;
     // encoder side
     ConvW e_conv_in, e_conv_out, e_quant, e_down[3];
@@ -290,6 +291,16 @@ extern "C" int flux2mi_vae_finalize(flux2mi_vae* v) {
         }
     v->stage_raw.release();
     v->stage_bf16.release();
+    // nearest-2x upsample + 3x3 convolution = four 2x2 convolutions on the source image (4/9 of the MACs): combined weights, once
+    for (int i = 0; i < 3; ++i) {
+        const ConvW& c = v->upsample[i];
+        if (c.w < 0 || c.ks != 3 || c.cin % 64 != 0) continue;
+        const int cout_pad = pad32(c.cout);
+        F2_TRY(v->up_phase[i].reserve((size_t)16 * cout_pad * c.cin * 2));
+        F2_LAUNCH(launch_upsample_phase_weights(v->ctx->stream, reinterpret_cast<const uint16_t*>(v->params[c.w].ptr), cout_pad, c.cin,
+                                                v->up_phase[i].as<uint16_t>()), "upsample_phase_weights");
+    }
+    F2_CHECK_HIP(hipStreamSynchronize(v->ctx->stream));
     v->finalized = true;
     return FLUX2MI_OK;
 }
@@ -312,17 +323,18 @@ struct Dec {
 
     // resample: 0 none, 1 nearest-2x upsample folded into the gather, -1 stride-2 downsample
     int conv(const ConvW& c, const uint16_t* x, int Hin, int Win, int resample, const uint16_t* resid, uint16_t* y,
-             float* y_f32 = nullptr, uint8_t* y_u8 = nullptr) {
+             float* y_f32 = nullptr, uint8_t* y_u8 = nullptr, const uint16_t* w_phase = nullptr) {
         ConvArgs a;
         memset(&a, 0, sizeof a);
         a.x = x; a.w = W(c.w); a.bias = F(c.b); a.resid = resid; a.y = y; a.y_f32_nchw = y_f32; a.y_u8_hwc = y_u8;
         a.Hin = Hin; a.Win = Win; a.Cin = c.cin; a.Cout = c.cout; a.ks = c.ks;
         a.upsample = resample > 0; a.downsample = resample < 0;
+        a.w_phase = resample > 0 ? w_phase : nullptr;
         const double ho = resample > 0 ? 2.0 * Hin : resample < 0 ? 0.5 * Hin : Hin;
         const double wo = resample > 0 ? 2.0 * Win : resample < 0 ? 0.5 * Win : Win;
         prof_before(v->ctx, PROF_VAE_CONV);
         const int r = launch_conv2d(st, a);
-        prof_after(v->ctx, PROF_VAE_CONV, 2.0 * ho * wo * c.cout * c.cin * c.ks * c.ks);
+        prof_after(v->ctx, PROF_VAE_CONV, 2.0 * ho * wo * c.cout * c.cin * (a.w_phase ? 4 : c.ks * c.ks));
         F2_LAUNCH(r, "conv2d");
         return FLUX2MI_OK;
     }
@@ -420,7 +432,7 @@ extern "C" int flux2mi_vae_decode(flux2mi_vae* v, const float* z, int h, int w, 
             F2_TRY(d.resnet(v->up[i][j], A, B, C, D, H, W));
         }
         if (i < 3) {
-            F2_TRY(d.conv(v->upsample[i], A, H, W, 1, nullptr, B));
+            F2_TRY(d.conv(v->upsample[i], A, H, W, 1, nullptr, B, nullptr, nullptr, v->up_phase[i].ptr ? v->up_phase[i].as<uint16_t>() : nullptr));
             std::swap(A, B);
             H *= 2;
             W *= 2;

@@ -12,6 +12,7 @@
 #include "dev.h"
 #include "kernels.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -165,7 +166,9 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a, int Ho, int Wo,
 // CONSECUTIVE output channels of one pixel: bias, residual and the store are 16 / 8 / 8-byte accesses.
 // TK = 64 (Cin % 64 == 0) or 32 (the 96-channel level of the small decoder: rows of 64 B, which ds_read_b128 reads
 // conflict-free without a swizzle; one MFMA k-step per barrier).
-template <int TK>
+// PH (a.w_phase): the upsampling 3x3 convolution as four 2x2 convolutions on the source image.  The tile runs over SOURCE pixels
+// (Ho, Wo = Hin, Win here), a workgroup takes one phase (py, px) of its pixel block and stores to output pixel (2y + py, 2x + px).
+template <int TK, bool PH = false>
 __global__ __launch_bounds__(256, 2) void conv2d_g128_kernel(ConvArgs a, int Ho, int Wo, int cout_pad) {
     constexpr int TM = 128, TN = 128;
     constexpr int RB = TK * 2;            // bytes per LDS row
@@ -179,22 +182,26 @@ __global__ __launch_bounds__(256, 2) void conv2d_g128_kernel(ConvArgs a, int Ho,
     const int tiles_m = (P + TM - 1) / TM, tiles_n = (a.Cout + TN - 1) / TN;
     // XCD remap: workgroups with equal (blockIdx % 8) share an XCD; give each a contiguous run of tiles, the
     // N-tiles of one pixel block adjacent (they re-read the same activation rows from that XCD's L2)
-    int tm, tn;
+    int tm, tn, ph = 0;
     {
-        const int ntiles = tiles_m * tiles_n, q = ntiles >> 3, r = ntiles & 7;
+        const int ntiles = tiles_m * tiles_n * (PH ? 4 : 1), q = ntiles >> 3, r = ntiles & 7;
         const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
-        const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+        int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+        if (PH) { ph = idx & 3; idx >>= 2; }   // the four phases of a pixel block are neighbours: they read the same source rows
         tm = idx / tiles_n;
         tn = idx - tm * tiles_n;
     }
+    const int py = ph >> 1, px = ph & 1;
     const int m0 = tm * TM, n0 = tn * TN;
-    const int taps = a.ks * a.ks, pad = a.ks >> 1;
+    const int ks = PH ? 2 : a.ks;
+    const int taps = ks * ks, pad = PH ? 0 : (a.ks >> 1);
     const int cblocks = a.Cin / TK;
     const int nk = taps * cblocks;
-    const int up = a.upsample;
+    const int up = PH ? 0 : a.upsample;
     const int stride = a.downsample ? 2 : 1;
     const int pad_tl = a.downsample ? 0 : pad;
     const int Hv = a.Hin << up, Wv = a.Win << up;
+    const uint16_t* wbase = PH ? a.w_phase + (size_t)ph * cout_pad * taps * a.Cin : a.w;
 
     // ---- staging: NP x 16 B per operand per thread: rows t / CPR + (256 / CPR) i, chunk t % CPR
     const int chunk = t % CPR;
@@ -206,16 +213,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_g128_kernel(ConvArgs a, int Ho,
         const int p = m0 + row;
         const bool ok = p < P;
         const int pp = ok ? p : 0;
-        a_y[i] = ok ? (pp / Wo) * stride - pad_tl : -100000;   // a dead row is out of bounds for every tap
-        a_x[i] = (pp % Wo) * stride - pad_tl;
-        w_src[i] = a.w + (size_t)min(n0 + row, cout_pad - 1) * taps * a.Cin + chunk * 8;
+        a_y[i] = ok ? (PH ? pp / Wo + py - 1 : (pp / Wo) * stride - pad_tl) : -100000;   // a dead row is out of bounds for every tap
+        a_x[i] = PH ? pp % Wo + px - 1 : (pp % Wo) * stride - pad_tl;
+        w_src[i] = wbase + (size_t)min(n0 + row, cout_pad - 1) * taps * a.Cin + chunk * 8;
         lds_off[i] = TK == 64 ? row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) : row * 64 + (chunk << 4);
     }
     u32x4 a_reg[NP], w_reg[NP];
 #define CG_LOAD(kt_)                                                                                           \
     {                                                                                                          \
         const int tap_ = (kt_) / cblocks, cb_ = (kt_) - tap_ * cblocks;                                        \
-        const int ky_ = tap_ / a.ks, kx_ = tap_ - ky_ * a.ks;                                                  \
+        const int ky_ = tap_ / ks, kx_ = tap_ - ky_ * ks;                                                      \
         _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) {                                                    \
             const int iy_ = a_y[i_] + ky_, ix_ = a_x[i_] + kx_;                                                \
             u32x4 v_ = {0u, 0u, 0u, 0u};                                                                       \
@@ -279,14 +286,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_g128_kernel(ConvArgs a, int Ho,
         const float4 bs = a.bias ? *reinterpret_cast<const float4*>(a.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int p = m0 + wm * 64 + i * 16 + frow;
-            if (p >= P) continue;
+            const int ps = m0 + wm * 64 + i * 16 + frow;
+            if (ps >= P) continue;
+            const size_t p = PH ? (size_t)(2 * (ps / Wo) + py) * (size_t)(2 * Wo) + (size_t)(2 * (ps % Wo) + px) : (size_t)ps;
             float v0 = acc[i][j][0] + bs.x, v1 = acc[i][j][1] + bs.y, v2 = acc[i][j][2] + bs.z, v3 = acc[i][j][3] + bs.w;
             if (a.resid) {
-                const uint2 rv = *reinterpret_cast<const uint2*>(a.resid + (size_t)p * a.Cout + col);
+                const uint2 rv = *reinterpret_cast<const uint2*>(a.resid + p * a.Cout + col);
                 v0 += lo_bf16(rv.x); v1 += hi_bf16(rv.x); v2 += lo_bf16(rv.y); v3 += hi_bf16(rv.y);
             }
-            *reinterpret_cast<uint2*>(a.y + (size_t)p * a.Cout + col) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            *reinterpret_cast<uint2*>(a.y + p * a.Cout + col) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
         }
     }
 }
@@ -492,9 +500,36 @@ __global__ void nhwc_to_nchw_f32_kernel(const uint16_t* __restrict__ in, float* 
     }
 }
 
+// w_phase[ph][o][a*2+b][c] = sum of w[o][ky][kx][c] over the taps (ky, kx) that read source pixel (a, b) of phase ph = py*2 + px:
+// py = 0: a = 0 <- ky 0, a = 1 <- ky 1, 2;  py = 1: a = 0 <- ky 0, 1, a = 1 <- ky 2 (rows; the same rule for columns)
+__global__ __launch_bounds__(256) void upsample_phase_weights_kernel(const uint16_t* __restrict__ w, int cout_pad, int cin,
+                                                                     uint16_t* __restrict__ wp) {
+    const long total = (long)4 * cout_pad * 4 * cin;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cin);
+        const int tap = (int)((i / cin) & 3);
+        const int o = (int)((i / ((long)cin * 4)) % cout_pad);
+        const int ph = (int)(i / ((long)cin * 4 * cout_pad));
+        const int py = ph >> 1, px = ph & 1, ta = tap >> 1, tb = tap & 1;
+        const int ky0 = py == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2), ky1 = py == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
+        const int kx0 = px == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2), kx1 = px == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
+        float s = 0.f;
+        for (int ky = ky0; ky <= ky1; ++ky)
+            for (int kx = kx0; kx <= kx1; ++kx) s += bf16_bits_to_f32(w[((size_t)o * 9 + ky * 3 + kx) * cin + c]);
+        wp[i] = f32_to_bf16_bits(s);
+    }
+}
+
 }  // namespace
 
 #define VK_DONE() return hipGetLastError() == hipSuccess ? 0 : 2
+
+int launch_upsample_phase_weights(hipStream_t stream, const uint16_t* w, int cout_pad, int cin, uint16_t* w_phase) {
+    if (!w || !w_phase || cout_pad <= 0 || cin <= 0) return 1;
+    const long total = (long)16 * cout_pad * cin;
+    hipLaunchKernelGGL(upsample_phase_weights_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, stream, w, cout_pad, cin, w_phase);
+    VK_DONE();
+}
 
 int launch_conv2d(hipStream_t stream, const ConvArgs& a) {
     if ((a.ks != 1 && a.ks != 3) || a.Cin % CBK != 0 || a.Cout <= 0 || a.Hin <= 0 || a.Win <= 0) return 1;
@@ -513,6 +548,11 @@ int launch_conv2d(hipStream_t stream, const ConvArgs& a) {
         (reinterpret_cast<uintptr_t>(a.y) & 7) == 0 && (!a.resid || (reinterpret_cast<uintptr_t>(a.resid) & 7) == 0) &&
         (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0)) {
         const int tm128 = (P + 127) / 128, tn128 = (a.Cout + 127) / 128;
+        if (a.upsample && a.w_phase && a.ks == 3 && a.Cin % 64 == 0) {   // four 2x2 convolutions over the SOURCE pixels
+            const int tms = (a.Hin * a.Win + 127) / 128;
+            hipLaunchKernelGGL((conv2d_g128_kernel<64, true>), dim3(tms * tn128 * 4), dim3(256), 0, stream, a, a.Hin, a.Win, cout_pad);
+            VK_DONE();
+        }
         if (a.Cin % 64 == 0) hipLaunchKernelGGL(conv2d_g128_kernel<64>, dim3(tm128 * tn128), dim3(256), 0, stream, a, Ho, Wo, cout_pad);
         else hipLaunchKernelGGL(conv2d_g128_kernel<32>, dim3(tm128 * tn128), dim3(256), 0, stream, a, Ho, Wo, cout_pad);
         VK_DONE();

@@ -61,6 +61,17 @@ def test_vae_standard_decoder_channels(flux2mi, ctx):
     _check(*_decode_both(flux2mi, ctx, syn.VAE_PRESETS["standard"], 16, 16))
 
 
+def test_vae_standard_decoder_ragged_upsample_phases(flux2mi, ctx):
+    """The upsampling convolutions of the standard decoder run as four 2x2 convolutions on the source image, one per output phase
+    (vae_kernels.hip, conv2d_g128_kernel<64, true>; combined weights from launch_upsample_phase_weights): a 6x10 latent makes every
+    source-pixel count (60, 240, 960) a partial 128-pixel tile and every phase touch all four borders — against the oracle's
+    upsample-then-3x3 restatement (VAEDecoder.swift:91-121)."""
+    from flux2mi import synthetic as syn
+    of, ou, ref = _decode_both(flux2mi, ctx, syn.VAE_PRESETS["standard"], 6, 10)
+    assert tuple(of.shape) == (1, 3, 48, 80)
+    _check(of, ou, ref)
+
+
 # ---- encoder (SURVEY §8f rank 2: VAE encoder + encodeImageToPackedSequence) ---------------------
 def _image(h, w, seed=3):
     g = torch.Generator().manual_seed(seed)
