@@ -1172,9 +1172,20 @@ extern "C" int flux2mi_dit_forward_kv_cached(flux2mi_dit* m, flux2mi_kv_cache* c
 }
 
 // ------------------------------------------------------------------ standalone ops (tests, microbenchmarks)
+// op entry points: give launch_gemm the context's scratch as split-K workspace where it would split (few 128x128 tiles, long K)
+static int op_splitk_ws(flux2mi_ctx* ctx, GemmProblem& p) {
+    const size_t need = gemm_splitk_ws_bytes(p.M, p.N, p.K);
+    if (!need) return FLUX2MI_OK;
+    F2_TRY(ctx->scratch.reserve(need));
+    p.splitk_ws = ctx->scratch.as<float>();
+    p.splitk_ws_bytes = need;
+    return FLUX2MI_OK;
+}
+
 extern "C" int flux2mi_op_gemm_bf16(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K) {
     F2_REQUIRE(ctx && A && W && C, FLUX2MI_ERR_INVALID_ARG, "op_gemm: NULL argument");
     GemmProblem p = mk(reinterpret_cast<const uint16_t*>(A), K, reinterpret_cast<const uint16_t*>(W), K, C, N, M, N, K, EPI_F32);
+    F2_TRY(op_splitk_ws(ctx, p));
     prof_before(ctx, PROF_DIT_GEMM);
     const int r = launch_gemm(ctx->stream, &p, 1);
     prof_after(ctx, PROF_DIT_GEMM, 2.0 * M * (double)N * K);
@@ -1187,6 +1198,7 @@ extern "C" int flux2mi_op_gemm_bf16(flux2mi_ctx* ctx, const void* A, const void*
 extern "C" int flux2mi_op_gemm_bf16_out_bf16(flux2mi_ctx* ctx, const void* A, const void* W, void* C, int M, int N, int K) {
     F2_REQUIRE(ctx && A && W && C && M > 0 && N > 0 && K > 0, FLUX2MI_ERR_INVALID_ARG, "op_gemm_bf16_out_bf16: bad argument");
     GemmProblem p = mk(reinterpret_cast<const uint16_t*>(A), K, reinterpret_cast<const uint16_t*>(W), K, C, N, M, N, K, EPI_BF16);
+    F2_TRY(op_splitk_ws(ctx, p));
     prof_before(ctx, PROF_DIT_GEMM);
     const int r = launch_gemm(ctx->stream, &p, 1);
     prof_after(ctx, PROF_DIT_GEMM, 2.0 * M * (double)N * K);
@@ -1217,6 +1229,7 @@ extern "C" int flux2mi_op_gemm_gate_resid(flux2mi_ctx* ctx, const void* A, const
     F2_REQUIRE(ctx && A && W && gate && X && M > 0 && N > 0 && K > 0, FLUX2MI_ERR_INVALID_ARG, "op_gemm_gate_resid: bad argument");
     GemmProblem p = mk(reinterpret_cast<const uint16_t*>(A), K, reinterpret_cast<const uint16_t*>(W), K, X, N, M, N, K, EPI_GATE_RESID);
     p.vec = gate;
+    F2_TRY(op_splitk_ws(ctx, p));
     prof_before(ctx, PROF_DIT_GEMM);
     const int r = launch_gemm(ctx->stream, &p, 1);
     prof_after(ctx, PROF_DIT_GEMM, 2.0 * M * (double)N * K);

@@ -64,8 +64,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128x128_kernel(GemmBatch bat
     const int bid = blockIdx.x;
     const int pi = (batch.nprob > 1 && bid >= batch.tile_start1) ? 1 : 0;
     const GemmProblem& p = batch.p[pi];
-    const int local = bid - (pi ? batch.tile_start1 : 0);
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    // split-K (single-problem launches): workgroup = (K range `split`, tile `local`), split-major
+    const int splits = batch.splits;
+    const int split = splits > 1 ? bid / (tiles_m * tiles_n) : 0;
+    const int local = splits > 1 ? bid - split * (tiles_m * tiles_n) : bid - (pi ? batch.tile_start1 : 0);
     int tm, tn;
     tile_coords(local, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
@@ -120,12 +123,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128x128_kernel(GemmBatch bat
         w_off[i] = (wn * 64 + i * 16 + frow) * 128;
     }
 
-    const int nk = p.K / BK;
-    GEMM_LOAD_TILE(0)
-    GEMM_STORE_TILE(0)
+    const int nk_all = p.K / BK;
+    const int kt0 = (int)((long)nk_all * split / splits), nk = (int)((long)nk_all * (split + 1) / splits);   // this workgroup's K-tiles [kt0, nk)
+    GEMM_LOAD_TILE(kt0)
+    GEMM_STORE_TILE(kt0 & 1)
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) { GEMM_LOAD_TILE(kt + 1) }
         const uint8_t* sa = smem + buf * (2 * BM * BK * 2);
@@ -155,7 +159,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128x128_kernel(GemmBatch bat
     int epi = p.epi;
     if (epi == EPI_QKV_MLP) epi = (n0 >= p.n_split) ? EPI_SWIGLU : EPI_BF16;
 
-    if (epi == EPI_F32) {
+    if (splits > 1) {   // the partial accumulator of this K range: ws[split][row][col] f32 (gemm_splitk_reduce_kernel finishes the job)
+        float* C = p.splitk_ws + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row_base + i * 16 + r;
+                if (row < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = col_base + j * 16;
+                        if (col < p.N) C[(size_t)row * p.N + col] = acc[i][j][r];
+                    }
+                }
+            }
+    } else if (epi == EPI_F32) {
         float* C = reinterpret_cast<float*>(p.C);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -262,6 +281,30 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128x128_kernel(GemmBatch bat
     }
 }
 
+// Split-K, second half: the partial accumulators of a tile's K ranges are added in split order (fixed: bit-reproducible) and the
+// problem's epilogue is applied — the same arithmetic as the one-pass epilogues above on the summed accumulator.
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmProblem p, int splits) {
+    const long total = (long)p.M * p.N;
+    const size_t plane = (size_t)p.M * p.N;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int row = (int)(idx / p.N), col = (int)(idx - (long)row * p.N);
+        float acc = p.splitk_ws[idx];
+        for (int s = 1; s < splits; ++s) acc += p.splitk_ws[(size_t)s * plane + idx];
+        if (p.epi == EPI_F32) {
+            reinterpret_cast<float*>(p.C)[(size_t)row * p.ldc + col] = acc * p.alpha;
+        } else if (p.epi == EPI_BF16) {
+            reinterpret_cast<uint16_t*>(p.C)[(size_t)row * p.ldc + col] = f32_to_bf16_bits(acc * p.alpha);
+        } else if (p.epi == EPI_GATE_RESID) {
+            float* dst = reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + col;
+            *dst = *dst + p.vec[col] * acc;
+        } else {   // EPI_BIAS_BF16
+            float v = acc * p.alpha + (p.vec ? p.vec[col] : 0.f);
+            if (p.resid) v += bf16_bits_to_f32(p.resid[(size_t)row * p.ldr + col]);
+            reinterpret_cast<uint16_t*>(p.C)[(size_t)row * p.ldc + col] = f32_to_bf16_bits(v);
+        }
+    }
+}
+
 // Fallback for shapes the MFMA kernel does not take (K % 64 != 0), e.g. the VAE's
 // 32->32 post_quant_conv.  One thread per output element, f32 accumulate.
 __global__ void gemm_naive_kernel(GemmProblem p) {
@@ -284,6 +327,23 @@ __global__ void gemm_naive_kernel(GemmProblem p) {
 }
 
 }  // namespace
+
+// K ranges per tile for the 128x128 kernel: only when its tiles would fill less than half of the 512 workgroup slots (2 per CU x 256)
+// and every range keeps >= 8 K-tiles; as many ranges as fit the slots, at most 8.
+static int gemm_splitk_plan(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K % BK != 0) return 1;
+    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int nk = K / BK;
+    if (tiles > 256 || nk < 16) return 1;
+    long s = 512 / tiles;
+    if (s > 8) s = 8;
+    if (s > nk / 8) s = nk / 8;
+    return s < 2 ? 1 : (int)s;
+}
+size_t gemm_splitk_ws_bytes(int M, int N, int K) {
+    const int s = gemm_splitk_plan(M, N, K);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
 
 int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
     if (nprob < 1 || nprob > 2) return 1;
@@ -365,6 +425,17 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
     }
     if (nprob == 1) b.p[1] = probs[0];
     b.tile_start1 = tiles[0];
-    hipLaunchKernelGGL(gemm_bf16_128x128_kernel, dim3(tiles[0] + tiles[1]), dim3(256), 0, stream, b);
+    b.splits = 1;
+    if (nprob == 1 && probs[0].splitk_ws != nullptr) {
+        const GemmProblem& q = probs[0];
+        const int s = gemm_splitk_plan(q.M, q.N, q.K);
+        const bool epi_ok = q.epi == EPI_F32 || q.epi == EPI_BF16 || q.epi == EPI_GATE_RESID || q.epi == EPI_BIAS_BF16;
+        if (s > 1 && epi_ok && q.splitk_ws_bytes >= (size_t)s * q.M * q.N * sizeof(float)) b.splits = s;
+    }
+    hipLaunchKernelGGL(gemm_bf16_128x128_kernel, dim3((tiles[0] + tiles[1]) * b.splits), dim3(256), 0, stream, b);
+    if (b.splits > 1) {
+        const long total = (long)probs[0].M * probs[0].N;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), dim3(256), 0, stream, probs[0], b.splits);
+    }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

@@ -55,6 +55,12 @@ struct GemmProblem {
     // (the key order of the attention's V^T operand, attention.hip).  With A = W_v [dim, K], W = the activation
     // [S, K] and C = vt [dim, s_pad] the GEMM writes V^T directly: no V round trip, no transpose kernel.
     int col_perm16;
+    // 128x128 kernel, single-problem launches with few tiles and a long K (the text encoders' M = 512 projections): split-K.
+    // splitk_ws (>= gemm_splitk_ws_bytes(M, N, K) bytes of device scratch) lets launch_gemm cut K into `splits` ranges, one
+    // workgroup each per tile; the partial accumulators go to the workspace and a second kernel adds them IN SPLIT ORDER and
+    // applies the epilogue (EPI_F32 / EPI_BF16 / EPI_GATE_RESID / EPI_BIAS_BF16): deterministic, no atomics.  nullptr = off.
+    float* splitk_ws;
+    size_t splitk_ws_bytes;
     const uint16_t* qk_qw;
     const uint16_t* qk_kw;
     const float* qk_pos;
@@ -67,8 +73,11 @@ struct GemmBatch {
     int tile_start1;
     int flags;    // gemm256: bit 0 = 16-byte bf16 epilogue stores
     unsigned long long* trace;   // gemm256: per-wave time stamps (dev tool), nullptr normally
+    int splits;   // 128x128 kernel: K ranges per tile (1 = whole K in one workgroup)
 };
 int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob);
+// Workspace launch_gemm wants in GemmProblem::splitk_ws to split the K dimension of a bf16 [M,K] x [N,K]^T product (0 = it would not split)
+size_t gemm_splitk_ws_bytes(int M, int N, int K);
 
 // ---------------------------------------------------------------- attention (attention.hip)
 // Joint (text+image) non-causal attention, head_dim 128, bf16 in/out, f32 softmax.

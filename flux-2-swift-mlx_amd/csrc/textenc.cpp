@@ -42,6 +42,7 @@ struct flux2mi_textenc {
     uint16_t* embed = nullptr;
     DevBuf stage_raw, stage_bf16, stage_gu;
     DevBuf hs, xn, qkv, vt, attn, hid, ones;
+    DevBuf splitk_ws;                   // partial accumulators of the split-K projections (S = 512: few tiles, long K)
 };
 
 namespace {
@@ -148,7 +149,7 @@ extern "C" int flux2mi_textenc_destroy(flux2mi_textenc* m) {
     (void)hipStreamSynchronize(m->ctx->stream);
     for (TBuf& b : m->bufs)
         if (b.ptr) (void)hipFree(b.ptr);
-    DevBuf* ws[] = {&m->stage_raw, &m->stage_bf16, &m->stage_gu, &m->hs, &m->xn, &m->qkv, &m->vt, &m->attn, &m->hid, &m->ones};
+    DevBuf* ws[] = {&m->stage_raw, &m->stage_bf16, &m->stage_gu, &m->hs, &m->xn, &m->qkv, &m->vt, &m->attn, &m->hid, &m->ones, &m->splitk_ws};
     for (DevBuf* w : ws) w->release();
     delete m;
     return FLUX2MI_OK;
@@ -248,6 +249,14 @@ extern "C" int flux2mi_textenc_forward(flux2mi_textenc* m, const int32_t* ids, i
         F2_CHECK_HIP(hipMemcpyAsync(m->ones.ptr, one.data(), (size_t)d * 4, hipMemcpyHostToDevice, st));
         F2_CHECK_HIP(hipStreamSynchronize(st));
     }
+    // the qkv / o / down projections have M = S rows: at 512 tokens their 128x128 tiles fill a fifth to a third of the chip, so
+    // launch_gemm splits their K (deterministic, kernels.h GemmProblem::splitk_ws) when given a workspace
+    const size_t ws_bytes = std::max(gemm_splitk_ws_bytes(S, nqkv, d), std::max(gemm_splitk_ws_bytes(S, d, nq), gemm_splitk_ws_bytes(S, d, I)));
+    if (ws_bytes) F2_TRY(m->splitk_ws.reserve(ws_bytes));
+    auto with_ws = [&](GemmProblem& p) {
+        p.splitk_ws = ws_bytes ? m->splitk_ws.as<float>() : nullptr;
+        p.splitk_ws_bytes = ws_bytes;
+    };
     float* hs = m->hs.as<float>();
     uint16_t* xn = m->xn.as<uint16_t>();
     uint16_t* qkv = m->qkv.as<uint16_t>();
@@ -263,6 +272,7 @@ extern "C" int flux2mi_textenc_forward(flux2mi_textenc* m, const int32_t* ids, i
         F2_LAUNCH(launch_rmsnorm_rows(st, hs, w.ln_in, xn, S, d, c.rms_eps), "input_layernorm");
         {
             GemmProblem p = te_mk(xn, d, w.qkv, d, qkv, nqkv, S, nqkv, d, EPI_BF16);
+            with_ws(p);
             F2_LAUNCH(launch_gemm(st, &p, 1), "qkv_proj");
         }
         F2_LAUNCH(launch_qk_norm_rope_llm_vt(st, qkv, S, hq, hkv, c.qk_norm ? w.qn : nullptr, c.qk_norm ? w.kn : nullptr,
@@ -272,6 +282,7 @@ extern "C" int flux2mi_textenc_forward(flux2mi_textenc* m, const int32_t* ids, i
         {
             GemmProblem p = te_mk(attn, nq, w.o, nq, hs, d, S, d, nq, EPI_GATE_RESID);
             p.vec = m->ones.as<float>();
+            with_ws(p);
             F2_LAUNCH(launch_gemm(st, &p, 1), "o_proj");
         }
         F2_LAUNCH(launch_rmsnorm_rows(st, hs, w.ln_post, xn, S, d, c.rms_eps), "post_attention_layernorm");
@@ -283,6 +294,7 @@ extern "C" int flux2mi_textenc_forward(flux2mi_textenc* m, const int32_t* ids, i
         {
             GemmProblem p = te_mk(hid, I, w.down, I, hs, d, S, d, I, EPI_GATE_RESID);
             p.vec = m->ones.as<float>();
+            with_ws(p);
             F2_LAUNCH(launch_gemm(st, &p, 1), "down_proj");
         }
         if (next < 3 && c.extract_layers[next] == l + 1) {   // 1-based: "after layer l + 1" (Qwen3Model.swift:147-165)

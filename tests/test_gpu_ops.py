@@ -510,3 +510,44 @@ def test_mfma_stream_probe(ctx):
     assert 800.0 < bf16 < 2600.0, bf16
     assert 1600.0 < fp8 < 5200.0, fp8
     assert fp8 > 1.5 * bf16
+
+
+# ---- split-K of the 128x128 kernel (few tiles, long K: the text encoders' M = 512 projections) ----------
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [
+    (512, 2560, 9728),   # Qwen3-4B down_proj: 80 tiles, 152 K-tiles -> 6 K ranges
+    (512, 2560, 4096),   # o_proj: 6 ranges of 10-11 K-tiles
+    (512, 6144, 2560),   # qkv_proj: 192 tiles -> 2 ranges
+    (500, 2500, 4096),   # ragged rows and columns
+    (128, 128, 1024),    # one tile, 16 K-tiles -> 2 ranges of 8
+    (384, 640, 1088),    # 17 K-tiles: uneven ranges
+])
+def test_gemm_split_k_exact_all_epilogues(ctx, M, N, K):
+    """launch_gemm cuts the K dimension of such launches into ranges (one workgroup per tile and range), parks the partial
+    accumulators in a workspace and a second kernel adds them in range order and applies the epilogue (gemm.hip,
+    gemm_splitk_reduce_kernel).  Integer-valued operands make every partial sum exact: f32, bf16-rounded and gate + residual
+    outputs must equal the reference bit for bit, on repeated launches."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randint(-2, 3, (M, K), generator=g, device="cuda").to(torch.bfloat16)
+    w = torch.randint(-2, 3, (N, K), generator=g, device="cuda").to(torch.bfloat16)
+    ref = a.float() @ w.float().t()
+    gate = torch.randint(-2, 3, (N,), generator=g, device="cuda").float()
+    x0 = torch.randint(-8, 9, (M, N), generator=g, device="cuda").float()
+    for _ in range(3):
+        assert torch.equal(ctx.op_gemm_bf16(a, w), ref)
+        out16 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        ctx.op_gemm_bf16_out_bf16(a, w, out16)
+        ctx.sync()
+        assert torch.equal(out16, ref.to(torch.bfloat16))
+        assert torch.equal(ctx.op_gemm_gate_resid(a, w, gate, x0.clone()), x0 + gate[None, :] * ref)
+
+
+@pytest.mark.gpu
+def test_gemm_split_k_random_deterministic(ctx):
+    g = torch.Generator(device="cuda").manual_seed(9)
+    a = torch.randn((512, 9728), generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn((2560, 9728), generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    outs = [ctx.op_gemm_bf16(a, w) for _ in range(4)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    assert rel_l2(outs[0].cpu(), (a.float() @ w.float().t()).cpu()) < 2e-3
