@@ -91,6 +91,7 @@ struct flux2mi_dit {
     DevBuf stage_raw, stage_bf16, stage_w, stage_d, stage_q8;
     // forward workspace
     DevBuf hs, xn, qkv, vt, comb, mods, rope, lat_bf16, xq, xs;
+    DevBuf splitk_ws;   // proj_out ([s_out, d] x [128, d]^T: 32 tiles of 128x128 at 1024^2, 48 K-tiles): split-K workspace (kernels.h)
     int ws_S = 0;
 };
 
@@ -322,7 +323,7 @@ extern "C" int flux2mi_dit_destroy(flux2mi_dit* m) {
         if (b.scale) (void)hipFree(b.scale);
     }
     DevBuf* ws[] = {&m->stage_raw, &m->stage_bf16, &m->stage_w, &m->stage_d, &m->stage_q8, &m->hs, &m->xn, &m->qkv, &m->vt, &m->comb, &m->mods,
-                    &m->rope, &m->lat_bf16, &m->xq, &m->xs};
+                    &m->rope, &m->lat_bf16, &m->xq, &m->xs, &m->splitk_ws};
     for (DevBuf* w : ws) w->release();
     delete m;
     return FLUX2MI_OK;
@@ -1071,6 +1072,12 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
               "ln_mod(final)");
     {
         GemmProblem p = mk(xn, d, m->final_lin, d, out, 128, s_out, 128, d, EPI_F32);
+        const size_t ws = gemm_splitk_ws_bytes(s_out, 128, d);
+        if (ws) {
+            F2_TRY(m->splitk_ws.reserve(ws));
+            p.splitk_ws = m->splitk_ws.as<float>();
+            p.splitk_ws_bytes = ws;
+        }
         F2_TRY(run_gemm(m, &p, 1, 0, "proj_out"));
     }
     if (mode == FWD_KV_EXTRACT) cache->filled = true;
