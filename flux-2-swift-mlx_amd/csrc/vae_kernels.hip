@@ -456,6 +456,44 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int c = threadIdx.x; c < cols; c += 256) o[c] = f32_to_bf16_bits(__expf(r[c] - mx) * inv);
 }
 
+// The same softmax with the row held in registers (cols <= 256 threads x 16 float4, cols % 4 == 0: the VAE mid-block attention's
+// 16384 keys at 1024^2): one 16-byte read per 4 scores, one 8-byte write per 4 probabilities, every exponential computed once.
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int cols) {
+    __shared__ float red[4];
+    const float4* r = reinterpret_cast<const float4*>(in + (size_t)blockIdx.x * cols);
+    uint2* o = reinterpret_cast<uint2*>(out + (size_t)blockIdx.x * cols);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nvec = cols >> 2;
+    float4 v[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        v[i] = c < nvec ? r[c] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        mx = fmaxf(mx, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wid] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        v[i].x = __expf(v[i].x - mx); v[i].y = __expf(v[i].y - mx); v[i].z = __expf(v[i].z - mx); v[i].w = __expf(v[i].w - mx);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wid] = s;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < nvec) o[c] = make_uint2(pack_bf16x2(v[i].x * inv, v[i].y * inv), pack_bf16x2(v[i].z * inv, v[i].w * inv));
+    }
+}
+
 __global__ void transpose_bf16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int rows, int cols) {
     __shared__ uint16_t tile[32][34];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -619,7 +657,10 @@ int launch_nchw_f32_to_nhwc_bf16(hipStream_t stream, const float* in, uint16_t* 
 }
 int launch_softmax_rows(hipStream_t stream, const float* in, uint16_t* out, int rows, int cols) {
     if (rows <= 0 || cols <= 0) return 1;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, in, out, cols);
+    if ((cols & 3) == 0 && cols <= 256 * 64 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0)
+        hipLaunchKernelGGL(softmax_rows_reg_kernel, dim3(rows), dim3(256), 0, stream, in, out, cols);
+    else
+        hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, in, out, cols);
     VK_DONE();
 }
 int launch_transpose_bf16(hipStream_t stream, const uint16_t* in, uint16_t* out, int rows, int cols) {
