@@ -54,6 +54,8 @@ def parse_args(argv=None):
                          "offset otherwise (what a checkpoint with larger norm scales gets: exact for any scores); "
                          "online: force the data-offset form in every block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mfma-stream", action="store_true",
+                    help="skip the register-only MFMA stream after the timed region (roofline.mfma_stream): profiler runs")
     ap.add_argument("--prof-class", type=int, default=0, help="kernel class timed with HIP events (0 = linear1 GEMM)")
     ap.add_argument("--dry-run", action="store_true", help="harness self-test on CPU/gloo: no GPU, no compute")
     return ap.parse_args(argv)
@@ -254,10 +256,11 @@ def main():
         # what the matrix pipe of THIS card sustains at its power cap (register-only MFMA stream, ~0.6 s, after the timed region):
         # the ceiling a perfect kernel would see here; `peak` stays the data-sheet figure
         stream_tf = None
-        try:
-            stream_tf = round(pipe.ctx.mfma_stream_tflops(fp8=(args.weights == "fp8")), 1)
-        except Exception as e:   # diagnostic only
-            print(f"[bench] mfma stream probe failed: {e}", file=sys.stderr)
+        if not args.no_mfma_stream:
+            try:
+                stream_tf = round(pipe.ctx.mfma_stream_tflops(fp8=(args.weights == "fp8")), 1)
+            except Exception as e:   # diagnostic only
+                print(f"[bench] mfma stream probe failed: {e}", file=sys.stderr)
         roofline = {"bound": "mfma", "kernel": pipe.ctx.prof_kernel_name(args.prof_class),
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,

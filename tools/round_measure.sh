@@ -10,7 +10,7 @@ python bench.py --steps 3 --warmup 1 --no-cpu-baseline --weights fp8 > $O/bench_
 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --attn-softmax online > $O/bench_online_softmax.json.log 2>>$O/bench.err || exit 1
 python tools/run_configs.py A D D8 C E K T > $O/configs.jsonl 2>>$O/bench.err || exit 1
 tail -8 $O/configs.jsonl | cut -c1-200
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/prof.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-mfma-stream > $O/prof.log 2>&1 || exit 1
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 tools/one_forward.py klein-4b 2 > $O/fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 tools/one_forward.py klein-4b 2 > $O/write.log 2>&1 || exit 1
