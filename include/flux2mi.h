@@ -463,7 +463,8 @@ int flux2mi_op_groupnorm_silu(flux2mi_ctx* ctx, const void* x, void* y, long lon
 /* joint attention: qkv bf16 [S, 3*heads*128] (q|k|v, already normalised/rotated) -> out bf16 [S, heads*128] */
 int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv, void* out, int S, int heads);
 /* the form the blocks run: q pre-multiplied by log2(e)/sqrt(128), |q.k| <= score_bound_log2 in that domain -> softmax against a
-   fixed zero offset when 0 < bound <= 80 (Flux2Attention.swift:168-174 after the QK RMSNorm bounds the scores) */
+   fixed zero offset when 0 < bound <= 80 (Flux2Attention.swift:168-174 after the QK RMSNorm bounds the scores); bound <= 0
+   (unknown) or > 80: a per-query offset taken from the data, exact for any scores (attention64b.hip, DOFF) */
 int flux2mi_op_attention_prescaled(flux2mi_ctx* ctx, const void* qkv, void* out, int S, int heads, float score_bound_log2);
 
 #ifdef __cplusplus
