@@ -551,3 +551,31 @@ def test_gemm_split_k_random_deterministic(ctx):
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
     assert rel_l2(outs[0].cpu(), (a.float() @ w.float().t()).cpu()) < 2e-3
+
+
+@pytest.mark.gpu
+def test_attention_prescaled_random_shapes(ctx):
+    """A seeded sweep of 24 sequence lengths (1 .. 1500, most of them not multiples of the 64-key tile or the 256-query block) x 1-4
+    heads through both softmax forms of the one-wave-per-SIMD kernel (fixed zero offset with a valid bound, per-query data offset
+    without one) against the oracle: prologue-only, tail-only and loop paths, clamped K rows and masked row sums at every remainder."""
+    import math
+    import random
+    rng = random.Random(2024)
+    c = math.log2(math.e) / math.sqrt(128.0)
+    cases = [(1, 1), (63, 2), (65, 1), (129, 3), (255, 2), (257, 1)] + [(rng.randint(1, 1500), rng.randint(1, 4)) for _ in range(18)]
+    for S, heads in cases:
+        g = torch.Generator().manual_seed(S * 13 + heads)
+        d = heads * 128
+        x = torch.randn((S, 3 * d), generator=g)
+        q = x[:, :d].view(S, heads, 128)
+        k = x[:, d:2 * d].view(S, heads, 128)
+        q = q / q.pow(2).mean(-1, keepdim=True).sqrt()
+        k = k / k.pow(2).mean(-1, keepdim=True).sqrt()
+        qkv = torch.cat([(q * c).reshape(S, d), k.reshape(S, d), x[:, 2 * d:]], dim=1).to(torch.bfloat16)
+        qs, ks, vs = qkv.float().split(d, dim=1)
+        hv = lambda t: t.reshape(1, S, heads, 128).permute(0, 2, 1, 3)
+        ref = R.sdpa(hv(qs / c), hv(ks), hv(vs)).permute(0, 2, 1, 3).reshape(S, d)
+        for bound in (128.0 * c, 0.0):
+            out = ctx.op_attention_prescaled(qkv.cuda(), heads, bound)
+            assert torch.isfinite(out).all(), (S, heads, bound)
+            assert rel_l2(out, ref) < 1e-2, (S, heads, bound, rel_l2(out, ref))
