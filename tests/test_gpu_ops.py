@@ -579,3 +579,23 @@ def test_attention_prescaled_random_shapes(ctx):
             out = ctx.op_attention_prescaled(qkv.cuda(), heads, bound)
             assert torch.isfinite(out).all(), (S, heads, bound)
             assert rel_l2(out, ref) < 1e-2, (S, heads, bound, rel_l2(out, ref))
+
+
+@pytest.mark.gpu
+def test_gemm_random_shapes_exact(ctx):
+    """A seeded sweep of 20 shapes over the dispatch (128x128 kernel with and without split-K, gemm256s at every tile height, ragged
+    M and N, 1 .. 64 K-tiles) on integer-valued operands: the f32 result must equal the reference bit for bit, and the bf16-stored
+    form its rounding."""
+    import random
+    rng = random.Random(77)
+    cases = [(1, 1, 64), (257, 255, 128), (4607, 3071, 192), (5000, 4097, 64), (33, 8192, 1024), (2048, 2048, 4096)]
+    cases += [(rng.randint(1, 5000), rng.randint(1, 6500), 64 * rng.randint(1, 40)) for _ in range(14)]
+    for M, N, K in cases:
+        g = torch.Generator(device="cuda").manual_seed(M * 31 + N * 7 + K)
+        a = torch.randint(-2, 3, (M, K), generator=g, device="cuda").to(torch.bfloat16)
+        w = torch.randint(-2, 3, (N, K), generator=g, device="cuda").to(torch.bfloat16)
+        ref = a.float() @ w.float().t()
+        assert torch.equal(ctx.op_gemm_bf16(a, w), ref), (M, N, K)
+        out16 = ctx.op_gemm_bf16_out_bf16(a, w)
+        ctx.sync()
+        assert torch.equal(out16, ref.to(torch.bfloat16)), (M, N, K)
