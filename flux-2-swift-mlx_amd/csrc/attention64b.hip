@@ -76,7 +76,16 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
     __shared__ int s_again;               // DOFF: some wave of the workgroup asks for another pass
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int c16 = lane & 15, g4 = lane >> 4;
-    const int head = blockIdx.y, q0 = blockIdx.x * 256 + wid * 64;
+    // Workgroup -> (head, query block).  Workgroups are dealt to the 8 XCDs round-robin in launch order (id % 8); with the head count a
+    // multiple of 8, XCD x takes heads x, x + 8, ... and runs the query blocks of one head back to back, so that the workgroups of a head
+    // stream its K / V^T through ONE L2 instead of eight.
+    int head = blockIdx.y, qblk = blockIdx.x;
+    if ((gridDim.y & 7) == 0) {
+        const int id = blockIdx.y * gridDim.x + blockIdx.x, xcd = id & 7, k = id >> 3;
+        head = (k / (int)gridDim.x) * 8 + xcd;
+        qblk = k % (int)gridDim.x;
+    }
+    const int q0 = qblk * 256 + wid * 64;
     const int nt = (S + BKV - 1) / BKV;   // the last tile may be partial: its missing keys score against key S - 1 again (clamped rows) and are
                                           // kept out of the row sums by a masked ones operand; V^T is zero there (s_pad >= 64 nt, producers clear it)
 
