@@ -12,6 +12,8 @@ python tools/run_configs.py A D D8 C E K T > $O/configs.jsonl 2>>$O/bench.err ||
 tail -8 $O/configs.jsonl | cut -c1-200
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-mfma-stream > $O/prof.log 2>&1 || exit 1
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv
+python3 tools/linear1_from_trace.py $O/prof $O/linear1_rocprof.json
+grep '^{"metric' $O/prof.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('bench roofline.avg_launch_ms (HIP events) of the same run:', d['roofline']['avg_launch_ms'], 'over', d['roofline']['launches'], 'launches')" | tee $O/linear1_bench_events.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 tools/one_forward.py klein-4b 2 > $O/fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 tools/one_forward.py klein-4b 2 > $O/write.log 2>&1 || exit 1
 python3 tools/pmc_summary.py $O/fetch > $O/pmc_fetch_size.txt
