@@ -140,6 +140,7 @@ PROTOTYPES = {
     "flux2mi_dit_attention_softmax_info": (_I, [_P, _PI, _PI]),
     "flux2mi_kv_cache_create": (_I, [_P, _I, _I, C.POINTER(_P)]),
     "flux2mi_kv_cache_destroy": (_I, [_P]),
+    "flux2mi_kv_cache_entry": (_I, [_P, _I, _P, _P]),
     "flux2mi_dit_forward_kv_extract": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _F, _F, _P, _P, _P, _P]),
     "flux2mi_dit_forward_kv_cached": (_I, [_P, _P, _P, _I, _P, _I, _F, _F, _P, _P, _P]),
     "flux2mi_textenc_preset": (_I, [C.c_char_p, C.POINTER(TextEncConfig)]),
@@ -166,7 +167,6 @@ PROTOTYPES = {
     "flux2mi_prof_end": (_I, [_P, _PI, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "flux2mi_op_gemm_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I]),
     "flux2mi_op_gemm_bf16_out_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I]),
-    "flux2mi_op_gemm_bf16_ex": (_I, [_P, _P, _I, C.c_longlong, _P, _I, C.c_longlong, _P, _I, _I, _I]),
     "flux2mi_op_gemm_fp8": (_I, [_P, _P, _P, _P, _I, _I, _I]),
     "flux2mi_op_gemm_gate_resid": (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
     "flux2mi_op_layernorm_modulate": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
@@ -175,6 +175,7 @@ PROTOTYPES = {
     "flux2mi_op_groupnorm_silu": (_I, [_P, _P, _P, C.c_longlong, _I, _I, _P, _P, _F, _I]),
     "flux2mi_op_attention": (_I, [_P, _P, _P, _I, _I]),
     "flux2mi_op_attention_prescaled": (_I, [_P, _P, _P, _I, _I, C.c_float]),
+    "flux2mi_op_attention_prescaled_range": (_I, [_P, _P, _P, _I, _I, C.c_float, _I, _I, _I]),
 }
 
 _lib = None

@@ -309,13 +309,6 @@ class Context:
         return n.value, ms.value, fl.value
 
     # ---- standalone ops
-    def op_gemm_bf16_ex(self, a, lda, a_kstride, w, ldw, w_kstride, m, n, k) -> torch.Tensor:
-        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
-        self._enter()
-        check(lib().flux2mi_op_gemm_bf16_ex(self.handle, _ptr(a), lda, a_kstride, _ptr(w), ldw, w_kstride, _ptr(out), m, n, k))
-        self._exit()
-        return out
-
     def op_gemm_bf16(self, a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
         a, w = _req(a, torch.bfloat16, "A"), _req(w, torch.bfloat16, "W")
         m, k = a.shape
@@ -413,6 +406,17 @@ class Context:
         out = torch.empty((s, heads * 128), dtype=torch.bfloat16, device=qkv.device)
         self._enter()
         check(lib().flux2mi_op_attention_prescaled(self.handle, _ptr(qkv), _ptr(out), s, heads, float(score_bound_log2)))
+        self._exit()
+        return out
+
+    def op_attention_prescaled_range(self, qkv: torch.Tensor, heads: int, score_bound_log2: float, q0: int, nq: int, nk: int) -> torch.Tensor:
+        """Queries [q0, q0+nq) against the key prefix [0, nk) of the full V^T image (the KV-extraction pass's launch shape);
+        rows outside the query range come back zero."""
+        qkv = _req(qkv, torch.bfloat16, "qkv")
+        s = qkv.shape[0]
+        out = torch.zeros((s, heads * 128), dtype=torch.bfloat16, device=qkv.device)
+        self._enter()
+        check(lib().flux2mi_op_attention_prescaled_range(self.handle, _ptr(qkv), _ptr(out), s, heads, float(score_bound_log2), q0, nq, nk))
         self._exit()
         return out
 
@@ -709,6 +713,18 @@ class KVCache:
         h = C.c_void_p()
         check(lib().flux2mi_kv_cache_create(dit.handle, s_txt, s_ref, C.byref(h)))
         self.handle = h
+        self.s_txt, self.s_ref = s_txt, s_ref
+
+    def entry(self, layer: int):
+        """`doubleStreamEntry(at:)` / `singleStreamEntry(at:)` (layer = double blocks, then single blocks): (keys bf16 [s_ref, dim]
+        post-RoPE, values bf16 [s_ref, dim])."""
+        d = self.dit.cfg.dim
+        keys = torch.empty((self.s_ref, d), dtype=torch.bfloat16, device=self.dit.ctx.device)
+        vt = torch.empty((d, self.s_ref), dtype=torch.bfloat16, device=self.dit.ctx.device)
+        self.dit.ctx._enter()
+        check(lib().flux2mi_kv_cache_entry(self.handle, layer, _ptr(keys), _ptr(vt)))
+        self.dit.ctx._exit()
+        return keys, vt.t().contiguous()
 
     def close(self):
         if self.handle and self.dit.handle and self.dit.ctx.handle:

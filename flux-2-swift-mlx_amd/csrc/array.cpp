@@ -7,6 +7,7 @@
 // the Swift shim's `MLXArray` is a handle to one of these: an f32 device tensor of <= 4 dims on the context's stream.
 // Every op is eager (enqueued, not synchronised); `eval` is flux2mi_ctx_sync.  Values are immutable like MLX's: ops
 // return new arrays, except that flux2mi_array_wrap gives a view over caller memory (the hook's latent buffer).
+#include <stdint.h>
 #include <string.h>
 
 #include "common.h"
@@ -33,7 +34,7 @@ int make(flux2mi_ctx* ctx, const int64_t* shape, int ndim, bool alloc, flux2mi_a
     a->ctx = ctx;
     a->ndim = ndim;
     for (int i = 0; i < ndim; ++i) {
-        if (shape[i] <= 0 || shape[i] > (int64_t)1 << 31) { delete a; flux2mi_set_error("array: dim %d is %lld", i, (long long)shape[i]); return FLUX2MI_ERR_SHAPE; }
+        if (shape[i] <= 0 || shape[i] > (int64_t)INT32_MAX) {   // binary() narrows dims to int delete a; flux2mi_set_error("array: dim %d is %lld", i, (long long)shape[i]); return FLUX2MI_ERR_SHAPE; }
         a->shape[i] = shape[i];
     }
     if (a->numel() > (int64_t)1 << 40) { delete a; flux2mi_set_error("array: too many elements"); return FLUX2MI_ERR_SHAPE; }

@@ -467,8 +467,6 @@ __global__ __launch_bounds__(NW * 64) void attn_combine_kernel(uint16_t* __restr
 
 }  // namespace
 
-int launch_attention64(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
-                       int ldo, int Sq, int S, int heads);   // experimental/attention64.hip (MFMA 32x32x16; dev library only)
 int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
                         int ldo, int Sq, int S, int heads, bool data_offset);  // attention64b.hip (MFMA 16x16x32)
 
@@ -538,14 +536,9 @@ int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, i
     // bound allows it and with its per-query data offset otherwise (the "online" count of flux2mi_dit_attention_softmax_info).
     // FLUX2MI_ATTN64=0 with the dev library keeps the kernel below (A/B runs)
     if (q_prescaled && fx != 1 && !nw_env) {
-        static const int a64 = [] { const char* e = F2_DEV_ENV("FLUX2MI_ATTN64"); return e ? atoi(e) : 2; }();   // dev: 0 = the kernel below, 1 = the 32x32x16 form
+        static const int a64 = [] { const char* e = F2_DEV_ENV("FLUX2MI_ATTN64"); return e ? atoi(e) : 2; }();   // dev: 0 = the kernel below
         if (a64 != 0) {
-#ifdef FLUX2MI_DEV
-            const int r64 = (a64 == 1 && fx == 2) ? launch_attention64(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads)
-                                                  : launch_attention64b(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads, fx != 2);
-#else
             const int r64 = launch_attention64b(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads, fx != 2);
-#endif
             if (r64 != 1) return r64;
         }
     }

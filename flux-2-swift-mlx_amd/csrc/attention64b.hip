@@ -43,7 +43,7 @@ __device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, I...>)
     (f(ic<I>{}), ...);
 }
 #define B64_INLINE __attribute__((always_inline))
-#define B64_USE (void)o; (void)s; (void)p; (void)kf; (void)vf; (void)qf; (void)lacc; (void)ones; (void)ones_last; (void)kfa; (void)vfa; (void)negm;
+#define B64_USE (void)o; (void)s; (void)p; (void)kf; (void)vf; (void)qf; (void)lacc; (void)ones; (void)pmask; (void)kfa; (void)vfa; (void)negm;
 
 // ---- the schedule (gap = the slot behind MFMA number g of the iteration; >= T: the same slot of the NEXT iteration)
 // softmax element e of a half (query blocks 2H, 2H+1): e = st*16 + qh*8 + u*4 + r -> s[2 st + u][2H + qh][r]; pack c = e / 2
@@ -86,8 +86,10 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
         qblk = k % (int)gridDim.x;
     }
     const int q0 = qblk * 256 + wid * 64;
-    const int nt = (S + BKV - 1) / BKV;   // the last tile may be partial: its missing keys score against key S - 1 again (clamped rows) and are
-                                          // kept out of the row sums by a masked ones operand; V^T is zero there (s_pad >= 64 nt, producers clear it)
+    const int nt = (S + BKV - 1) / BKV;   // the last tile may be partial: its missing keys score against key S - 1 again (clamped rows: finite
+                                          // scores) and their P^T slots are cleared in front of the last tile's PV (pmask), so that neither the
+                                          // row sums nor O see them — whatever V^T holds behind key S - 1 (the KV-extract pass runs the reference
+                                          // queries against a key PREFIX of the shared V^T image: real values follow).  V^T must be finite there.
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = qb*16 + c16][d = 32 ks + 8 g4 + j]; loaded by asm straight into
     // their registers (blocks 0, 1 in AGPRs, 2, 3 in VGPRs); the loads are older than every DMA piece: the prologue's vmcnt covers them
@@ -143,8 +145,9 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (DOFF && t == 0) s_again = 0;
-    bf16x8 ones, ones_last[2];   // ones_last[st]: 1 for the k-slots of step st whose key exists in the last tile (slot (g4, j) <-> key
-                                 // 32 st + 16 (g4 >> 1) + 8 (j >> 2) + 4 (g4 & 1) + (j & 3)), 0 for the others
+    bf16x8 ones;
+    u32x4 pmask[2];              // pmask[st]: all-ones bits for the k-slots of step st whose key exists in the last tile (slot (g4, j) <-> key
+                                 // 32 st + 16 (g4 >> 1) + 8 (j >> 2) + 4 (g4 & 1) + (j & 3)), 0 for the others; word w = slots 2w, 2w + 1
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
     {
@@ -152,8 +155,15 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                ones_last[st][j] = (32 * st + 16 * (g4 >> 1) + 8 * (j >> 2) + 4 * (g4 & 1) + (j & 3)) < valid ? (__bf16)1.0f : (__bf16)0.0f;
+            for (int w = 0; w < 4; ++w) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = 2 * w + h;
+                    if ((32 * st + 16 * (g4 >> 1) + 8 * (j >> 2) + 4 * (g4 & 1) + (j & 3)) < valid) m |= 0xffffu << (16 * h);
+                }
+                pmask[st][w] = m;
+            }
     }
     asm volatile("" : "+v"(ones));   // one register tuple, not re-materialised in the loop
 
@@ -311,10 +321,15 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
                     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(o[db][qb]) : "v"(vf[8 * st + db]), "v"(p[st][qb]));
                 } else {
                     constexpr int qb = 2 * H + (m - 16);
-                    // the last tile (the only iteration without a QK^T part) sums over its valid keys only
-                    if constexpr (HAS_QK) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(lacc[qb]) : "v"(ones), "v"(p[st][qb]));
-                    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(lacc[qb]) : "v"(ones_last[st]), "v"(p[st][qb]));
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(lacc[qb]) : "v"(ones), "v"(p[st][qb]));
                 }
+            }
+            // ---- the last tile (the only iteration without a QK^T part; its gaps 0..63 carry no MFMA): behind the last pack (gap 31) the
+            // P^T slots of keys that do not exist are cleared — one v_and per P register, two per gap
+            if constexpr (!HAS_QK && HAS_PV && g >= 36 && g < 52) {
+                constexpr int n0 = 2 * (g - 36);
+                asm volatile("v_and_b32 %0, %0, %1" : "+v"(p[n0 / 16][(n0 / 4) % 4][n0 % 4]) : "v"(pmask[n0 / 16][n0 % 4]));
+                asm volatile("v_and_b32 %0, %0, %1" : "+v"(p[(n0 + 1) / 16][((n0 + 1) / 4) % 4][(n0 + 1) % 4]) : "v"(pmask[(n0 + 1) / 16][(n0 + 1) % 4]));
             }
             // ---- fillers, in issue order
             if constexpr (g == BAR_GAP) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
@@ -439,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
 
 // 0 launched / 1 not this kernel's case (the caller falls back) / 2 launch error.
 // Requires: q pre-multiplied by scale*log2(e); data_offset = false: the fixed zero offset valid (the caller checks), true: any scores;
-// vt zero beyond key S - 1.
+// vt finite beyond key S - 1 (up to s_pad): those P^T slots are zero, the values themselves are not used.
 // The two instantiations are separate translation units (attention64b_doff.hip includes this file with ATTN64B_DOFF 1): each takes
 // hipcc ~2.5 minutes, side by side in a parallel build.
 #ifndef ATTN64B_DOFF

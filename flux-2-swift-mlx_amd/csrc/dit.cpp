@@ -938,7 +938,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         const char* e = F2_DEV_ENV("FLUX2MI_QK_FUSE");
         return e ? atoi(e) != 0 : true;
     }();
-    const bool qk_fuse_ok = qk_fuse_on && d % 256 == 0 && !F2_DEV_ENV("FLUX2MI_GEMM") && !F2_DEV_ENV("FLUX2MI_GEMM_V");
+    const bool qk_fuse_ok = qk_fuse_on && d % 256 == 0 && !F2_DEV_ENV("FLUX2MI_GEMM");
     // decided on the whole sequence S, not on the live rows of this pass: a KV-cached pass (fewer live rows) must
     // treat q / k exactly like the extraction pass whose keys it reuses
     const bool qk_fuse_dbl = qk_fuse_ok && (long)((S + 255) / 256) * ((3 * d + 255) / 256) >= 100;
@@ -1139,6 +1139,19 @@ extern "C" int flux2mi_kv_cache_create(flux2mi_dit* m, int s_txt, int s_ref, flu
     return FLUX2MI_OK;
 }
 
+// LayerKVCacheEntry of one block (TransformerKVCache.swift:13-25, doubleStreamEntry(at:) / singleStreamEntry(at:) :59-67): layer =
+// double blocks first, then single blocks.  keys bf16 [s_ref, d] (post-RoPE, head h at columns h*128..), values_t bf16 [d, s_ref]
+// (row h*128 + c = channel c of head h: the cache keeps V transposed, as the attention consumes it).  Device buffers; async.
+extern "C" int flux2mi_kv_cache_entry(flux2mi_kv_cache* c, int layer, void* keys, void* values_t) {
+    F2_REQUIRE(c && c->dit && layer >= 0 && layer < c->dit->cfg.n_double + c->dit->cfg.n_single, FLUX2MI_ERR_INVALID_ARG, "kv_cache_entry: bad argument");
+    F2_REQUIRE(c->filled, FLUX2MI_ERR_NOT_LOADED, "kv_cache_entry: the cache has not been filled by an extraction pass");
+    F2_CHECK_HIP(hipSetDevice(c->dit->ctx->device));
+    const size_t bytes = c->layer_elems / 2 * 2;
+    if (keys) F2_CHECK_HIP(hipMemcpyAsync(keys, c->k(layer), bytes, hipMemcpyDeviceToDevice, c->dit->ctx->stream));
+    if (values_t) F2_CHECK_HIP(hipMemcpyAsync(values_t, c->v(layer), bytes, hipMemcpyDeviceToDevice, c->dit->ctx->stream));
+    return FLUX2MI_OK;
+}
+
 extern "C" int flux2mi_kv_cache_destroy(flux2mi_kv_cache* c) {
     if (!c) return FLUX2MI_OK;
     (void)hipSetDevice(c->dit->ctx->device);
@@ -1210,22 +1223,6 @@ extern "C" int flux2mi_op_gemm_bf16_out_bf16(flux2mi_ctx* ctx, const void* A, co
     const int r = launch_gemm(ctx->stream, &p, 1);
     prof_after(ctx, PROF_DIT_GEMM, 2.0 * M * (double)N * K);
     F2_LAUNCH(r, "op_gemm_bf16_out_bf16");
-    return FLUX2MI_OK;
-}
-
-// C = A W^T with explicit operand strides: lda / ldw in elements, a_kstride / w_kstride = bytes between consecutive
-// 128-byte K-tile pieces of a row (0 = contiguous rows).  Layout experiments of tools/gemm_bench.py (256x256 kernel only).
-extern "C" int flux2mi_op_gemm_bf16_ex(flux2mi_ctx* ctx, const void* A, int lda, long long a_kstride, const void* W, int ldw,
-                                       long long w_kstride, float* C, int M, int N, int K) {
-    F2_REQUIRE(ctx && A && W && C && M > 0 && N > 0 && K > 0 && K % 64 == 0, FLUX2MI_ERR_INVALID_ARG, "op_gemm_ex: bad argument");
-    F2_REQUIRE((long)((M + 255) / 256) * ((N + 255) / 256) >= 100, FLUX2MI_ERR_UNSUPPORTED, "op_gemm_ex: needs >= 100 tiles (256x256 kernel)");
-    GemmProblem p = mk(reinterpret_cast<const uint16_t*>(A), lda, reinterpret_cast<const uint16_t*>(W), ldw, C, N, M, N, K, EPI_F32);
-    p.a_kstride = a_kstride;
-    p.w_kstride = w_kstride;
-    prof_before(ctx, PROF_DIT_GEMM);
-    const int r = launch_gemm(ctx->stream, &p, 1);
-    prof_after(ctx, PROF_DIT_GEMM, 2.0 * M * (double)N * K);
-    F2_LAUNCH(r, "op_gemm_ex");
     return FLUX2MI_OK;
 }
 
@@ -1301,6 +1298,25 @@ extern "C" int flux2mi_op_attention_prescaled(flux2mi_ctx* ctx, const void* qkv_
                                    nullptr, 0);
     prof_after(ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
     F2_LAUNCH(r, "op_attention_prescaled");
+    return FLUX2MI_OK;
+}
+
+// The KV-extraction pass's launch shape (attend(), FWD_KV_EXTRACT: Flux2Attention.swift:407-425's additive mask is a key-prefix limit):
+// queries [q0, q0 + nq) against the key PREFIX [0, nk) of a V^T image that holds all S keys — real values behind key nk - 1, on an
+// unaligned boundary when nk % 64 != 0.  Only out rows [q0, q0 + nq) are written.
+extern "C" int flux2mi_op_attention_prescaled_range(flux2mi_ctx* ctx, const void* qkv_in, void* out, int S, int heads, float score_bound_log2,
+                                                    int q0, int nq, int nk) {
+    F2_REQUIRE(ctx && qkv_in && out && S > 0 && heads > 0 && q0 >= 0 && nq > 0 && q0 + nq <= S && nk > 0 && nk <= S, FLUX2MI_ERR_INVALID_ARG,
+               "op_attention_prescaled_range: bad argument");
+    const int d = heads * 128, s_pad = attn_s_pad(S);
+    F2_TRY(ctx->scratch.reserve((size_t)heads * 128 * s_pad * 2 + 256 * 4));
+    uint16_t* vt = ctx->scratch.as<uint16_t>();
+    F2_CHECK_HIP(hipMemsetAsync(vt, 0, (size_t)heads * 128 * s_pad * 2, ctx->stream));
+    F2_LAUNCH(launch_v_transpose_only(ctx->stream, reinterpret_cast<const uint16_t*>(qkv_in), 3 * d, S, heads, vt, s_pad), "v_transpose");
+    const uint16_t* q = reinterpret_cast<const uint16_t*>(qkv_in);
+    const int r = launch_attention(ctx->stream, q + (size_t)q0 * 3 * d, q + d, 3 * d, vt, s_pad, reinterpret_cast<uint16_t*>(out) + (size_t)q0 * d, d,
+                                   nq, nk, heads, score_bound_log2, true, nullptr, 0);
+    F2_LAUNCH(r, "op_attention_prescaled_range");
     return FLUX2MI_OK;
 }
 

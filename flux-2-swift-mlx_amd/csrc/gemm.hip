@@ -28,14 +28,8 @@
 #include "kernels.h"
 #include <stdlib.h>
 
-#ifdef FLUX2MI_DEV
-int launch_gemm256(hipStream_t stream, const GemmProblem* probs, int nprob);   // experimental/gemm256.hip: the 8-wave kernel
-#endif
 int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob);
 bool gemm256s_eligible(const GemmProblem* probs, int nprob);
-#ifdef FLUX2MI_DEV
-int launch_gemm256_g4(hipStream_t stream, const GemmProblem* probs, int nprob);
-#endif
 
 namespace {
 
@@ -357,10 +351,7 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
             if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.K % 128 != 0 || (p.lda & 15) || (p.ldw & 15) || !p.a_scale || !p.w_scale) return 1;
             if ((p.epi == EPI_SWIGLU || p.epi == EPI_QKV_MLP) && (p.N % 64 != 0 || p.n_split % 256 != 0)) return 1;
         }
-        // the one-wave-per-SIMD kernel (gemm256s.hip); FLUX2MI_GEMM_V with the dev library keeps the 8-wave fp8 kernel (A/B runs)
-#ifdef FLUX2MI_DEV
-        if (F2_DEV_ENV("FLUX2MI_GEMM_V")) return launch_gemm256(stream, probs, nprob);
-#endif
+        // the one-wave-per-SIMD kernel (gemm256s.hip)
         return gemm256s_eligible(probs, nprob) ? launch_gemm256s(stream, probs, nprob) : 1;
     }
     for (int i = 0; i < nprob; ++i) {
@@ -390,28 +381,13 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
         bool big = tiles256 >= 100;
         for (int i = 0; i < nprob; ++i)
             if (probs[i].epi == EPI_QKV_MLP && probs[i].n_split % 256 != 0) big = false;  // a 256-wide tile must not straddle the split
-        static const int ver = [] {
-            const char* e = F2_DEV_ENV("FLUX2MI_GEMM_V");
-            return e ? atoi(e) : 2;
-        }();
-        bool fused_qk = false;   // only the 256x256 kernel (gemm256.hip) applies GemmProblem::qk_*
+        bool fused_qk = false;   // only the 256x256 kernel (gemm256s.hip) applies GemmProblem::qk_*
         for (int i = 0; i < nprob; ++i) fused_qk |= probs[i].qk_qw != nullptr || probs[i].col_perm16 != 0;
-        if (fused_qk && (force == 128 || ver != 2)) return 1;
+        if (fused_qk && force == 128) return 1;
         if (fused_qk) big = true;   // the caller decides fusion per model and sequence, not per launch (dit.cpp)
         if (force == 256 || (force != 128 && big))
         {
-#ifdef FLUX2MI_DEV   // experimental structures (csrc/experimental/, `make dev` only)
-            if (ver == 6) {
-                bool ok = true;
-                for (int i = 0; i < nprob; ++i) ok = ok && !probs[i].fp8 && (probs[i].epi == EPI_F32 || probs[i].epi == EPI_GATE_RESID || (probs[i].epi == EPI_BF16 && !probs[i].qk_qw && !probs[i].col_perm16)) && !probs[i].a_kstride && !probs[i].w_kstride;
-                if (ok) return launch_gemm256_g4(stream, probs, nprob);
-            }
-#endif
-            // the one-wave-per-SIMD kernel (gemm256s.hip); the strided-layout experiments: the 8-wave one.
-            // FLUX2MI_GEMM_V=2 with the dev library forces the 8-wave kernel (A/B runs)
-#ifdef FLUX2MI_DEV
-            if (F2_DEV_ENV("FLUX2MI_GEMM_V") || !gemm256s_eligible(probs, nprob)) return launch_gemm256(stream, probs, nprob);
-#endif
+            // the one-wave-per-SIMD kernel (gemm256s.hip)
             if (gemm256s_eligible(probs, nprob)) return launch_gemm256s(stream, probs, nprob);
             if (fused_qk) return 1;   // source offsets beyond 32 bits: only the 128x128 kernel below, which has no fused epilogue
         }

@@ -726,7 +726,7 @@ int gemm256_pick_ni(const GemmProblem* probs, int nprob) {
 bool gemm256s_eligible(const GemmProblem* probs, int nprob) {
     for (int i = 0; i < nprob; ++i) {
         const GemmProblem& q = probs[i];
-        if (q.a_kstride || q.w_kstride || q.K % (q.fp8 ? 128 : 64) != 0 || (q.fp8 != 0) != (probs[0].fp8 != 0)) return false;
+        if (q.K % (q.fp8 ? 128 : 64) != 0 || (q.fp8 != 0) != (probs[0].fp8 != 0)) return false;
         if ((unsigned long long)q.M * (unsigned long long)q.lda * 2 >= (1ull << 32) || (unsigned long long)q.N * (unsigned long long)q.ldw * 2 >= (1ull << 32)) return false;
     }
     return true;

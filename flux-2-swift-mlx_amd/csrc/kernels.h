@@ -41,10 +41,6 @@ struct GemmProblem {
     const float* a_scale;
     const float* w_scale;
     int fp8;
-    // 256x256 kernel: bytes from one 128-byte K-tile piece of a row to the next (0 = 128: plain row-major rows).
-    // rows * 128 with lda / ldw = 128 bytes' worth of elements describes the K-blocked layout [K/tile][rows][128 B],
-    // in which the 256-row slice a workgroup stages per K-tile is one contiguous 32 KB block.
-    long long a_kstride, w_kstride;
     // 256x256 kernel, EPI_BF16 columns [0, qk_cols) (= q | k of a fused qkv projection, qk_cols = 2*dim, dim % 256 == 0):
     // per-head RMSNorm (eps 1e-6, weights qk_qw / qk_kw bf16 [128]) + RoPE applied to the f32 accumulators before
     // the store — what launch_qk_norm_rope_vt does in a separate pass over the stored bf16 values; q additionally

@@ -69,7 +69,8 @@ int launch_mfma_stream(hipStream_t stream, float* out, int workgroups, bool fp8,
     const int trips = 2000;                                            // 2000 x 2048 MFMA cycles: ~2 ms per launch
     const double flops_per_launch = (double)workgroups * 4 * trips * (fp8 ? 64.0 * 2 * 16 * 16 * 128 : 128.0 * 2 * 16 * 16 * 32);
     hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 2;
+    if (hipEventCreate(&e0) != hipSuccess) return 2;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return 2; }
     auto go = [&]() {
         if (fp8) hipLaunchKernelGGL(mfma_stream_kernel<true>, dim3(workgroups), dim3(256), 0, stream, out, trips);
         else hipLaunchKernelGGL(mfma_stream_kernel<false>, dim3(workgroups), dim3(256), 0, stream, out, trips);

@@ -263,6 +263,10 @@ typedef struct flux2mi_kv_cache flux2mi_kv_cache;
 /* Storage for the post-RoPE keys and the values of s_ref reference tokens in every block. */
 int flux2mi_kv_cache_create(flux2mi_dit* dit, int s_txt, int s_ref, flux2mi_kv_cache** out);
 int flux2mi_kv_cache_destroy(flux2mi_kv_cache* cache);
+/* LayerKVCacheEntry of one block (TransformerKVCache.swift:13-25, :59-67; layer = double blocks, then single blocks):
+ * keys bf16 [s_ref, dim] post-RoPE (head h at columns h*128..), values_t bf16 [dim, s_ref] (V transposed); either may be NULL.
+ * Device buffers, async on the context's stream; an unfilled cache is FLUX2MI_ERR_NOT_LOADED. */
+int flux2mi_kv_cache_entry(flux2mi_kv_cache* cache, int layer, void* keys, void* values_t);
 /* forwardKVExtract (:346-446): sequence [txt | ref | out]; reference queries attend to [txt | ref]
  * only (Flux2Attention.swift:296-306, :407-425), everything else to all keys; fills `cache`.
  * latents f32 [s_out,128], ref_latents f32 [s_ref,128], ids i32 [.,4]; out f32 [s_out,128].  Async. */
@@ -432,10 +436,6 @@ int flux2mi_debug_mfma_stream(flux2mi_ctx* ctx, int fp8, double seconds, double*
 int flux2mi_op_gemm_bf16(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K);
 /* the same product stored as bf16 [M,N] (one rounding of the f32 accumulator), as the model's block GEMMs store it */
 int flux2mi_op_gemm_bf16_out_bf16(flux2mi_ctx* ctx, const void* A, const void* W, void* C, int M, int N, int K);
-/* the same product with explicit operand layouts (microbenchmarks of operand layouts): lda / ldw in elements,
- * a_kstride / w_kstride = bytes between consecutive 128-byte K pieces of a row (0 = contiguous rows) */
-int flux2mi_op_gemm_bf16_ex(flux2mi_ctx* ctx, const void* A, int lda, long long a_kstride, const void* W, int ldw,
-                            long long w_kstride, float* C, int M, int N, int K);
 /* X f32 [M,N] += gate f32 [N] (per column) * (A W^T): the gate + residual epilogue of the block output GEMMs
  * (Flux2TransformerBlock.swift:117-166 applyGate + residual). */
 int flux2mi_op_gemm_gate_resid(flux2mi_ctx* ctx, const void* A, const void* W, const float* gate, float* X, int M,
@@ -466,6 +466,11 @@ int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv, void* out, int S, in
    fixed zero offset when 0 < bound <= 80 (Flux2Attention.swift:168-174 after the QK RMSNorm bounds the scores); bound <= 0
    (unknown) or > 80: a per-query offset taken from the data, exact for any scores (attention64b.hip, DOFF) */
 int flux2mi_op_attention_prescaled(flux2mi_ctx* ctx, const void* qkv, void* out, int S, int heads, float score_bound_log2);
+/* the same with queries [q0, q0+nq) against the key PREFIX [0, nk) of a V^T image holding all S keys — the launch shape of the
+   KV-extraction pass, whose reference queries see [text | reference] only (Flux2Attention.swift:407-425: the additive mask is a
+   key-prefix limit; Flux2Transformer.swift:346-457).  Only out rows [q0, q0+nq) are written */
+int flux2mi_op_attention_prescaled_range(flux2mi_ctx* ctx, const void* qkv, void* out, int S, int heads, float score_bound_log2,
+                                         int q0, int nq, int nk);
 
 #ifdef __cplusplus
 }

@@ -295,6 +295,48 @@ def test_kv_extract_and_cached_production_width(flux2mi, ctx):
     assert rel_l2(h0_again, h0) < 2e-3
 
 
+@pytest.mark.parametrize("s_txt,h,w,ref_hw", [(64, 256, 256, (9, 15)), (19, 128, 192, (7, 9))])
+def test_kv_extract_unaligned_reference_rows_production_width(flux2mi, ctx, s_txt, h, w, ref_hw):
+    """Klein-4B width, two double + two single blocks, s_txt + s_ref NOT a multiple of the 64-key tile (64 + 135 = 199, 19 + 63 = 82):
+    the reference queries of the extraction pass run against a key prefix that ends inside a KV tile, with the output tokens' V^T
+    columns right behind it.  Checked where a leak would land: the cached K / V of every block after the first are functions of the
+    reference rows' attention output of the blocks before — compared PER REFERENCE ROW with the oracle's cache
+    (`LayerKVCacheEntry.keys / .values`, TransformerKVCache.swift:13-25), then the cached pass against the oracle."""
+    from flux2mi import synthetic as syn
+    from flux2mi.api import DiT, KVCache
+    cfg = dict(dim=3072, heads=24, n_double=2, n_single=2, joint_dim=7680, guidance=False)
+    P = syn.make_dit_weights(cfg, seed=5, std=0.05)
+    inp = syn.make_inputs(cfg, h, w, s_txt=s_txt)
+    lat = R.pack_patchified_to_sequence(inp["noise"])
+    g = torch.Generator().manual_seed(3)
+    s_ref = ref_hw[0] * ref_hw[1]
+    assert (s_txt + s_ref) % 64 != 0
+    ref = torch.randn((1, s_ref, 128), generator=g)
+    lat2 = lat + 0.3 * torch.randn(lat.shape, generator=g)
+    ref_ids = R.reference_position_ids([ref_hw[0]], [ref_hw[1]])
+    img_ids, txt_ids = R.image_position_ids(h, w), R.text_position_ids(s_txt)
+    o0, cache = R.dit_forward_kv(P, cfg, lat, inp["txt"].float(), torch.tensor([0.8]), None, img_ids, txt_ids, ref_lat=ref, ref_ids=ref_ids)
+    o1, _ = R.dit_forward_kv(P, cfg, lat2, inp["txt"].float(), torch.tensor([0.55]), None, img_ids, txt_ids, cache=cache)
+    dit = DiT(ctx, cfg).load(P).finalize()
+    kv = KVCache(dit, s_txt, s_ref)
+    d = lambda x: x.cuda()
+    h0 = dit.forward_kv_extract(kv, d(lat), d(ref), d(inp["txt"]), 0.8, 4.0, d(img_ids), d(txt_ids), d(ref_ids)).cpu()
+    worst = 0.0
+    for layer in range(4):
+        keys, vals = kv.entry(layer)
+        ok, ov = cache[layer]                                   # [1, H, s_ref, 128]
+        ok = ok[0].permute(1, 0, 2).reshape(s_ref, -1)
+        ov = ov[0].permute(1, 0, 2).reshape(s_ref, -1)
+        for got, exp in ((keys.float().cpu(), ok), (vals.float().cpu(), ov)):
+            row_err = (got - exp).norm(dim=1) / exp.norm(dim=1)
+            worst = max(worst, float(row_err.max()))
+            assert float(row_err.max()) < 3e-2, (layer, float(row_err.max()), int(row_err.argmax()))
+    h1 = dit.forward_kv_cached(kv, d(lat2), d(inp["txt"]), 0.55, 4.0, d(img_ids), d(txt_ids)).cpu()
+    kv.close()
+    dit.close()
+    assert rel_l2(h0, o0[0]) < 2e-2 and rel_l2(h1, o1[0]) < 2e-2
+
+
 def test_kv_cached_before_extract_is_an_error(flux2mi, ctx):
     """The reference calls fatalError on a missing cache entry (Flux2Transformer.swift:488); here: a status."""
     from flux2mi import Flux2Error, synthetic as syn

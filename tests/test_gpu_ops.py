@@ -554,6 +554,41 @@ def test_gemm_split_k_random_deterministic(ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("doff", [False, True])
+@pytest.mark.parametrize("S,q0,nq,nk", [(704, 100, 300, 400), (704, 64, 45, 109), (320, 19, 60, 79), (1217, 512, 700, 1212), (200, 0, 200, 1), (4608, 512, 3600, 4112)])
+def test_attention_prescaled_key_prefix_with_live_values_behind(ctx, S, q0, nq, nk, doff):
+    """The launch shape of the KV-extraction pass (dit.cpp attend(): reference queries against the [text | reference] key PREFIX of
+    the shared V^T image, Flux2Attention.swift:407-425): nk % 64 != 0 with REAL, large values behind key nk - 1.  The missing keys of
+    the partial last KV tile must contribute nothing — per query row against the oracle's softmax over the prefix (every row's
+    relative error, not a whole-tensor norm), for both softmax-offset forms; rows outside the query range are not written."""
+    import math
+    heads = 2
+    g = torch.Generator().manual_seed(S * 3 + nk)
+    d = heads * 128
+    x = torch.randn((S, 3 * d), generator=g)
+    q = x[:, :d].view(S, heads, 128)
+    k = x[:, d:2 * d].view(S, heads, 128)
+    q = q / q.pow(2).mean(-1, keepdim=True).sqrt() * (4.0 if doff else 1.0)
+    k = k / k.pow(2).mean(-1, keepdim=True).sqrt()
+    v = x[:, 2 * d:].clone()
+    v[nk:] = 40.0 + 10.0 * v[nk:]            # what a leak of the keys behind the prefix would add: far outside the prefix's value range
+    c = math.log2(math.e) / math.sqrt(128.0)
+    qkv = torch.cat([(q * c).reshape(S, d), k.reshape(S, d), v], dim=1).to(torch.bfloat16)
+    bound = 0.0 if doff else 128.0 * c
+    out = ctx.op_attention_prescaled_range(qkv.cuda(), heads, bound, q0, nq, nk).float().cpu()
+    qs, ks, vs = qkv.float().split(d, dim=1)
+    hv = lambda t: t.reshape(1, t.shape[0], heads, 128).permute(0, 2, 1, 3)
+    ref = R.sdpa(hv(qs[q0:q0 + nq] / c), hv(ks[:nk]), hv(vs[:nk])).permute(0, 2, 1, 3).reshape(nq, d)
+    got = out[q0:q0 + nq]
+    assert torch.isfinite(out).all()
+    row_err = (got - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-3)
+    assert float(row_err.max()) < 3e-2, (float(row_err.max()), int(row_err.argmax()))
+    assert rel_l2(got, ref) < 1e-2
+    assert float(out[:q0].abs().max() if q0 else 0.0) == 0.0 and float(out[q0 + nq:].abs().max() if q0 + nq < S else 0.0) == 0.0
+    assert torch.equal(out, ctx.op_attention_prescaled_range(qkv.cuda(), heads, bound, q0, nq, nk).float().cpu())
+
+
+@pytest.mark.gpu
 def test_attention_prescaled_random_shapes(ctx):
     """A seeded sweep of 24 sequence lengths (1 .. 1500, most of them not multiples of the 64-key tile or the 256-query block) x 1-4
     heads through both softmax forms of the one-wave-per-SIMD kernel (fixed zero offset with a valid bound, per-query data offset

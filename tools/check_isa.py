@@ -9,7 +9,10 @@
     * exactly the instruction mix the schedule tables describe (MFMA / ds_read / DMA counts per trip)
   and the kernels use no scratch at all; in particular no block that issues an MFMA may touch scratch: a spill store of an accumulator
   placed behind the asm MFMA that writes it stores a register whose result is still in flight.
-Run after any change to those files or to the toolchain (~5 min): python tools/check_isa.py"""
+Part of the product build: csrc/Makefile compiles the three objects with -save-temps=obj and runs `check_isa.py --from build` on the
+device assembly OF THE OBJECTS THAT ARE LINKED (build/isa.ok is a prerequisite of libflux2mi.so), so a toolchain bump or a source edit
+that breaks an invariant fails the build; tests/test_isa_invariants.py re-runs it on the same files.  Stand-alone (compiles its own
+assembly, ~5 min): python tools/check_isa.py"""
 import collections
 import os
 import re
@@ -21,7 +24,12 @@ CSRC = os.path.join(ROOT, "flux-2-swift-mlx_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_out", "isa")
 
 
+FROM = None   # --from DIR: read <name>-hip-amdgcn-amd-amdhsa-gfx950.s left there by `hipcc -save-temps=obj` instead of compiling
+
+
 def compile_s(name):
+    if FROM:
+        return open(os.path.join(FROM, name + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     os.makedirs(OUT, exist_ok=True)
     dst = os.path.join(OUT, name + ".s")
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-w", "-S", "--offload-device-only",
@@ -70,10 +78,23 @@ def check_loop(kname, label, ins, n_mfma, n_dsr, n_dma, dma_op, errors):
         errors.append((kname, label, bad, m0, mf, dict(c)))
 
 
+def check_m0(name, text, errors):
+    """M0 is written by the LDS-DMA asm without save / restore: hipcc must emit no other M0 reference in these objects (an M0 use of the
+    compiler's own between an M0 write and its DMA would break the destination address)."""
+    bad = [l.strip() for l in text.split("\n") if re.search(r"\bm0\b", l.split(";")[0]) and not re.search(r"s_(add_u32|mov_b32) m0, s", l)]
+    print(f"{name}: M0 references besides the LDS-DMA setup: {len(bad)}")
+    if bad:
+        errors.append((name, "foreign M0 references", bad[:5]))
+
+
 def main():
+    global FROM
+    if "--from" in sys.argv:
+        FROM = sys.argv[sys.argv.index("--from") + 1]
     errors = []
     # ---- GEMM: steady-state K-tile loop = the block with NI*16 (bf16) / NI*8 (fp8) MFMAs that carries the LDS-DMA pieces
     text = compile_s("gemm256s")
+    check_m0("gemm256s", text, errors)
     for kname, body in kernels(text):
         m = re.search(r"gemm256s_kernelILi(\d)ELb(\d)E", kname)
         if not m:
@@ -99,6 +120,8 @@ def main():
             errors.append((kname, "steady-state loop not found"))
     # ---- attention: the three-tile loop of both instantiations (DOFF = false: fixed zero offset, true: per-query data offset)
     texts = compile_many(["attention64b", "attention64b_doff"])
+    for n, t in zip(["attention64b", "attention64b_doff"], texts):
+        check_m0(n, t, errors)
     for text, (kname, body) in [(t, kb) for t in texts for kb in kernels(t)]:
         m = re.search(r"attn64b_kernelILb(\d)E", kname)
         if not m:
