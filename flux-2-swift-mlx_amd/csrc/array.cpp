@@ -34,7 +34,7 @@ int make(flux2mi_ctx* ctx, const int64_t* shape, int ndim, bool alloc, flux2mi_a
     a->ctx = ctx;
     a->ndim = ndim;
     for (int i = 0; i < ndim; ++i) {
-        if (shape[i] <= 0 || shape[i] > (int64_t)INT32_MAX) {   // binary() narrows dims to int delete a; flux2mi_set_error("array: dim %d is %lld", i, (long long)shape[i]); return FLUX2MI_ERR_SHAPE; }
+        if (shape[i] <= 0 || shape[i] > (int64_t)INT32_MAX) { /* binary() narrows dims to int */ delete a; flux2mi_set_error("array: dim %d is %lld", i, (long long)shape[i]); return FLUX2MI_ERR_SHAPE; }
         a->shape[i] = shape[i];
     }
     if (a->numel() > (int64_t)1 << 40) { delete a; flux2mi_set_error("array: too many elements"); return FLUX2MI_ERR_SHAPE; }
