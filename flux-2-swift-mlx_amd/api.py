@@ -426,6 +426,8 @@ def _set_tensors(fn, handle, tensors: Dict[str, torch.Tensor]):
         if t.dtype not in _DT:
             t = t.float()
         t = t.contiguous()
+        if t.is_cuda:   # the library copies on its own stream (and synchronises it before returning): the producer must be done
+            torch.cuda.current_stream(t.device).synchronize()
         shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
         check(fn(handle, name.encode(), _DT[t.dtype], shape, t.dim(), C.c_void_p(t.data_ptr())))
 

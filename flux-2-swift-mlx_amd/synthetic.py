@@ -11,6 +11,8 @@ bit-identical parameters.
 """
 from __future__ import annotations
 
+import zlib
+from collections.abc import Mapping
 from typing import Dict, List, Tuple
 
 import torch
@@ -164,6 +166,38 @@ def make_dit_weights(cfg: dict, seed: int = 1234, device="cpu", std: float = 0.0
             x = 1.0 + 0.1 * x
         P[name] = x.to(torch.bfloat16)
     return P
+
+
+class LazyDitWeights(Mapping):
+    """The same recipe, one tensor at a time: `P[name]` draws the tensor from its OWN seed (seed, crc32(name)) on `device`
+    and keeps nothing, so a 32 B-parameter Dev transformer (64 GB in bf16) is never resident outside the library — the
+    loader (`DiT.load`, which iterates `.items()`) and the CPU oracle (`cpu()`: the same values moved to the host per access)
+    see bit-identical parameters, each for the moment it uses them.  Values differ from `make_dit_weights` (one
+    sequential generator); a given (seed, name, shape, device type) always yields the same tensor."""
+
+    def __init__(self, cfg: dict, seed: int = 1234, device="cuda", std: float = 0.02, to_cpu: bool = False):
+        self.cfg, self.seed, self.device, self.std, self.to_cpu = cfg, seed, device, std, to_cpu
+        self.shapes = {name: (shape, kind) for name, shape, kind in dit_param_shapes(cfg)}
+
+    def __len__(self):
+        return len(self.shapes)
+
+    def __iter__(self):
+        return iter(self.shapes)
+
+    def __contains__(self, name):
+        return name in self.shapes
+
+    def __getitem__(self, name: str) -> torch.Tensor:
+        shape, kind = self.shapes[name]
+        g = _gen(self.device, (self.seed * 1_000_003 + zlib.crc32(name.encode())) & 0x7FFFFFFFFFFFFFFF)
+        x = torch.randn(shape, generator=g, device=self.device, dtype=torch.float32)
+        x = (x * self.std if kind == "linear" else 1.0 + 0.1 * x).to(torch.bfloat16)
+        return x.cpu() if self.to_cpu else x
+
+    def cpu(self) -> "LazyDitWeights":
+        """The oracle's view: the same device-generated values, copied to the host per access."""
+        return LazyDitWeights(self.cfg, self.seed, self.device, self.std, to_cpu=True)
 
 
 def make_vae_weights(vcfg: dict, seed: int = 4321, device="cpu", encoder: bool = True) -> Dict[str, torch.Tensor]:
