@@ -4,9 +4,11 @@
 One bench "step" = one batch of N images (one per GPU, batch-level data parallel): the
 28 denoise steps of the DiT, VAE decode, the all-gather of the decoded u8 images and the D2H
 copy of the batch on rank 0, with text embeddings and noise resident in HBM when the timed
-region starts.  Per batch the ranks exchange exactly two collectives (RCCL over xGMI):
+region starts.  Per batch the ranks exchange exactly two collectives (RCCL over xGMI, inside libflux2mi.so on the
+stream the pipeline generates on: flux2mi_dp_broadcast_embeddings / flux2mi_dp_all_gather_images):
 broadcast of the text embeddings from rank 0 and all-gather of the decoded images (device
-buffers, no host staging).
+buffers, no host staging).  torch.distributed is only the control plane (a gloo group on 127.0.0.1 that
+carries the RCCL unique id and the CPU-side barrier).
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
 itself (fresh child processes, spawned before anything in this process touches a GPU); under
@@ -122,7 +124,7 @@ def main():
     from flux2mi import synthetic as syn
 
     dry = args.dry_run
-    rank, world, local = par.init_distributed(backend="gloo" if dry else None)
+    rank, world, local = par.init_distributed()
     assert world == max(1, args.gpus), (world, args.gpus)
     if dry:
         dev = torch.device("cpu")
@@ -148,6 +150,8 @@ def main():
         P = syn.make_dit_weights(cfg, seed=1234, device=dev)
         VP = syn.make_vae_weights(vcfg, seed=4321, device=dev)
         pipe.load_models(P, VP)
+        if world > 1:
+            par.attach_context(pipe.ctx)   # this rank's RCCL communicator, on the stream the pipeline generates on
         if args.attn_softmax == "online":
             pipe.transformer.set_attention_softmax("online")
         if not (rank == 0 and not args.no_cpu_baseline):
@@ -269,6 +273,12 @@ def main():
                     "flops_per_launch": flops_per_launch}
         step_ms = ms_denoise / (K * T)
 
+    # ---- the decode tail with BOTH decoders (outside the timed region): the timed region uses --vae (default: standard, the
+    # larger one); the reference pipeline's own default is the small decoder (Flux2Pipeline.swift:303)
+    decode_by_vae = None
+    if not dry:
+        decode_by_vae = {v: time_vae_decode(pipe.ctx, v, syn, dev, H, W) for v in ("standard", "small")}
+
     cpu_baseline = None
     if world == 1 and not dry and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(P, cfg, syn, H, W, T, s_txt)
@@ -293,6 +303,10 @@ def main():
         "seconds_per_image": round(sec_per_image, 4),
         "denoise_ms_per_denoise_step": round(step_ms, 3),
         "decode_ms_per_image": round(ms_decode / K, 3),
+        "decode_vae": args.vae,
+        "decode_ms_by_vae": decode_by_vae,
+        "seconds_per_image_by_vae": None if not decode_by_vae else
+            {v: round(sec_per_image + (ms - ms_decode / K) * 1e-3, 4) for v, ms in decode_by_vae.items()},
         "dit_step_tflops": round(step_flops / (step_ms * 1e-3) / 1e12, 2) if step_ms > 0 else None,
         "dit_step_mfma_frac": round(step_flops / (step_ms * 1e-3) / 1e12 / peak, 4) if step_ms > 0 else None,
         "attention_softmax": None if dry else pipe.transformer.attention_softmax_paths(),
@@ -362,6 +376,40 @@ class CardSampler:
                 "median_sclk_mhz": med(ck), "min_sclk_mhz": round(ck[0], 1) if ck else None, "samples": len(self.rows)}
 
 
+def time_vae_decode(ctx, variant, syn, dev, H, W, reps=5):
+    """ms per latents -> u8 image decode (AutoencoderKLFlux2.decode + post-processing) of one VAE variant, HIP path, synchronised wall
+    time over `reps` back-to-back decodes after one warm-up."""
+    import torch
+
+    from flux2mi.api import VAE
+    vcfg = syn.VAE_PRESETS[variant]
+    vae = VAE(ctx, vcfg).load(syn.make_vae_weights(vcfg, seed=4321, device=dev, encoder=False)).finalize()
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    z = torch.randn((1, 32, H // 8, W // 8), generator=g, device=dev, dtype=torch.float32)
+    vae.decode(z, want_f32=False)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        vae.decode(z, want_f32=False)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / reps
+    vae.close()
+    return round(dt * 1e3, 3)
+
+
+def granted_cores() -> int:
+    """Host cores this process may use: the cgroup CPU quota where there is one, else the visible CPUs."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def run_cpu_baseline(P_dev, cfg, syn, H, W, T, s_txt):
     """The restated oracle (torch CPU fp32 — NOT the reference's MLX path, which cannot run here) on a bounded
     sample of THE metric's workload: ONE denoise step (one DiT forward at S = s_txt + HW/256) of the same model,
@@ -371,8 +419,9 @@ def run_cpu_baseline(P_dev, cfg, syn, H, W, T, s_txt):
 
     from oracle import flux2_ref as R
 
-    cores = host_threads()
-    torch.set_num_threads(cores)
+    threads = host_threads()
+    cores = granted_cores()
+    torch.set_num_threads(threads)
     Pc = {k: v.cpu() for k, v in P_dev.items()}
 
     def one(h, w):
@@ -386,10 +435,10 @@ def run_cpu_baseline(P_dev, cfg, syn, H, W, T, s_txt):
 
     dt_small = one(256, 256)
     dt = one(H, W)
-    return {"value": round(1.0 / dt, 5), "unit": "denoise-steps/s", "cores": cores, "kind": "port",
-            "sample": f"1 denoise step (DiT forward) of the restated fp32 oracle (torch CPU, {cores} threads = 2 per core of the "
-                      f"cgroup quota), same model / {H}x{W} / S={s_txt + (H // 16) * (W // 16)} as the metric",
-            "seconds_per_step": round(dt, 2), "extrapolated": True,
+    return {"value": round(1.0 / dt, 5), "unit": "denoise-steps/s", "cores": cores, "cores_granted": cores, "threads": threads, "kind": "port",
+            "sample": f"1 denoise step (DiT forward) of the restated fp32 oracle (torch CPU, {threads} threads on the {cores} host cores "
+                      f"the cgroup quota grants), same model / {H}x{W} / S={s_txt + (H // 16) * (W // 16)} as the metric",
+            "seconds_per_step": round(dt, 2), "extrapolated": True, "includes_vae": False,
             "seconds_per_image_extrapolated": round(dt * T, 1),
             "sample_256": {"seconds_per_step": round(dt_small, 2), "steps_per_s": round(1.0 / dt_small, 4)}}
 

@@ -80,6 +80,20 @@ PROTOTYPES = {
     "flux2mi_ctx_create": (_I, [_I, _P, C.POINTER(_P)]),
     "flux2mi_ctx_destroy": (_I, [_P]),
     "flux2mi_ctx_sync": (_I, [_P]),
+    "flux2mi_buffer_alloc": (_I, [_P, C.c_size_t, C.POINTER(_P)]),
+    "flux2mi_buffer_free": (_I, [_P, _P]),
+    "flux2mi_buffer_upload": (_I, [_P, _P, _P, C.c_size_t]),
+    "flux2mi_buffer_download": (_I, [_P, _P, _P, C.c_size_t]),
+    "flux2mi_dp_unique_id": (_I, [_P]),
+    "flux2mi_dp_init": (_I, [_P, _I, _I, _P]),
+    "flux2mi_dp_finalize": (_I, [_P]),
+    "flux2mi_dp_rank": (_I, [_P]),
+    "flux2mi_dp_world": (_I, [_P]),
+    "flux2mi_dp_broadcast_embeddings": (_I, [_P, _P, C.c_int64, _I]),
+    "flux2mi_dp_all_gather_images": (_I, [_P, _P, _P, C.c_int64]),
+    "flux2mi_dp_all_reduce_max": (_I, [_P, C.POINTER(C.c_double)]),
+    "flux2mi_array_to_bf16": (_I, [_P, _P, _P]),
+    "flux2mi_dit_load_lora_safetensors": (_I, [_P, C.c_char_p, C.c_float, C.POINTER(_I), C.POINTER(_I)]),
     "flux2mi_ctx_stream": (_P, [_P]),
     "flux2mi_compute_empirical_mu": (_F, [_I, _I]),
     "flux2mi_set_timesteps": (_I, [_I, _I, _F, C.POINTER(_F), _I, _PI, _PI]),
@@ -147,6 +161,7 @@ PROTOTYPES = {
     "flux2mi_textenc_create": (_I, [_P, C.POINTER(TextEncConfig), C.POINTER(_P)]),
     "flux2mi_textenc_destroy": (_I, [_P]),
     "flux2mi_textenc_set_tensor": (_I, [_P, C.c_char_p, _I, C.POINTER(_I64), _I, _P]),
+    "flux2mi_textenc_load_safetensors": (_I, [_P, C.c_char_p, _PI, _PI]),
     "flux2mi_textenc_finalize": (_I, [_P]),
     "flux2mi_textenc_param_bytes": (_I64, [_P]),
     "flux2mi_textenc_forward": (_I, [_P, _P, _I, _I, _I, _P]),

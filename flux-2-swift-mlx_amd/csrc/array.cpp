@@ -159,3 +159,12 @@ extern "C" int flux2mi_array_random_normal(flux2mi_ctx* ctx, const uint32_t key[
     *out = a;
     return FLUX2MI_OK;
 }
+
+// `precomputedEmbeddings: MLXArray?` (f32 [1, S_txt, J]) -> the bf16 device buffer flux2mi_generate_params.txt_emb wants
+// (Flux2Pipeline.swift:1166, :1381-1404: the reference feeds the array to the transformer as is)
+extern "C" int flux2mi_array_to_bf16(flux2mi_ctx* ctx, const flux2mi_array* a, void* dst_bf16_device) {
+    F2_REQUIRE(ctx && a && dst_bf16_device && a->ctx == ctx, FLUX2MI_ERR_INVALID_ARG, "array_to_bf16: bad argument");
+    F2_CHECK_HIP(hipSetDevice(ctx->device));
+    F2_LAUNCH(launch_convert_to_bf16(ctx->stream, a->data, FLUX2MI_F32, reinterpret_cast<uint16_t*>(dst_bf16_device), a->numel()), "array_to_bf16");
+    return FLUX2MI_OK;
+}

@@ -76,11 +76,48 @@ extern "C" int flux2mi_ctx_destroy(flux2mi_ctx* ctx) {
     if (!ctx) return FLUX2MI_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)flux2mi_dp_finalize(ctx);
     for (hipEvent_t e : ctx->prof.pool) (void)hipEventDestroy(e);
     ctx->scratch.release();
     ctx->attn_ws.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return FLUX2MI_OK;
+}
+
+// ---- plain device buffers for a host that has no HIP binding of its own (the Swift shim: prompt embeddings, token ids, image bytes)
+extern "C" int flux2mi_buffer_alloc(flux2mi_ctx* ctx, size_t bytes, void** out) {
+    F2_REQUIRE(ctx && out && bytes > 0, FLUX2MI_ERR_INVALID_ARG, "buffer_alloc: bad argument");
+    F2_CHECK_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {
+        flux2mi_set_error("buffer_alloc: hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return FLUX2MI_ERR_OOM;
+    }
+    return FLUX2MI_OK;
+}
+extern "C" int flux2mi_buffer_free(flux2mi_ctx* ctx, void* p) {
+    F2_REQUIRE(ctx, FLUX2MI_ERR_INVALID_ARG, "buffer_free: NULL ctx");
+    if (!p) return FLUX2MI_OK;
+    F2_CHECK_HIP(hipSetDevice(ctx->device));
+    F2_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // queued work may still read it
+    F2_CHECK_HIP(hipFree(p));
+    return FLUX2MI_OK;
+}
+// host -> device in stream order; the host bytes may be reused on return
+extern "C" int flux2mi_buffer_upload(flux2mi_ctx* ctx, void* dst_device, const void* src_host, size_t bytes) {
+    F2_REQUIRE(ctx && dst_device && src_host && bytes > 0, FLUX2MI_ERR_INVALID_ARG, "buffer_upload: bad argument");
+    F2_CHECK_HIP(hipSetDevice(ctx->device));
+    F2_CHECK_HIP(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    F2_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return FLUX2MI_OK;
+}
+// device -> host behind everything queued on the stream; synchronises
+extern "C" int flux2mi_buffer_download(flux2mi_ctx* ctx, void* dst_host, const void* src_device, size_t bytes) {
+    F2_REQUIRE(ctx && dst_host && src_device && bytes > 0, FLUX2MI_ERR_INVALID_ARG, "buffer_download: bad argument");
+    F2_CHECK_HIP(hipSetDevice(ctx->device));
+    F2_CHECK_HIP(hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    F2_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     return FLUX2MI_OK;
 }
 

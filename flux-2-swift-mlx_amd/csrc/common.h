@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include <string>
 #include <vector>
 #include "../../include/flux2mi.h"
@@ -59,6 +60,8 @@ struct ProfState {
     double flops = 0.0;
 };
 
+struct flux2mi_dp;   // dp.cpp: the RCCL communicator of a data-parallel batch
+
 struct flux2mi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -67,6 +70,7 @@ struct flux2mi_ctx {
     DevBuf scratch;  // small misc scratch
     int n_cu = 0;    // compute units of the device (workgroup slots for the attention's KV-split)
     DevBuf attn_ws;  // partial states of KV-split attention items (attention_split_ws_bytes)
+    flux2mi_dp* dp = nullptr;   // flux2mi_dp_init
 };
 
 // profiling helpers: bracket a launch of class `cls` with events when active.

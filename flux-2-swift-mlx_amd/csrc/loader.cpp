@@ -10,6 +10,7 @@
 // int8 pairs "<key>._data" + "<key>._scale" are de-quantised on the device; "*.input_scale" /
 // "*.output_scale" are skipped (:336-338); other unknown keys are counted and skipped.
 #include <errno.h>
+#include <stdlib.h>
 #include <fcntl.h>
 #include <stdio.h>
 #include <string.h>
@@ -270,4 +271,72 @@ extern "C" int flux2mi_vae_load_safetensors(flux2mi_vae* vae, const char* path, 
         [&](const char* k, int dt, const int64_t* sh, int nd, const void* p) { return flux2mi_vae_set_tensor(vae, k, dt, sh, nd, p); },
         [&](const char*, const int8_t*, const float*, int64_t, int64_t) { return (int)FLUX2MI_ERR_UNKNOWN_KEY; },
         n_loaded, n_skipped);
+}
+
+// Text-encoder checkpoint shards (HF keys; `language_model.` is the prefix of the text model inside the Mistral-Small-3.2 VLM
+// checkpoint).  Keys of layers that are not run, lm_head and vision towers are skipped (FLUX2MI_ERR_UNKNOWN_KEY from set_tensor).
+extern "C" int flux2mi_textenc_load_safetensors(flux2mi_textenc* te, const char* path, int* n_loaded, int* n_skipped) {
+    F2_REQUIRE(te && path, FLUX2MI_ERR_INVALID_ARG, "textenc_load_safetensors: NULL argument");
+    static const char* const prefixes[] = {"language_model.", "text_encoder.", nullptr};
+    return load_all(
+        path, prefixes,
+        [&](const char* k, int dt, const int64_t* sh, int nd, const void* p) { return flux2mi_textenc_set_tensor(te, k, dt, sh, nd, p); },
+        [&](const char*, const int8_t*, const float*, int64_t, int64_t) { return (int)FLUX2MI_ERR_UNKNOWN_KEY; },
+        n_loaded, n_skipped);
+}
+
+// `loadLoRA(LoRAConfig)` (Flux2Pipeline.swift:618-663) for the weights side: LoRA/LoRALoader.swift + WeightLoader.mergeLoRAWeights
+// (Loading/WeightLoader.swift:736-856).  Reads `<layer>.lora_A.weight` [rank, in] / `<layer>.lora_B.weight` [out, rank] pairs, strips
+// the prefixes `base_model.model.`, `transformer.`, `diffusion_model.` one after the other (LoRALoader.swift:132-140), scale =
+// (metadata lora_alpha / lora_rank, default 1) x user_scale, and merges W += s B A into the resident bf16 weights.  Layers this
+// transformer does not have are skipped like in the reference (:783-789) and counted in *n_unmatched; a file in which NO layer
+// matches is an error instead of a LoRA that silently does nothing.
+extern "C" int flux2mi_dit_load_lora_safetensors(flux2mi_dit* dit, const char* path, float user_scale, int* n_merged, int* n_unmatched) {
+    F2_REQUIRE(dit && path, FLUX2MI_ERR_INVALID_ARG, "dit_load_lora_safetensors: NULL argument");
+    MappedFile f;
+    std::map<std::string, TensorInfo> ts;
+    std::map<std::string, std::string> md;
+    const uint8_t* data = nullptr;
+    F2_TRY(parse_safetensors(path, f, ts, &data, &md));
+    float s = 1.0f;
+    {
+        auto r = md.find("lora_rank"), a = md.find("lora_alpha");
+        if (r != md.end() && a != md.end()) {
+            char *e1 = nullptr, *e2 = nullptr;
+            const double rank = strtod(r->second.c_str(), &e1), alpha = strtod(a->second.c_str(), &e2);
+            if (e1 != r->second.c_str() && e2 != a->second.c_str() && rank > 0) s = (float)(alpha / rank);
+        }
+    }
+    s *= user_scale;
+    static const char* const kSuffixA = ".lora_A.weight";
+    int merged = 0, unmatched = 0;
+    std::string first_unmatched;
+    for (const auto& kv : ts) {
+        if (!ends_with(kv.first, kSuffixA)) continue;
+        const std::string base = kv.first.substr(0, kv.first.size() - strlen(kSuffixA));
+        auto b = ts.find(base + ".lora_B.weight");
+        if (b == ts.end()) continue;
+        const TensorInfo &A = kv.second, &B = b->second;
+        const int dt = st_dtype(A.dtype);
+        if (dt < 0 || st_dtype(B.dtype) != dt || A.shape.size() != 2 || B.shape.size() != 2 || A.shape[0] != B.shape[1] ||
+            !bytes_match(A, dt == FLUX2MI_F32 ? 4 : 2) || !bytes_match(B, dt == FLUX2MI_F32 ? 4 : 2)) {
+            flux2mi_set_error("load_lora: '%s': pair '%s': A [rank, in] / B [out, rank] of one float dtype expected", path, base.c_str());
+            return FLUX2MI_ERR_SHAPE;
+        }
+        std::string layer = base;
+        for (const char* pre : {"base_model.model.", "transformer.", "diffusion_model."})
+            if (layer.compare(0, strlen(pre), pre) == 0) layer = layer.substr(strlen(pre));
+        const int r = flux2mi_dit_merge_lora(dit, (layer + ".weight").c_str(), dt, data + A.begin, data + B.begin, (int)A.shape[0], s);
+        if (r == FLUX2MI_ERR_UNKNOWN_KEY) {
+            if (!unmatched++) first_unmatched = layer;
+            continue;
+        }
+        F2_TRY(r);
+        ++merged;
+    }
+    if (n_merged) *n_merged = merged;
+    if (n_unmatched) *n_unmatched = unmatched;
+    F2_REQUIRE(merged > 0, FLUX2MI_ERR_INVALID_ARG, "LoRA '%s': none of its %d layers matches this transformer (first: %s)", path, unmatched,
+               first_unmatched.c_str());
+    return FLUX2MI_OK;
 }

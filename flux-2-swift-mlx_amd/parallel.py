@@ -1,36 +1,63 @@
-"""Batch-level data parallelism across the GPUs of one node.
+"""Batch-level data parallelism across the GPUs of one node — a CALLER of the library's RCCL entry points.
 
-The reference has no distributed code (single process, batch 1).  Images are
-independent units, so the path shards at image granularity: image i -> rank
-i mod world, full model replica per GPU, no collective inside the denoise loop.
-Exactly two exchanges per batch, over RCCL/xGMI on GPUs (backend "nccl") or gloo
-on CPU (tests):
-  * broadcast of the text embeddings [B,S_txt,J] bf16 from rank 0;
-  * all-gather of the decoded u8 images [H,W,3].
+The reference has no distributed code (single process, batch 1).  Images are independent units, so the path shards at image
+granularity: image i -> rank i mod world, full model replica per GPU, no collective inside the denoise loop.  Exactly two
+exchanges per batch, both inside libflux2mi.so on the context's own stream (csrc/dp.cpp, RCCL over xGMI):
+  * flux2mi_dp_broadcast_embeddings: the text embeddings [B,S_txt,J] bf16 from rank 0;
+  * flux2mi_dp_all_gather_images:    the decoded u8 images [H,W,3].
+What stays here is the control plane of one process per GPU: RANK / WORLD_SIZE / MASTER_* from the environment (the
+torchrun contract), a gloo process group on 127.0.0.1 that carries the 128-byte RCCL unique id from rank 0 to the others (and the
+CPU-side barrier), and the stream hand-off between torch's current stream (where the caller's tensors are produced / consumed) and
+the library's stream (where generate and both collectives run, in stream order): `Context._enter()` before, `Context._exit()` after.
+
+`backend="gloo"` WITHOUT an attached context (tests/test_parallel_gloo.py, `bench.py --dry-run`): the same call sequence on CPU
+tensors through torch.distributed — a harness self-test of launcher, rendezvous and index mapping, never a result.
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
 
+_CTX = None          # api.Context with a communicator (attach_context)
+
 
 def init_distributed(backend: Optional[str] = None) -> tuple:
-    """Read RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the env (torchrun contract)."""
+    """Read RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the env (torchrun contract) and join the gloo control group.
+    `backend` is accepted for symmetry with the earlier interface: only "gloo" exists here — the data path is the library's
+    communicator (attach_context), not a torch backend."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # the container hostname may not resolve
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     return rank, world, local
+
+
+def attach_context(ctx) -> None:
+    """Create the RCCL communicator of this rank on `ctx` (flux2mi_dp_init): rank 0 makes the unique id, the gloo group carries
+    it.  With WORLD_SIZE 1 this is a one-rank communicator (the self-test of tests/test_gpu_dp.py); `bench.py` attaches only
+    when world > 1."""
+    global _CTX
+    from ._lib import check, lib
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    ident = (C.c_uint8 * 128)()
+    if rank == 0:
+        check(lib().flux2mi_dp_unique_id(ident))
+    if world > 1:
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0)
+        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+    check(lib().flux2mi_dp_init(ctx.handle, rank, world, ident))
+    _CTX = ctx
 
 
 def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
@@ -38,34 +65,58 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     return [i for i in range(n_items) if i % world == rank]
 
 
+def _world() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
 def broadcast_text_embeddings(emb: Optional[torch.Tensor], shape: Sequence[int], device, src: int = 0) -> torch.Tensor:
-    """Rank `src` holds the text encoder output; everyone gets a copy.  bf16 is moved as
-    raw bytes so that gloo (CPU tests) and RCCL take the same path."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    """Rank `src` holds the text encoder output; everyone gets a copy (exchange 1)."""
+    if _CTX is None and _world() == 1:
         return emb.to(device)
-    if dist.get_rank() == src:
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if rank == src:
         buf = emb.to(device=device, dtype=torch.bfloat16).contiguous()
     else:
         buf = torch.empty(tuple(shape), dtype=torch.bfloat16, device=device)
-    bits = buf.view(torch.uint8)  # raw bytes: gloo (CPU tests) and RCCL take the same path
+    if _CTX is not None:
+        from ._lib import check, lib
+        _CTX._enter()      # the library's stream waits for the producer of `buf` on torch's current stream
+        check(lib().flux2mi_dp_broadcast_embeddings(_CTX.handle, C.c_void_p(buf.data_ptr()), buf.numel(), src))
+        _CTX._exit()       # torch's current stream waits for the broadcast
+        return buf
+    bits = buf.view(torch.uint8)  # gloo on CPU tensors: bf16 as raw bytes
     dist.broadcast(bits, src=src)
     return bits.view(torch.bfloat16)
 
 
 def all_gather_images(local_images: torch.Tensor) -> torch.Tensor:
     """local_images u8 [n_local,H,W,3] (same n_local on every rank) -> [world*n_local,H,W,3]
-    ordered by (slot, rank) so that image i = slot*world + rank keeps its global index."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    ordered by (slot, rank) so that image i = slot*world + rank keeps its global index (exchange 2)."""
+    if _CTX is None and _world() == 1:
         return local_images
-    world = dist.get_world_size()
+    world = _world()
+    local_images = local_images.contiguous()
+    if _CTX is not None:
+        from ._lib import check, lib
+        parts = torch.empty((world,) + tuple(local_images.shape), dtype=torch.uint8, device=local_images.device)
+        _CTX._enter()      # behind flux2mi_generate on the library's stream anyway; also behind the caller's own writes
+        check(lib().flux2mi_dp_all_gather_images(_CTX.handle, C.c_void_p(local_images.data_ptr()), C.c_void_p(parts.data_ptr()),
+                                                local_images.numel()))
+        _CTX._exit()
+        return parts.transpose(0, 1).reshape(-1, *local_images.shape[1:])
     parts = [torch.empty_like(local_images) for _ in range(world)]
-    dist.all_gather(parts, local_images.contiguous())
+    dist.all_gather(parts, local_images)
     stacked = torch.stack(parts, dim=1)  # [n_local, world, H, W, 3]
     return stacked.reshape(-1, *local_images.shape[1:])
 
 
 def finalize():
-    """Tear the process group down (ranks leave together; no-op for a single process)."""
+    """Tear communicator and control group down (ranks leave together; no-op for a single process)."""
+    global _CTX
+    if _CTX is not None:
+        from ._lib import check, lib
+        check(lib().flux2mi_dp_finalize(_CTX.handle))
+        _CTX = None
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -76,9 +127,14 @@ def barrier():
         dist.barrier()
 
 
-def all_reduce_max(value: float, device) -> float:
+def all_reduce_max(value: float, device=None) -> float:
+    if _CTX is not None:
+        from ._lib import check, lib
+        v = C.c_double(value)
+        check(lib().flux2mi_dp_all_reduce_max(_CTX.handle, C.byref(v)))
+        return float(v.value)
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

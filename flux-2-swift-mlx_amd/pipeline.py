@@ -163,44 +163,18 @@ class Flux2Pipeline:
         default 1) x LoRAConfig.effectiveScale, and merges W += s B A into the resident bf16 weights.  Scheduler
         overrides of the config become `activeSchedulerOverrides` (:625-637).  Returns the number of merged layers;
         layers the transformer does not have are skipped like in the reference (:783-789) — a file in which NO layer
-        matches is an error instead of a LoRA that silently does nothing."""
-        from safetensors import safe_open
+        matches is an error instead of a LoRA that silently does nothing.  File parsing, prefix handling and the merge are the
+        library's (flux2mi_dit_load_lora_safetensors, csrc/loader.cpp): the Swift shim calls the same entry point."""
         if not isinstance(config, LoRAConfig):
             config = LoRAConfig(filePath=str(config), scale=scale)
         if self.transformer is None:
             raise Flux2Error(L.ERR_NOT_LOADED, "Transformer")
-        merged, unknown = 0, []
-        with safe_open(config.filePath, framework="pt") as f:
-            md = f.metadata() or {}
-            s = 1.0
-            try:
-                if float(md.get("lora_rank", 0)) > 0:
-                    s = float(md["lora_alpha"]) / float(md["lora_rank"])
-            except (KeyError, ValueError):
-                s = 1.0
-            s *= config.effectiveScale
-            keys = set(f.keys())
-            for k in sorted(keys):
-                if not k.endswith(".lora_A.weight"):
-                    continue
-                base = k[:-len(".lora_A.weight")]
-                kb = base + ".lora_B.weight"
-                if kb not in keys:
-                    continue
-                layer = base
-                for pre in ("base_model.model.", "transformer.", "diffusion_model."):
-                    if layer.startswith(pre):
-                        layer = layer[len(pre):]
-                try:
-                    self.transformer.merge_lora(layer + ".weight", f.get_tensor(k), f.get_tensor(kb), s)
-                    merged += 1
-                except Flux2Error as e:
-                    if e.code != L.ERR_UNKNOWN_KEY:   # a layer this transformer does not have: skip; anything else is an error
-                        raise
-                    unknown.append(layer)
-        if merged == 0:
-            raise Flux2Error(L.ERR_INVALID_ARG, f"LoRA '{config.filePath}': none of its {len(unknown)} layers matches this transformer "
-                                                f"(first: {unknown[:3]})")
+        n_merged, n_unmatched = C.c_int(0), C.c_int(0)
+        self.ctx._enter()
+        check(lib().flux2mi_dit_load_lora_safetensors(self.transformer.handle, str(config.filePath).encode(), float(config.effectiveScale),
+                                                      C.byref(n_merged), C.byref(n_unmatched)))
+        self.ctx._exit()
+        merged = n_merged.value
         self._lora = getattr(self, "_lora", []) + [config.name]
         if config.schedulerOverrides is not None and config.schedulerOverrides.hasOverrides:
             self._lora_scheduler_overrides = config.schedulerOverrides

@@ -62,6 +62,31 @@ const char* flux2mi_last_error(void);
 int flux2mi_ctx_create(int device, void* hip_stream, flux2mi_ctx** out);
 int flux2mi_ctx_destroy(flux2mi_ctx* ctx);
 int flux2mi_ctx_sync(flux2mi_ctx* ctx);                 /* == MLX eval(): stream synchronise */
+/* Plain device buffers for a host without a HIP binding of its own (the Swift shim: prompt embeddings, token ids, image bytes).
+ * upload: the host bytes may be reused on return; download: behind everything queued on the stream, synchronises. */
+int flux2mi_buffer_alloc(flux2mi_ctx* ctx, size_t bytes, void** out);
+int flux2mi_buffer_free(flux2mi_ctx* ctx, void* device_ptr);
+int flux2mi_buffer_upload(flux2mi_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
+int flux2mi_buffer_download(flux2mi_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
+
+/* ---- batch-level data parallelism over RCCL / xGMI (the reference has no distributed code, SURVEY F2 — this
+ * interface is the build's own).  One process per GPU, image i -> rank i mod world, a full replica per GPU, NO collective inside
+ * the denoise loop: per batch one broadcast of the prompt embeddings (the output of flux2mi_textenc_forward on `root`, i.e. what
+ * Flux2Pipeline.swift:1381-1404 computes once per prompt) and one all-gather of the decoded images (:2095, postprocessVAEOutput).
+ * Both are enqueued on the context's stream, in stream order with flux2mi_generate — nothing to hand over, no host sync.
+ * The 128-byte id is made on rank 0 and carried to the other ranks by the host (TCP store, file, environment). */
+#define FLUX2MI_DP_UNIQUE_ID_BYTES 128
+int flux2mi_dp_unique_id(uint8_t* id /* [FLUX2MI_DP_UNIQUE_ID_BYTES] */);
+int flux2mi_dp_init(flux2mi_ctx* ctx, int rank, int world, const uint8_t* id);
+int flux2mi_dp_finalize(flux2mi_ctx* ctx);               /* also done by flux2mi_ctx_destroy */
+int flux2mi_dp_rank(const flux2mi_ctx* ctx);             /* 0 without a communicator */
+int flux2mi_dp_world(const flux2mi_ctx* ctx);            /* 1 without a communicator */
+/* bf16 [n_images, s_txt, joint_dim] device, in place, from `root` */
+int flux2mi_dp_broadcast_embeddings(flux2mi_ctx* ctx, void* embeddings, int64_t elems, int root);
+/* u8 device: local_images [bytes_per_rank] -> all_images [world][bytes_per_rank] (rank-major) */
+int flux2mi_dp_all_gather_images(flux2mi_ctx* ctx, const uint8_t* local_images, uint8_t* all_images, int64_t bytes_per_rank);
+/* max over the ranks of one host f64, in place (the bench's max-over-ranks time; doubles as a barrier); synchronises */
+int flux2mi_dp_all_reduce_max(flux2mi_ctx* ctx, double* value);
 void* flux2mi_ctx_stream(flux2mi_ctx* ctx);             /* hipStream_t */
 
 /* ---- scheduler (host) -------------------------------------------------- */
@@ -179,6 +204,8 @@ int flux2mi_array_mul(flux2mi_ctx* ctx, const flux2mi_array* a, const flux2mi_ar
 /* the hook's returned array -> the library's latent buffer (no-op when it is the same memory) */
 int flux2mi_array_copy_to(flux2mi_ctx* ctx, const flux2mi_array* src, float* dst_device, int64_t n);
 int flux2mi_array_to_host(flux2mi_ctx* ctx, const flux2mi_array* a, float* host);                     /* synchronises */
+/* `precomputedEmbeddings: MLXArray?` f32 -> the bf16 device buffer flux2mi_generate_params.txt_emb takes (Flux2Pipeline.swift:1166) */
+int flux2mi_array_to_bf16(flux2mi_ctx* ctx, const flux2mi_array* a, void* dst_bf16_device);
 /* MLXRandom.normal(shape) with an explicit key (see flux2mi_mlx_random_* for the key bookkeeping) */
 int flux2mi_array_random_normal(flux2mi_ctx* ctx, const uint32_t key[2], const int64_t* shape, int ndim, flux2mi_array** out);
 
@@ -243,7 +270,12 @@ int flux2mi_dit_set_tensor_q8(flux2mi_dit* dit, const char* name, const int8_t* 
  * (WeightLoader.mergeLoRAWeights :736-856, LoRA/LoRAConfig.swift:7-35; scale = alpha/rank x user scale).
  * `name` = checkpoint key of the target weight.  Not available for weight_format 1. */
 int flux2mi_dit_merge_lora(flux2mi_dit* dit, const char* name, int dtype, const void* A, const void* B, int rank,
-                           float scale); /* error if a tensor is missing */
+                           float scale); /* `loadLoRA(LoRAConfig)`, weights side (Flux2Pipeline.swift:618-663, LoRA/LoRALoader.swift:132-140, WeightLoader.swift:736-856):
+ * every `<layer>.lora_A.weight` / `.lora_B.weight` pair of the file, prefixes `base_model.model.` / `transformer.` /
+ * `diffusion_model.` stripped in sequence, scale = (metadata lora_alpha / lora_rank, default 1) x user_scale.  Layers the
+ * transformer does not have are skipped and counted; a file matching no layer is FLUX2MI_ERR_INVALID_ARG. */
+int flux2mi_dit_load_lora_safetensors(flux2mi_dit* dit, const char* path, float user_scale, int* n_merged, int* n_unmatched);
+/* error if a tensor is missing */
 int64_t flux2mi_dit_param_bytes(const flux2mi_dit* dit);
 /* Flux2Transformer2DModel.callAsFunction (Transformer/Flux2Transformer.swift:123-327), async.
  *   latents   f32 [s_img, 128] device  (output tokens first, then reference tokens)
@@ -303,6 +335,9 @@ int flux2mi_textenc_destroy(flux2mi_textenc* te);
  * keys of layers that are not run return FLUX2MI_ERR_UNKNOWN_KEY and can be skipped by the caller. */
 int flux2mi_textenc_set_tensor(flux2mi_textenc* te, const char* name, int dtype, const int64_t* shape, int ndim,
                                const void* data);
+/* every tensor of a .safetensors shard through flux2mi_textenc_set_tensor (prefixes `language_model.` / `text_encoder.` stripped);
+ * keys of layers that are not run, lm_head, vision towers are skipped and counted */
+int flux2mi_textenc_load_safetensors(flux2mi_textenc* te, const char* path, int* n_loaded, int* n_skipped);
 int flux2mi_textenc_finalize(flux2mi_textenc* te);
 int64_t flux2mi_textenc_param_bytes(const flux2mi_textenc* te);
 /* ids i32 [S] on the device; real tokens are [pad_left, pad_left + valid_len): Klein right-pads

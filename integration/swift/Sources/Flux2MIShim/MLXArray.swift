@@ -60,6 +60,14 @@ public final class MLXArray: @unchecked Sendable {
         self.init(handle: h!)
     }
 
+    /// Uninitialised owning array (outputs of encodeImageToPackedSequence / packMaskForLatentBlending, the initial noise's siblings).
+    static func uninitialized(_ shape: [Int]) throws -> MLXArray {
+        var h: OpaquePointer?
+        var sh = shape.map { Int64($0) }
+        try check(flux2mi_array_alloc(MIContext.current, &sh, Int32(sh.count), &h))
+        return MLXArray(handle: h!)
+    }
+
     /// Non-owning view over device memory (the hook's latent buffer, an encoder output).
     static func borrowing(_ ptr: UnsafeMutablePointer<Float>, shape: [Int]) -> MLXArray {
         var h: OpaquePointer?
