@@ -28,7 +28,7 @@ def main():
     kernels = sorted({k[:2] for k in vals}, key=lambda kg: -vals.get(kg + ("SQ_BUSY_CU_CYCLES",), 0.0) * counts.get(kg, 0))
     for kg in kernels:
         g = lambda c: vals.get(kg + (c,), float("nan"))
-        if not ("gemm" in kg[0] or "attn" in kg[0] or "conv2d" in kg[0]):
+        if not any(t in kg[0] for t in ("gemm", "attn", "conv2d", "gn_", "softmax", "groupnorm")):
             continue
         print(f"{kg[0]}  grid {kg[1]}  launches {counts[kg]}")
         print(f"    MFMA busy / (CU busy x 4 SIMDs) {g('SQ_VALU_MFMA_BUSY_CYCLES') / (4.0 * g('SQ_BUSY_CU_CYCLES')):.3f}   "
