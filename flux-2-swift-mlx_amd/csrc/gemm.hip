@@ -341,6 +341,8 @@ size_t gemm_splitk_ws_bytes(int M, int N, int K) {
 
 int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
     if (nprob < 1 || nprob > 2) return 1;
+    if (probs[0].epi == EPI_CONV)   // implicit-GEMM convolutions of the VAE: only the one-wave-per-SIMD kernel has the form
+        return gemm256s_eligible(probs, nprob) ? launch_gemm256s(stream, probs, nprob) : 1;
     bool mfma_ok = true;
     int n_fp8 = 0;
     for (int i = 0; i < nprob; ++i) n_fp8 += probs[i].fp8 ? 1 : 0;

@@ -64,7 +64,9 @@ __device__ __forceinline__ void s_swap32(uint32_t& a, uint32_t& b) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
 
-template <int NI>
+// WIDE (convolutions with <= 128 output channels): a 512 x 128 tile, the four waves stacked along M (wave tile 128 x 128 as before);
+// per K-tile and wave 16 A pieces + 4 W pieces, LDS 2 x (64 + 16) KB = all 160 KB.
+template <int NI, bool WIDE = false>
 struct Sched {
     static constexpr int G = NI * 8;                 // MFMAs (= gaps) per K-step
     static constexpr int T = 2 * G;
@@ -72,8 +74,9 @@ struct Sched {
     static constexpr int B1 = R + 5;
     static constexpr int RD1 = T - R - 6;            // first gap of the next tile's K-step-0 reads
     static constexpr int B2 = RD1 - 2;
-    static constexpr int NPA = NI <= 6 ? 6 : 8;      // live A pieces per wave (rows (j & 3) 32 + .. >= 16 NI are never read)
-    static constexpr int NP = NPA + 8;
+    static constexpr int NPA = WIDE ? 16 : (NI <= 6 ? 6 : 8);   // live A pieces per wave (rows (j & 3) 32 + .. >= 16 NI are never read)
+    static constexpr int NPW = WIDE ? 4 : 8;
+    static constexpr int NP = NPA + NPW;
     static constexpr int Q0 = B1 + 3, Q1 = T - 2;
     static constexpr int q_gap(int n) { return Q0 + (n * (Q1 - Q0) + (NP - 1) / 2) / (NP - 1); }
     static constexpr int piece_at_q(int gap) {
@@ -87,13 +90,13 @@ struct Sched {
         for (int n = 0; n < NP; ++n) c += q_gap(n) < B2 ? 1 : 0;
         return c;
     }
-    static constexpr int a_j(int n) { return NPA == 8 ? n : n + (n >= 3 ? 1 : 0); }   // NPA 6: j = 0,1,2,4,5,6
+    static constexpr int a_j(int n) { return NPA != 6 ? n : n + (n >= 3 ? 1 : 0); }   // NPA 6: j = 0,1,2,4,5,6
     static constexpr bool spaced() {
         for (int n = 0; n + 1 < NP; ++n)
             if (q_gap(n + 1) < q_gap(n) + 2) return false;
         return true;
     }
-    static_assert(B1 < Q0 && B2 > B1 && RD1 + R <= T - 6 + 0 && spaced(), "schedule");
+    static_assert(B1 < Q0 && B2 > B1 && RD1 + R <= T - 6 + 0 && spaced() && (!WIDE || NI == 8), "schedule");
 };
 
 // FP8 (e4m3 operands, v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: 32 cycles each, a K-tile = 128 k = NI x 8 MFMAs).
@@ -115,6 +118,7 @@ struct SchedF {
     static constexpr int RA0 = 33;                    // first of the 8 reads of the next tile's A rows 0-3
     static constexpr int w_gap(int n) { return (n / 2 == 7) ? G - 1 : 32 + (n / 2 + 1) * H1N - 1 + (n % 2); }   // half n % 2 of W operand n / 2
     static constexpr int NPA = NI <= 6 ? 6 : 8;
+    static constexpr int NPW = 8;
     static constexpr int NP = NPA + 8;
     static constexpr int Q0 = B1 + 2, Q1 = G - 2;
     static constexpr int q_gap(int n) { return Q0 + (n * (Q1 - Q0) + (NP - 1) / 2) / (NP - 1); }
@@ -172,12 +176,18 @@ __device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, I...>)
 }
 #define GS_INLINE __attribute__((always_inline))
 
-template <int NI, bool FP8 = false>
+// CONV: the A source of a K-tile jumps by conv_row_jump at every tap row (GemmProblem::conv_*, kernels.h) and the epilogue is EPI_CONV;
+// a separate instantiation, so that the DiT's kernels stay instruction for instruction what they were.
+template <int NI, bool FP8 = false, bool CONV = false, bool WIDE = false>
 __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE];  // 128 KB, the only LDS object
-    using S = std::conditional_t<FP8, SchedF<NI>, Sched<NI>>;
+    static_assert(!WIDE || (CONV && !FP8 && NI == 8), "the 512 x 128 tile exists for the convolution form only");
+    constexpr int PARTA = WIDE ? 4 * PART / 2 : PART;          // bytes of the A rows of a stage (512 or 256 rows x 128 B)
+    constexpr int STG = WIDE ? PARTA + PART / 2 : STAGE;       // A rows + W rows (128 or 256 rows)
+    constexpr int TN = WIDE ? 128 : 256;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STG];  // 128 KB (WIDE: 160 KB), the only LDS object
+    using S = std::conditional_t<FP8, SchedF<NI>, Sched<NI, WIDE>>;
     constexpr int ES = FP8 ? 1 : 2;   // bytes per operand element: the byte geometry of a tile is the same (128-byte rows)
-    constexpr int BMT = 32 * NI, WROWS = 16 * NI;
+    constexpr int BMT = WIDE ? 512 : 32 * NI, WROWS = WIDE ? 128 : 16 * NI;
 
     const int bid = blockIdx.x;
     const int pi = (batch.nprob > 1 && bid >= batch.tile_start1) ? 1 : 0;
@@ -190,19 +200,24 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
 
     const int t = threadIdx.x;
     const int lane = t & 63, wid = t >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = WIDE ? wid : wid >> 1, wn = WIDE ? 0 : wid & 1;
 
     // ---- LDS-DMA sources: piece j of a part -> rows (4j + wid) 8 + (lane >> 3), LDS chunk lane & 7 <- global chunk
     // (lane & 7) ^ ((row >> 1) & 7).  A part row r belongs to wave-row r >> 7: tile row (r & 127) + (r >> 7) WROWS.
-    uint32_t voffA[8], voffW[8];
+    constexpr int NVA = WIDE ? 16 : 8, NVW = WIDE ? 4 : 8;
+    uint32_t voffA[NVA], voffW[NVW];
     {
         const int wr8 = wid * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((wr8 >> 1) & 7);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NVA; ++j) {
             const int r = j * 32 + wr8;
             const int arow = (r & 127) + (r >> 7) * WROWS;
             voffA[j] = (uint32_t)(((size_t)min(m0 + arow, p.M - 1) * p.lda + chunk * (16 / ES)) * ES);
+        }
+#pragma unroll
+        for (int j = 0; j < NVW; ++j) {
+            const int r = j * 32 + wr8;
             voffW[j] = (uint32_t)(((size_t)min(n0 + r, p.N - 1) * p.ldw + chunk * (16 / ES)) * ES);
         }
     }
@@ -211,6 +226,13 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
     const uint32_t m0_wave = __builtin_amdgcn_readfirstlane(lds_base + wid * 1024);   // + j*4096 + part + stage
     const int nk = p.K / (FP8 ? 128 : 64);
+    const int cseg = CONV ? p.conv_seg : 0x7fffffff;
+    const long long cjump = CONV ? p.conv_row_jump : 0;
+    // A source of K-tile kt (bytes from gA): at most three tap rows
+    auto a_src = [&](int kt) GS_INLINE -> const uint8_t* {
+        if constexpr (CONV) return gA + (size_t)kt * 128 + (size_t)((kt >= cseg ? cjump : 0) + (kt >= 2 * cseg ? cjump : 0));
+        else return gA + (size_t)kt * 128;
+    };
 
     f32x4 acc[NI][8];
 #pragma unroll
@@ -222,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     const int frow = lane & 15, fq = lane >> 4;
     const int sw = (frow >> 1) & 7;
     const uint32_t a_frag = lds_base + (wm * 128 + frow) * 128;
-    const uint32_t b_frag = lds_base + PART + (wn * 128 + frow) * 128;
+    const uint32_t b_frag = lds_base + PARTA + (wn * 128 + frow) * 128;
     const uint32_t ch0 = ((0 + fq) ^ sw) << 4, ch1 = ((4 + fq) ^ sw) << 4;
 
     bf16x8 fa0[NI], fb0[8], fa1[NI], fb1[8];
@@ -242,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     // piece n of a K-tile: M0 <- LDS destination (P), then the DMA (Q); A pieces first
     auto piece_p = [&](auto nc, uint32_t mm) GS_INLINE {
         constexpr int n = decltype(nc)::value;
-        constexpr int off = n < S::NPA ? S::a_j(n) * 4096 : PART + (n - S::NPA) * 4096;
+        constexpr int off = n < S::NPA ? S::a_j(n) * 4096 : PARTA + (n - S::NPA) * 4096;
         asm volatile("s_add_u32 m0, %0, %1" ::"s"(mm), "i"(off) : "memory", "scc");   // s_add writes SCC: hipcc may hold a loop condition there
     };
     auto piece_q = [&](auto nc, const uint8_t* sa, const uint8_t* sw_) GS_INLINE {
@@ -267,7 +289,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
         };
         fill_all(m0_wave, gA, gW);
         if (nk > 1) {
-            fill_all(m0_wave + (uint32_t)STAGE, gA + 128, gW + 128);
+            fill_all(m0_wave + (uint32_t)STG, a_src(1), gW + 128);
             asm volatile("s_waitcnt vmcnt(%0)" ::"i"(S::NP) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -280,12 +302,12 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     // ---- one K-tile.  IS: the pieces of tile u+2 are issued; RD: the next tile's first fragments are read
     auto ktile = [&](auto is_c, auto rd_c, int u) GS_INLINE {
         constexpr bool IS = decltype(is_c)::value, RD = decltype(rd_c)::value;
-        const uint32_t st_cur = (uint32_t)((u & 1) * STAGE), st_nxt = (uint32_t)(((u + 1) & 1) * STAGE);
+        const uint32_t st_cur = (uint32_t)((u & 1) * STG), st_nxt = (uint32_t)(((u + 1) & 1) * STG);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const uint32_t ha = a_frag + st_cur + ch1, hb = b_frag + st_cur + ch1;
         const uint32_t ha2 = a_frag + st_nxt + ch0, hb2 = b_frag + st_nxt + ch0;
         const uint32_t mm = m0_wave + st_cur;
-        const uint8_t* sa = gA + (size_t)(u + 2) * 128;
+        const uint8_t* sa = a_src(u + 2);
         const uint8_t* sw_ = gW + (size_t)(u + 2) * 128;
         auto gap = [&](auto gc) GS_INLINE {
             constexpr int I = decltype(gc)::value;
@@ -329,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
         };
         fill_all(m0_wave, gA, gW);
         if (nk > 1) {
-            fill_all(m0_wave + (uint32_t)STAGE, gA + 128, gW + 128);
+            fill_all(m0_wave + (uint32_t)STG, gA + 128, gW + 128);
             asm volatile("s_waitcnt vmcnt(%0)" ::"i"(S::NP) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -351,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     }
     auto ktile8 = [&](auto is_c, auto rd_c, int u) GS_INLINE {
         constexpr bool IS = decltype(is_c)::value, RD = decltype(rd_c)::value;
-        const uint32_t st_cur = (uint32_t)((u & 1) * STAGE), st_nxt = (uint32_t)(((u + 1) & 1) * STAGE);
+        const uint32_t st_cur = (uint32_t)((u & 1) * STG), st_nxt = (uint32_t)(((u + 1) & 1) * STG);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(S::top_allow()) : "memory");   // the youngest reads belong to operands first used behind B1
         const uint32_t hal = a_frag + st_cur + ch0, hah = a_frag + st_cur + ch1;                    // A rows 4.. of this tile
         const uint32_t hal2 = a_frag + st_nxt + ch0, hah2 = a_frag + st_nxt + ch1;                  // next tile
@@ -447,6 +469,100 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
         if constexpr (FP8) return acc[i][j] * (fs_col[j] * fs_row[i]);
         else return acc[i][j];
     };
+    if constexpr (CONV) {
+        // ---- EPI_CONV: GEMM row -> pixel (kernels.h, GemmProblem::conv_*); bias, optional plain-layout residual, bf16 NHWC store.
+        // 16-byte accesses: the 8-byte runs of accumulator blocks 2jp, 2jp + 1 are paired across the fq lanes of a row
+        // (v_permlane16_swap: lane fq then owns the 8 consecutive columns starting at (fq & 1) 16 + (fq >> 1) 8 of the 32-column pair);
+        // the residual is loaded in that arrangement and swapped back in front of the f32 add.  The exchange stays inside a GEMM row,
+        // so the row's validity is uniform across the lanes that trade.
+        uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+        const uint32_t wp = (uint32_t)p.conv_wp, wi = (uint32_t)p.conv_w;
+        const int up = p.conv_up, opad = p.conv_out_padded;
+        const uint32_t wo = up ? 2 * wi : wi;
+        const int cbase = n0 + wn * 128;
+        const bool vec16 = (p.N & 31) == 0 && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+                           (!p.resid || ((p.ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0));
+        f32x4 bsv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = cbase + j * 16 + fq * 4 + r;
+                bsv[j][r] = (p.vec != nullptr && col < p.N) ? p.vec[col] : 0.f;
+            }
+        const int wcol = cbase + (fq & 1) * 16 + (fq >> 1) * 8;
+        // rows in batches of four: the batch's residual loads (16 x 16 B per lane) are all issued before the first is consumed
+        // (issued one by one in front of their use they ran at ~2 TB/s chip-wide: +115 us on a 1024^2 x 128 layer)
+        constexpr int RBATCH = 4;
+#pragma unroll
+        for (int i0 = 0; i0 < NI; i0 += RBATCH) {
+            size_t o_plain[RBATCH], o_out[RBATCH];
+            bool interior[RBATCH], store[RBATCH];
+            uint4 rv[RBATCH][4];
+#pragma unroll
+            for (int ii = 0; ii < RBATCH; ++ii) {
+                const int i = i0 + ii;
+                if (i >= NI) break;
+                const int row = row_base + i * 16;
+                const bool live = row < p.M;
+                const uint32_t q = (uint32_t)min(row, p.M - 1) + wp + 1u;
+                const uint32_t yy = q / wp, xx = q - yy * wp;          // padded coordinates; the row range keeps yy in [1, H]
+                interior[ii] = live && xx >= 1u && xx <= wi;
+                const uint32_t oy = up ? 2u * (yy - 1u) + (uint32_t)p.conv_py : yy - 1u;
+                const uint32_t ox = interior[ii] ? (up ? 2u * (xx - 1u) + (uint32_t)p.conv_px : xx - 1u) : 0u;
+                o_plain[ii] = (size_t)oy * wo + ox;
+                o_out[ii] = opad ? (interior[ii] ? (size_t)(oy + 1u) * (wo + 2u) + (ox + 1u) : (size_t)q) : o_plain[ii];
+                store[ii] = interior[ii] || (live && opad && !up);   // a halo column of a padded output is written as zeros
+                if (vec16 && p.resid) {
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp) {
+                        const int col = wcol + jp * 32;
+                        rv[ii][jp] = make_uint4(0u, 0u, 0u, 0u);
+                        if (interior[ii] && col < p.N) rv[ii][jp] = *reinterpret_cast<const uint4*>(p.resid + o_plain[ii] * p.ldr + col);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < RBATCH; ++ii) {
+                const int i = i0 + ii;
+                if (i >= NI) break;
+                if (vec16) {
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp) {
+                        const int col = wcol + jp * 32;
+                        f32x4 vx = acc[i][2 * jp] + bsv[2 * jp], vy = acc[i][2 * jp + 1] + bsv[2 * jp + 1];
+                        if (p.resid) {
+                            uint4 r4 = rv[ii][jp];
+                            s_swap16(r4.x, r4.z);
+                            s_swap16(r4.y, r4.w);
+                            vx[0] += lo_bf16(r4.x); vx[1] += hi_bf16(r4.x); vx[2] += lo_bf16(r4.y); vx[3] += hi_bf16(r4.y);
+                            vy[0] += lo_bf16(r4.z); vy[1] += hi_bf16(r4.z); vy[2] += lo_bf16(r4.w); vy[3] += hi_bf16(r4.w);
+                        }
+                        uint32_t x0 = pack_bf16x2(vx[0], vx[1]), x1 = pack_bf16x2(vx[2], vx[3]);
+                        uint32_t y0 = pack_bf16x2(vy[0], vy[1]), y1 = pack_bf16x2(vy[2], vy[3]);
+                        s_swap16(x0, y0);
+                        s_swap16(x1, y1);
+                        if (store[ii] && col < p.N)
+                            *reinterpret_cast<uint4*>(C + o_out[ii] * p.ldc + col) = interior[ii] ? make_uint4(x0, x1, y0, y1) : make_uint4(0u, 0u, 0u, 0u);
+                    }
+                } else if (store[ii]) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int col = cbase + j * 16 + fq * 4;
+                        if (col >= p.N) continue;                      // N % 4 == 0 (launcher)
+                        f32x4 v = acc[i][j] + bsv[j];
+                        if (p.resid && interior[ii]) {
+                            const uint2 r2 = *reinterpret_cast<const uint2*>(p.resid + o_plain[ii] * p.ldr + col);
+                            v[0] += lo_bf16(r2.x); v[1] += hi_bf16(r2.x); v[2] += lo_bf16(r2.y); v[3] += hi_bf16(r2.y);
+                        }
+                        *reinterpret_cast<uint2*>(C + o_out[ii] * p.ldc + col) =
+                            interior[ii] ? make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])) : make_uint2(0u, 0u);
+                    }
+                }
+            }
+        }
+        return;
+    }
     int epi = p.epi;
     if (epi == EPI_QKV_MLP) epi = (n0 >= p.n_split) ? EPI_SWIGLU : EPI_BF16;
     if (p.qk_qw != nullptr && epi == EPI_BF16 && n0 < p.qk_cols) {
@@ -736,7 +852,10 @@ bool gemm256s_eligible(const GemmProblem* probs, int nprob) {
 int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
     GemmBatch b;
     b.nprob = nprob;
-    const int ni = gemm256_pick_ni(probs, nprob);
+    int ni = gemm256_pick_ni(probs, nprob);
+    // convolutions with <= 128 output channels: the 512 x 128 tile (a 256-column tile would idle half of every MFMA)
+    const bool wide = probs[0].epi == EPI_CONV && nprob == 1 && probs[0].N <= 128;
+    if (wide) ni = 8;
     int tiles[2] = {0, 0};
     for (int i = 0; i < nprob; ++i) {
         b.p[i] = probs[i];
@@ -745,7 +864,7 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
                         (reinterpret_cast<uintptr_t>(q.C) & 15) || (q.epi != EPI_BF16 && q.epi != EPI_QKV_MLP) ||
                         (q.epi == EPI_QKV_MLP && q.qk_cols > q.n_split)))
             return 1;
-        tiles[i] = ((q.M + 32 * ni - 1) / (32 * ni)) * ((q.N + TN - 1) / TN);
+        tiles[i] = wide ? ((q.M + 511) / 512) * ((q.N + 127) / 128) : ((q.M + 32 * ni - 1) / (32 * ni)) * ((q.N + TN - 1) / TN);
     }
     if (nprob == 1) b.p[1] = probs[0];
     b.tile_start1 = tiles[0];
@@ -770,6 +889,23 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
                     probs[0].M, probs[0].N, probs[0].K, probs[0].fp8 ? " fp8" : "", cyc / kt, cyc / rt * 100.0, rt / kt * 0.01);
         }
     } trace_out{b, stream, tn, probs};
+    if (probs[0].epi == EPI_CONV) {
+        for (int i = 0; i < nprob; ++i) {
+            const GemmProblem& q = probs[i];
+            if (q.epi != EPI_CONV || q.fp8 || q.conv_seg < 2 || q.conv_wp < 3 || q.conv_w != q.conv_wp - 2 || (q.N & 3) || (q.ldc & 3) ||
+                (reinterpret_cast<uintptr_t>(q.C) & 7) || (q.resid && ((q.ldr & 3) || (reinterpret_cast<uintptr_t>(q.resid) & 7))) ||
+                (q.K / 64 + q.conv_seg - 1) / q.conv_seg > 3)
+                return 1;
+        }
+        if (wide) hipLaunchKernelGGL((gemm256s_kernel<8, false, true, true>), grid, block, 0, stream, b);
+        else switch (ni) {
+            case 7: hipLaunchKernelGGL((gemm256s_kernel<7, false, true>), grid, block, 0, stream, b); break;
+            case 6: hipLaunchKernelGGL((gemm256s_kernel<6, false, true>), grid, block, 0, stream, b); break;
+            case 5: hipLaunchKernelGGL((gemm256s_kernel<5, false, true>), grid, block, 0, stream, b); break;
+            default: hipLaunchKernelGGL((gemm256s_kernel<8, false, true>), grid, block, 0, stream, b); break;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
     if (probs[0].fp8) {
         switch (ni) {
             case 7: hipLaunchKernelGGL((gemm256s_kernel<7, true>), grid, block, 0, stream, b); break;

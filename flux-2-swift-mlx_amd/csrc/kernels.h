@@ -21,7 +21,8 @@ enum GemmEpilogue {
     EPI_GATE_RESID = 2, // C f32 += vec[col]*acc                (x += gate * f(y))
     EPI_SWIGLU = 3,     // C2 bf16[row, h] = silu(gate)*value   (interleaved weight rows)
     EPI_QKV_MLP = 4,    // cols < n_split: EPI_BF16 into C; cols >= n_split: EPI_SWIGLU into C2
-    EPI_BIAS_BF16 = 5   // C bf16 = alpha*acc + vec[col] (+ resid[row,col])
+    EPI_BIAS_BF16 = 5,  // C bf16 = alpha*acc + vec[col] (+ resid[row,col])
+    EPI_CONV = 6        // implicit-GEMM convolution (GemmProblem::conv_*): C bf16 NHWC = acc + vec[col] (+ resid), rows remapped to pixels
 };
 
 struct GemmProblem {
@@ -62,6 +63,18 @@ struct GemmProblem {
     const float* qk_pos;
     int qk_cols, qk_row0;
     float qk_qmul, qk_l2t16;
+    // gemm256s, EPI_CONV: a 3x3 (or the 2x2 of an upsample phase) convolution over a ZERO-HALOED NHWC image as a plain GEMM.
+    // The image is stored [(H + 2)][Wp = W + 2][Cin] with a zero border; GEMM row r = padded pixel q = Wp + 1 + r (first interior pixel
+    // on), M = H*Wp - 2, lda = Cin, A = the padded image's base (+ the phase's (py*Wp + px) pixels).  For tap (ky, kx) every row reads
+    // the SAME byte offset (ky*Wp + kx)*Cin*2 from its own address, so with K ordered (ky, kx, c) — the OHWI weight rows as they are —
+    // the A source of K-tile kt is  row + kt*128 + (kt / conv_seg) * conv_row_jump:  conv_seg = taps_x * Cin/64 K-tiles per tap row,
+    // conv_row_jump = (Wp - taps_x) * Cin * 2 bytes.  Rows whose pixel is a halo column compute garbage and are masked in the epilogue.
+    // Output pixel of row r: (y, x) = (q / Wp - 1, q % Wp - 1), valid when 0 <= x < conv_w; conv_up: (2y + conv_py, 2x + conv_px) of a
+    // 2H x 2W image.  conv_out_padded 0: C / resid are plain [Ho][Wo][N]; 1: C is zero-haloed [(Ho + 2)][Wo + 2][N] (halo columns inside
+    // the row range are written as zeros; the first / last halo row are the caller's), resid stays plain.
+    int conv_seg;
+    long long conv_row_jump;
+    int conv_wp, conv_w, conv_up, conv_py, conv_px, conv_out_padded;
 };
 struct GemmBatch {
     GemmProblem p[2];
@@ -216,6 +229,9 @@ int launch_groupnorm_stats(hipStream_t stream, const uint16_t* x, int64_t pixels
 int groupnorm_partial_floats(int64_t pixels, int groups);
 int launch_groupnorm_apply(hipStream_t stream, const uint16_t* x, uint16_t* y, int64_t pixels, int C,
                            const float* ab, int silu);
+// the same, written as a zero-haloed image [(H + 2)][(W + 2)][C] (every pixel of the padded extent, the halo as zeros): the operand of
+// the implicit-GEMM convolution (GemmProblem::conv_*)
+int launch_groupnorm_apply_padded(hipStream_t stream, const uint16_t* x, uint16_t* y_padded, int H, int W, int C, const float* ab, int silu);
 int launch_nchw_f32_to_nhwc_bf16(hipStream_t stream, const float* in, uint16_t* out, int C, int H, int W);
 // same, output channel count C_pad >= C with zeros in the padding (conv_in of the encoder: 3 -> 32)
 int launch_nchw_f32_to_nhwc_bf16_padded(hipStream_t stream, const float* in, uint16_t* out, int C, int C_pad, int H, int W);

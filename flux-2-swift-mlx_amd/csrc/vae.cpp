@@ -13,6 +13,7 @@
 // Encoder tensors are optional: a checkpoint loaded without them can decode but not encode.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -346,18 +347,98 @@ struct Dec {
         F2_LAUNCH(launch_groupnorm_apply(st, x, y, pixels, g.c, v->gn_ab.as<float>(), silu), "groupnorm_apply");
         return FLUX2MI_OK;
     }
-    // x (A) -> A in place; scratch B, C, D
-    int resnet(const ResnetW& r, uint16_t* A, uint16_t* B, uint16_t* C, uint16_t* D, int H, int Wd) {
+    // ---- the heavy 3x3 convolutions as plain GEMMs on the one-wave-per-SIMD kernel (gemm256s.hip, GemmProblem::conv_*): the input is
+    // a ZERO-HALOED image [(H + 2)][(W + 2)][Cin] (written by gn_padded / by the producing convolution), GEMM rows = the padded pixels
+    // from the first to the last interior one, K = (ky, kx, c) = the OHWI weight rows as they are.  Taken when the 256-column tile is
+    // at least 3/4 used and a K-tile is 64 whole channels; the other layers (Cout 128 / 96, conv_in, conv_out, stride 2, 1x1) stay on
+    // vae_kernels.hip.  FLUX2MI_VAE_GEMM=0 (dev library) keeps everything there (A/B runs).
+    bool gemm_ok(const ConvW& c, int H, int Wd) const {
+        static const bool on = [] {
+            const char* e = F2_DEV_ENV("FLUX2MI_VAE_GEMM");
+            return e ? atoi(e) != 0 : true;
+        }();
+        // 256-column tiles at least 3/4 used, or <= 128 columns on the 512 x 128 tile (at least 3/4 used as well)
+        const bool n_ok = c.cout >= 192 || (c.cout <= 128 && c.cout >= 96);
+        return on && c.ks == 3 && c.cin % 64 == 0 && c.cout % 4 == 0 && n_ok && H >= 8 && Wd >= 8 && (long)H * Wd >= 4096;
+    }
+    // GroupNorm(+SiLU) of plain x -> zero-haloed y
+    int gn_padded(const GNW& g, const uint16_t* x, uint16_t* y, int H, int Wd, int silu) {
+        const int64_t pixels = (int64_t)H * Wd;
+        F2_TRY(v->gn_partial.reserve((size_t)groupnorm_partial_floats(pixels, v->cfg.groups) * 4));
+        F2_TRY(v->gn_ab.reserve((size_t)2 * g.c * 4));
+        F2_LAUNCH(launch_groupnorm_stats(st, x, pixels, g.c, v->cfg.groups, F(g.g), F(g.b), 1e-6f,
+                                         v->gn_partial.as<float>(), v->gn_ab.as<float>()), "groupnorm_stats");
+        F2_LAUNCH(launch_groupnorm_apply_padded(st, x, y, H, Wd, g.c, v->gn_ab.as<float>(), silu), "groupnorm_apply_padded");
+        return FLUX2MI_OK;
+    }
+    // 3x3 convolution of the zero-haloed xp -> y (plain [H][W][Cout], or zero-haloed when y_padded); resid plain
+    int conv_gemm(const ConvW& c, const uint16_t* xp, int H, int Wd, const uint16_t* resid, uint16_t* y, bool y_padded) {
+        const int wp = Wd + 2;
+        GemmProblem p;
+        memset(&p, 0, sizeof p);
+        p.A = xp; p.lda = c.cin; p.W = W(c.w); p.ldw = 9 * c.cin; p.C = y; p.ldc = c.cout;
+        p.M = H * wp - 2; p.N = c.cout; p.K = 9 * c.cin; p.epi = EPI_CONV; p.alpha = 1.0f;
+        p.vec = F(c.b); p.resid = resid; p.ldr = c.cout;
+        p.conv_seg = 3 * (c.cin / 64); p.conv_row_jump = (long long)(wp - 3) * c.cin * 2;
+        p.conv_wp = wp; p.conv_w = Wd; p.conv_out_padded = y_padded ? 1 : 0;
+        if (y_padded) {   // the halo pixels in front of the first / behind the last GEMM row: rows 0 and H + 1, plus one pixel each
+            const size_t edge = (size_t)(wp + 1) * c.cout * 2;
+            F2_CHECK_HIP(hipMemsetAsync(y, 0, edge, st));
+            F2_CHECK_HIP(hipMemsetAsync(y + ((size_t)(H + 1) * wp - 1) * c.cout, 0, edge, st));
+        }
+        prof_before(v->ctx, PROF_VAE_CONV);
+        const int r = launch_gemm(st, &p, 1);
+        prof_after(v->ctx, PROF_VAE_CONV, 2.0 * H * Wd * (double)c.cout * c.cin * 9);
+        F2_LAUNCH(r, "conv2d(gemm)");
+        return FLUX2MI_OK;
+    }
+    // nearest-2x + 3x3 convolution = four 2x2 convolutions on the zero-haloed SOURCE xp (w_phase), two phases per launch -> plain [2H][2W][Cout]
+    int upsample_gemm(const ConvW& c, const uint16_t* xp, int H, int Wd, const uint16_t* w_phase, uint16_t* y) {
+        const int wp = Wd + 2, cout_pad = pad32(c.cout);
+        for (int half = 0; half < 2; ++half) {
+            GemmProblem p[2];
+            memset(p, 0, sizeof p);
+            for (int k = 0; k < 2; ++k) {
+                const int ph = half * 2 + k, py = ph >> 1, px = ph & 1;
+                GemmProblem& q = p[k];
+                q.A = xp + ((size_t)py * wp + px) * c.cin; q.lda = c.cin;
+                q.W = w_phase + (size_t)ph * cout_pad * 4 * c.cin; q.ldw = 4 * c.cin;
+                q.C = y; q.ldc = c.cout; q.M = H * wp - 2; q.N = c.cout; q.K = 4 * c.cin; q.epi = EPI_CONV; q.alpha = 1.0f;
+                q.vec = F(c.b); q.ldr = c.cout;
+                q.conv_seg = 2 * (c.cin / 64); q.conv_row_jump = (long long)(wp - 2) * c.cin * 2;
+                q.conv_wp = wp; q.conv_w = Wd; q.conv_up = 1; q.conv_py = py; q.conv_px = px;
+            }
+            prof_before(v->ctx, PROF_VAE_CONV);
+            const int r = launch_gemm(st, p, 2);
+            prof_after(v->ctx, PROF_VAE_CONV, 2.0 * 2 * H * Wd * (double)c.cout * c.cin * 4);
+            F2_LAUNCH(r, "upsample(gemm)");
+        }
+        return FLUX2MI_OK;
+    }
+    // x (A) -> A in place (or, with out_padded, -> out_padded as a zero-haloed image: the operand of a following upsample_gemm);
+    // scratch B, C, D
+    int resnet(const ResnetW& r, uint16_t* A, uint16_t* B, uint16_t* C, uint16_t* D, int H, int Wd, uint16_t* out_padded = nullptr) {
         const int64_t px = (int64_t)H * Wd;
-        F2_TRY(gn(r.n1, A, B, px, 1));
-        F2_TRY(conv(r.c1, B, H, Wd, 0, nullptr, C));
-        F2_TRY(gn(r.n2, C, B, px, 1));
+        if (gemm_ok(r.c1, H, Wd)) {
+            F2_TRY(gn_padded(r.n1, A, B, H, Wd, 1));
+            F2_TRY(conv_gemm(r.c1, B, H, Wd, nullptr, C, false));
+        } else {
+            F2_TRY(gn(r.n1, A, B, px, 1));
+            F2_TRY(conv(r.c1, B, H, Wd, 0, nullptr, C));
+        }
+        const bool g2 = gemm_ok(r.c2, H, Wd);
+        if (g2) F2_TRY(gn_padded(r.n2, C, B, H, Wd, 1));
+        else F2_TRY(gn(r.n2, C, B, px, 1));
         const uint16_t* shortcut = A;
         if (r.has_sc) {
             F2_TRY(conv(r.sc, A, H, Wd, 0, nullptr, D));
             shortcut = D;
         }
-        F2_TRY(conv(r.c2, B, H, Wd, 0, shortcut, A));
+        if (g2) F2_TRY(conv_gemm(r.c2, B, H, Wd, shortcut, out_padded ? out_padded : A, out_padded != nullptr));
+        else {
+            F2_REQUIRE(!out_padded, FLUX2MI_ERR_UNSUPPORTED, "vae: padded resnet output needs the GEMM convolution");
+            F2_TRY(conv(r.c2, B, H, Wd, 0, shortcut, A));
+        }
         return FLUX2MI_OK;
     }
     int lin(const LinW& l, const uint16_t* x, uint16_t* y, int M, int C, const uint16_t* resid) {
@@ -412,6 +493,16 @@ extern "C" int flux2mi_vae_decode(flux2mi_vae* v, const float* z, int h, int w, 
         const size_t ch = (size_t)(i == 0 ? c.channels[3] : (c.channels[3 - i] > c.channels[4 - i] ? c.channels[3 - i] : c.channels[4 - i]));
         if (hw * ch > max_elems) max_elems = hw * ch;
     }
+    // zero-haloed operands of the GEMM convolutions: (H + 2)(W + 2) pixels instead of H W
+    {
+        size_t padded = 0;
+        for (int i = 0; i < 4; ++i) {
+            const size_t hw = (((size_t)h << i) + 2) * (((size_t)w << i) + 2);
+            const size_t ch = (size_t)(i == 0 ? c.channels[3] : (c.channels[3 - i] > c.channels[4 - i] ? c.channels[3 - i] : c.channels[4 - i]));
+            if (hw * ch > padded) padded = hw * ch;
+        }
+        if (padded > max_elems) max_elems = padded;
+    }
     for (int i = 0; i < 4; ++i) F2_TRY(v->act[i].reserve(max_elems * 2));
     F2_TRY(v->zin.reserve((size_t)h * w * 32 * 2));
     Dec d{v, v->ctx->stream};
@@ -428,11 +519,16 @@ extern "C" int flux2mi_vae_decode(flux2mi_vae* v, const float* z, int h, int w, 
     F2_TRY(d.resnet(v->mid1, A, B, C, D, h, w));
     int H = h, W = w;
     for (int i = 0; i < 4; ++i) {
+        // the upsampling convolution on the GEMM kernel reads a zero-haloed source: the block's last resnet writes it that way (into D;
+        // that resnet has no shortcut convolution, D is free)
+        const bool up_gemm = i < 3 && v->up_phase[i].ptr && d.gemm_ok(v->upsample[i], H, W) && d.gemm_ok(v->up[i][c.layers_per_block].c2, H, W) &&
+                             !v->up[i][c.layers_per_block].has_sc;
         for (int j = 0; j < c.layers_per_block + 1; ++j) {
-            F2_TRY(d.resnet(v->up[i][j], A, B, C, D, H, W));
+            F2_TRY(d.resnet(v->up[i][j], A, B, C, D, H, W, (up_gemm && j == c.layers_per_block) ? D : nullptr));
         }
         if (i < 3) {
-            F2_TRY(d.conv(v->upsample[i], A, H, W, 1, nullptr, B, nullptr, nullptr, v->up_phase[i].ptr ? v->up_phase[i].as<uint16_t>() : nullptr));
+            if (up_gemm) F2_TRY(d.upsample_gemm(v->upsample[i], D, H, W, v->up_phase[i].as<uint16_t>(), B));
+            else F2_TRY(d.conv(v->upsample[i], A, H, W, 1, nullptr, B, nullptr, nullptr, v->up_phase[i].ptr ? v->up_phase[i].as<uint16_t>() : nullptr));
             std::swap(A, B);
             H *= 2;
             W *= 2;

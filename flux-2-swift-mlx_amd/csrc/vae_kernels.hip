@@ -426,6 +426,37 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
     }
 }
 
+// The same affine (+SiLU), written as a ZERO-HALOED image [(H + 2)][Wp = W + 2][C] — the operand layout of the implicit-GEMM
+// convolution on gemm256s (kernels.h, GemmProblem::conv_*): every pixel of the padded extent is written, the halo with zeros, so the
+// buffer needs no clearing whatever it held.  blockDim = ppi * cpb threads (<= 256): a thread keeps one 8-channel chunk and its 16
+// coefficients, and walks the padded pixels of its block's range.
+__global__ __launch_bounds__(256) void gn_apply_padded_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int H, int W, int cpb,
+                                                              int ppi, const float* __restrict__ ab, int C, int silu, uint32_t px_per_block) {
+    const int cc = threadIdx.x % cpb, pl = threadIdx.x / cpb;
+    float ca[8], cb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ca[j] = ab[cc * 8 + j]; cb[j] = ab[C + cc * 8 + j]; }
+    const uint32_t wp = (uint32_t)W + 2u, total = ((uint32_t)H + 2u) * wp;
+    const uint32_t q0 = blockIdx.x * px_per_block, q1 = min(total, q0 + px_per_block);
+    for (uint32_t q = q0 + pl; q < q1; q += ppi) {
+        const uint32_t yy = q / wp, xx = q - yy * wp;
+        uint4 o = make_uint4(0u, 0u, 0u, 0u);
+        if (yy >= 1u && yy <= (uint32_t)H && xx >= 1u && xx <= (uint32_t)W) {
+            const uint4 v = *reinterpret_cast<const uint4*>(x + ((size_t)(yy - 1u) * W + (xx - 1u)) * C + cc * 8);
+            float f[8] = {lo_bf16(v.x), hi_bf16(v.x), lo_bf16(v.y), hi_bf16(v.y), lo_bf16(v.z), hi_bf16(v.z), lo_bf16(v.w), hi_bf16(v.w)};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = ca[j] * f[j] + cb[j];
+                if (silu) t = silu_f(t);
+                f[j] = t;
+            }
+            o.x = pack_bf16x2(f[0], f[1]); o.y = pack_bf16x2(f[2], f[3]);
+            o.z = pack_bf16x2(f[4], f[5]); o.w = pack_bf16x2(f[6], f[7]);
+        }
+        *reinterpret_cast<uint4*>(y + (size_t)q * C + cc * 8) = o;
+    }
+}
+
 // ---------------------------------------------------------------- layout helpers
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int C, int HW) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < C * HW; i += gridDim.x * blockDim.x) {
@@ -645,6 +676,16 @@ int launch_groupnorm_apply(hipStream_t stream, const uint16_t* x, uint16_t* y, i
     }
     hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y, nchunks, C >> 3, ab, C,
                        silu);
+    VK_DONE();
+}
+int launch_groupnorm_apply_padded(hipStream_t stream, const uint16_t* x, uint16_t* y_padded, int H, int W, int C, const float* ab, int silu) {
+    if (H <= 0 || W <= 0 || (C & 7) || (C >> 3) > 256) return 1;
+    const int cpb = C >> 3, ppi = 256 / cpb;
+    const uint32_t total = (uint32_t)(H + 2) * (uint32_t)(W + 2);
+    // ~8 pixels per thread, at least 4 blocks per CU's worth of work on a full chip
+    uint32_t ppb = (uint32_t)ppi * 8u;
+    while ((total + ppb - 1) / ppb > 16384u) ppb *= 2u;
+    hipLaunchKernelGGL(gn_apply_padded_kernel, dim3((total + ppb - 1) / ppb), dim3(ppi * cpb), 0, stream, x, y_padded, H, W, cpb, ppi, ab, C, silu, ppb);
     VK_DONE();
 }
 int launch_nchw_f32_to_nhwc_bf16(hipStream_t stream, const float* in, uint16_t* out, int C, int H, int W) {

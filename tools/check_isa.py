@@ -96,20 +96,21 @@ def main():
     text = compile_s("gemm256s")
     check_m0("gemm256s", text, errors)
     for kname, body in kernels(text):
-        m = re.search(r"gemm256s_kernelILi(\d)ELb(\d)E", kname)
+        m = re.search(r"gemm256s_kernelILi(\d)ELb(\d)E(?:Lb(\d)E)?(?:Lb(\d)E)?", kname)
         if not m:
             continue
         ni, fp8 = int(m.group(1)), int(m.group(2))
+        conv, wide = int(m.group(3) or 0), int(m.group(4) or 0)   # the convolution form; its 512 x 128 tile (16 A + 4 W pieces per wave)
         scratch = meta(text, kname, "private_segment_fixed_size")
         spills = meta(text, kname, "vgpr_spill_count")
-        print(f"gemm256s_kernel<{ni}, {'fp8' if fp8 else 'bf16'}>: scratch {scratch} B, spills {spills}")
+        print(f"gemm256s_kernel<{ni}, {'fp8' if fp8 else 'bf16'}{', conv' if conv else ''}{', 512x128' if wide else ''}>: scratch {scratch} B, spills {spills}")
         if scratch:
             errors.append((kname, "scratch", scratch))
         for label, ins in blocks(body):
             if any(i.startswith("v_mfma") for i in ins) and any(i.startswith("scratch_") for i in ins):
                 errors.append((kname, label, "scratch access in a block that issues MFMAs"))
         n_mfma = ni * (8 if fp8 else 16)
-        npieces = (6 if ni <= 6 else 8) + 8
+        npieces = 20 if wide else (6 if ni <= 6 else 8) + 8
         found = False
         for label, ins in blocks(body):
             c = collections.Counter(i.split()[0] for i in ins)
