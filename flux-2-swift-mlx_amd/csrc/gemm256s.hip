@@ -476,89 +476,171 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
         // the residual is loaded in that arrangement and swapped back in front of the f32 add.  The exchange stays inside a GEMM row,
         // so the row's validity is uniform across the lanes that trade.
         uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
-        const uint32_t wp = (uint32_t)p.conv_wp, wi = (uint32_t)p.conv_w;
+        uint32_t wp = (uint32_t)p.conv_wp;
+        // the per-row pixel arithmetic (a division per row) depends on this value only: tie it to a point BEHIND the K loop, or hipcc
+        // hoists it in front of the loop and carries eight registers through it (spills: every VGPR of the loop is spoken for)
+        asm volatile("" : "+s"(wp));
+        const uint32_t wi = (uint32_t)p.conv_w;
         const int up = p.conv_up, opad = p.conv_out_padded;
         const uint32_t wo = up ? 2 * wi : wi;
         const int cbase = n0 + wn * 128;
         const bool vec16 = (p.N & 31) == 0 && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
                            (!p.resid || ((p.ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(p.resid) & 15) == 0));
-        f32x4 bsv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int col = cbase + j * 16 + fq * 4 + r;
-                bsv[j][r] = (p.vec != nullptr && col < p.N) ? p.vec[col] : 0.f;
-            }
         const int wcol = cbase + (fq & 1) * 16 + (fq >> 1) * 8;
-        // rows in batches of four: the batch's residual loads (16 x 16 B per lane) are all issued before the first is consumed
-        // (issued one by one in front of their use they ran at ~2 TB/s chip-wide: +115 us on a 1024^2 x 128 layer)
+        const bool want_gn = p.gn_part != nullptr;
+        float* red = reinterpret_cast<float*>(smem);   // gn_part: [quantity][wave][frow][128 + 1] floats
+        constexpr int RW = 129;
+        // the tile's 128 columns per wave in two halves of 64 (register budget: the accumulators fill the AGPRs, the epilogue lives in
+        // the 256 VGPRs), rows in batches of four: the batch's residual loads (8 x 16 B per lane) are all issued before the first is
+        // consumed (issued one by one in front of their use they ran at ~2 TB/s chip-wide: +115 us on a 1024^2 x 128 layer)
         constexpr int RBATCH = 4;
 #pragma unroll
-        for (int i0 = 0; i0 < NI; i0 += RBATCH) {
-            size_t o_plain[RBATCH], o_out[RBATCH];
-            bool interior[RBATCH], store[RBATCH];
-            uint4 rv[RBATCH][4];
+        for (int h = 0; h < 2; ++h) {
+            typedef float gs_f32x2 __attribute__((ext_vector_type(2)));
+            gs_f32x2 gs[4][2], gq[4][2];    // gn_part: this lane's sums over its valid rows, per (column block of the half, column pair):
+                                            // two-wide so that hipcc emits v_pk_add_f32 / v_pk_fma_f32 (half the VALU issue of the scalar form)
+            f32x4 bsv[4];                   // bias of the half's column blocks
+            int rbase = row_base;           // opaque per half: the rows' pixel arithmetic is recomputed, not carried from one half to the
+            asm volatile("" : "+v"(rbase)); // other (eight rows x several values would not fit next to the batch in flight: spills)
 #pragma unroll
-            for (int ii = 0; ii < RBATCH; ++ii) {
-                const int i = i0 + ii;
-                if (i >= NI) break;
-                const int row = row_base + i * 16;
-                const bool live = row < p.M;
-                const uint32_t q = (uint32_t)min(row, p.M - 1) + wp + 1u;
-                const uint32_t yy = q / wp, xx = q - yy * wp;          // padded coordinates; the row range keeps yy in [1, H]
-                interior[ii] = live && xx >= 1u && xx <= wi;
-                const uint32_t oy = up ? 2u * (yy - 1u) + (uint32_t)p.conv_py : yy - 1u;
-                const uint32_t ox = interior[ii] ? (up ? 2u * (xx - 1u) + (uint32_t)p.conv_px : xx - 1u) : 0u;
-                o_plain[ii] = (size_t)oy * wo + ox;
-                o_out[ii] = opad ? (interior[ii] ? (size_t)(oy + 1u) * (wo + 2u) + (ox + 1u) : (size_t)q) : o_plain[ii];
-                store[ii] = interior[ii] || (live && opad && !up);   // a halo column of a padded output is written as zeros
-                if (vec16 && p.resid) {
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int jp = 0; jp < 4; ++jp) {
-                        const int col = wcol + jp * 32;
-                        rv[ii][jp] = make_uint4(0u, 0u, 0u, 0u);
-                        if (interior[ii] && col < p.N) rv[ii][jp] = *reinterpret_cast<const uint4*>(p.resid + o_plain[ii] * p.ldr + col);
+                for (int r = 0; r < 4; ++r) {
+                    gs[j][r >> 1] = gs_f32x2{0.f, 0.f}; gq[j][r >> 1] = gs_f32x2{0.f, 0.f};
+                    const int col = cbase + (4 * h + j) * 16 + fq * 4 + r;
+                    bsv[j][r] = (p.vec != nullptr && col < p.N) ? p.vec[col] : 0.f;
+                }
+#pragma unroll
+            for (int i0 = 0; i0 < NI; i0 += RBATCH) {
+                uint32_t o_plain[RBATCH], o_out[RBATCH];   // pixel indices
+                bool interior[RBATCH], store[RBATCH];
+                uint4 rv[RBATCH][2];
+#pragma unroll
+                for (int ii = 0; ii < RBATCH; ++ii) {
+                    const int i = i0 + ii;
+                    if (i >= NI) break;
+                    const int row = rbase + i * 16;
+                    const bool live = row < p.M;
+                    const uint32_t q = (uint32_t)min(row, p.M - 1) + wp + 1u;
+                    const uint32_t yy = q / wp, xx = q - yy * wp;          // padded coordinates; the row range keeps yy in [1, H]
+                    interior[ii] = live && xx >= 1u && xx <= wi;
+                    const uint32_t oy = up ? 2u * (yy - 1u) + (uint32_t)p.conv_py : yy - 1u;
+                    const uint32_t ox = interior[ii] ? (up ? 2u * (xx - 1u) + (uint32_t)p.conv_px : xx - 1u) : 0u;
+                    o_plain[ii] = oy * wo + ox;
+                    o_out[ii] = opad ? (interior[ii] ? (oy + 1u) * (wo + 2u) + (ox + 1u) : q) : o_plain[ii];
+                    store[ii] = interior[ii] || (live && opad && !up);   // a halo column of a padded output is written as zeros
+                    if (vec16 && p.resid) {
+#pragma unroll
+                        for (int jq = 0; jq < 2; ++jq) {
+                            const int col = wcol + (2 * h + jq) * 32;
+                            rv[ii][jq] = make_uint4(0u, 0u, 0u, 0u);
+                            if (interior[ii] && col < p.N) rv[ii][jq] = *reinterpret_cast<const uint4*>(p.resid + (size_t)o_plain[ii] * p.ldr + col);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int ii = 0; ii < RBATCH; ++ii) {
+                    const int i = i0 + ii;
+                    if (i >= NI) break;
+                    if (vec16) {
+#pragma unroll
+                        for (int jq = 0; jq < 2; ++jq) {
+                            const int jp = 2 * h + jq;
+                            const int col = wcol + jp * 32;
+                            f32x4 vx = acc[i][2 * jp] + bsv[2 * jq], vy = acc[i][2 * jp + 1] + bsv[2 * jq + 1];
+                            if (p.resid) {
+                                uint4 r4 = rv[ii][jq];
+                                s_swap16(r4.x, r4.z);
+                                s_swap16(r4.y, r4.w);
+                                vx[0] += lo_bf16(r4.x); vx[1] += hi_bf16(r4.x); vx[2] += lo_bf16(r4.y); vx[3] += hi_bf16(r4.y);
+                                vy[0] += lo_bf16(r4.z); vy[1] += hi_bf16(r4.z); vy[2] += lo_bf16(r4.w); vy[3] += hi_bf16(r4.w);
+                            }
+                            if (want_gn) {
+                                const float m = interior[ii] ? 1.0f : 0.0f;
+                                const gs_f32x2 m2 = {m, m};
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) {
+                                    const gs_f32x2 ax = gs_f32x2{vx[2 * k], vx[2 * k + 1]} * m2, ay = gs_f32x2{vy[2 * k], vy[2 * k + 1]} * m2;
+                                    gs[2 * jq][k] += ax; gq[2 * jq][k] += ax * ax;
+                                    gs[2 * jq + 1][k] += ay; gq[2 * jq + 1][k] += ay * ay;
+                                }
+                            }
+                            uint32_t x0 = pack_bf16x2(vx[0], vx[1]), x1 = pack_bf16x2(vx[2], vx[3]);
+                            uint32_t y0 = pack_bf16x2(vy[0], vy[1]), y1 = pack_bf16x2(vy[2], vy[3]);
+                            s_swap16(x0, y0);
+                            s_swap16(x1, y1);
+                            if (store[ii] && col < p.N)
+                                *reinterpret_cast<uint4*>(C + (size_t)o_out[ii] * p.ldc + col) = interior[ii] ? make_uint4(x0, x1, y0, y1) : make_uint4(0u, 0u, 0u, 0u);
+                        }
+                    } else if (store[ii]) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int j = 4 * h + jj;
+                            const int col = cbase + j * 16 + fq * 4;
+                            if (col >= p.N) continue;                      // N % 4 == 0 (launcher)
+                            f32x4 v = acc[i][j] + bsv[jj];
+                            if (p.resid && interior[ii]) {
+                                const uint2 r2 = *reinterpret_cast<const uint2*>(p.resid + (size_t)o_plain[ii] * p.ldr + col);
+                                v[0] += lo_bf16(r2.x); v[1] += hi_bf16(r2.x); v[2] += lo_bf16(r2.y); v[3] += hi_bf16(r2.y);
+                            }
+                            if (want_gn && interior[ii]) {
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) {
+                                    const gs_f32x2 a = {v[2 * k], v[2 * k + 1]};
+                                    gs[jj][k] += a; gq[jj][k] += a * a;
+                                }
+                            }
+                            *reinterpret_cast<uint2*>(C + (size_t)o_out[ii] * p.ldc + col) =
+                                interior[ii] ? make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])) : make_uint2(0u, 0u);
+                        }
                     }
                 }
             }
+            if (want_gn) {
+                // the barrier in front of the first write: LDS holds the last K-tile until every wave has left the K loop
+                if (h == 0) __syncthreads();
 #pragma unroll
-            for (int ii = 0; ii < RBATCH; ++ii) {
-                const int i = i0 + ii;
-                if (i >= NI) break;
-                if (vec16) {
+                for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                    for (int jp = 0; jp < 4; ++jp) {
-                        const int col = wcol + jp * 32;
-                        f32x4 vx = acc[i][2 * jp] + bsv[2 * jp], vy = acc[i][2 * jp + 1] + bsv[2 * jp + 1];
-                        if (p.resid) {
-                            uint4 r4 = rv[ii][jp];
-                            s_swap16(r4.x, r4.z);
-                            s_swap16(r4.y, r4.w);
-                            vx[0] += lo_bf16(r4.x); vx[1] += hi_bf16(r4.x); vx[2] += lo_bf16(r4.y); vx[3] += hi_bf16(r4.y);
-                            vy[0] += lo_bf16(r4.z); vy[1] += hi_bf16(r4.z); vy[2] += lo_bf16(r4.w); vy[3] += hi_bf16(r4.w);
-                        }
-                        uint32_t x0 = pack_bf16x2(vx[0], vx[1]), x1 = pack_bf16x2(vx[2], vx[3]);
-                        uint32_t y0 = pack_bf16x2(vy[0], vy[1]), y1 = pack_bf16x2(vy[2], vy[3]);
-                        s_swap16(x0, y0);
-                        s_swap16(x1, y1);
-                        if (store[ii] && col < p.N)
-                            *reinterpret_cast<uint4*>(C + o_out[ii] * p.ldc + col) = interior[ii] ? make_uint4(x0, x1, y0, y1) : make_uint4(0u, 0u, 0u, 0u);
+                    for (int r = 0; r < 4; ++r) {
+                        const int cc = (4 * h + jj) * 16 + fq * 4 + r;
+                        red[(wid * 16 + frow) * RW + cc] = gs[jj][r >> 1][r & 1];
+                        red[(64 + wid * 16 + frow) * RW + cc] = gq[jj][r >> 1][r & 1];
                     }
-                } else if (store[ii]) {
+            }
+        }
+        if (want_gn) {
+            // ---- the tile's per-channel (sum, sum of squares): one thread per column adds the 16 frow lanes of every wave that holds
+            // the column, in a fixed order
+            __syncthreads();
+            constexpr int NWV = WIDE ? 4 : 2;                 // waves that hold a column
+            const int cidx = WIDE ? (t & 127) : t;            // column of the tile; WIDE: threads 128.. do the squares
+            const int cc = cidx & 127, w0 = WIDE ? 0 : (cidx >> 7);
+            const int col = n0 + cidx;
+            const int quant0 = WIDE ? (t >> 7) : 0;
+            // all reads first (independent), then the sums in a fixed order
+            float va[NWV][16], vb[WIDE ? 1 : NWV][16];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int col = cbase + j * 16 + fq * 4;
-                        if (col >= p.N) continue;                      // N % 4 == 0 (launcher)
-                        f32x4 v = acc[i][j] + bsv[j];
-                        if (p.resid && interior[ii]) {
-                            const uint2 r2 = *reinterpret_cast<const uint2*>(p.resid + o_plain[ii] * p.ldr + col);
-                            v[0] += lo_bf16(r2.x); v[1] += hi_bf16(r2.x); v[2] += lo_bf16(r2.y); v[3] += hi_bf16(r2.y);
-                        }
-                        *reinterpret_cast<uint2*>(C + o_out[ii] * p.ldc + col) =
-                            interior[ii] ? make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])) : make_uint2(0u, 0u);
-                    }
+            for (int w = 0; w < NWV; ++w) {
+                const int wv = WIDE ? w : w * 2 + w0;
+#pragma unroll
+                for (int f = 0; f < 16; ++f) {
+                    va[w][f] = red[(quant0 * 64 + wv * 16 + f) * RW + cc];
+                    if constexpr (!WIDE) vb[w][f] = red[(64 + wv * 16 + f) * RW + cc];
                 }
+            }
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w)
+#pragma unroll
+                for (int f = 0; f < 16; ++f) {
+                    a0 += va[w][f];
+                    if constexpr (!WIDE) a1 += vb[w][f];
+                }
+            if (col < p.N) {
+                float* dst = p.gn_part + ((size_t)tm * p.N + col) * 2;
+                if (WIDE) dst[quant0] = a0;
+                else { dst[0] = a0; dst[1] = a1; }
             }
         }
         return;
@@ -846,6 +928,12 @@ bool gemm256s_eligible(const GemmProblem* probs, int nprob) {
         if ((unsigned long long)q.M * (unsigned long long)q.lda * 2 >= (1ull << 32) || (unsigned long long)q.N * (unsigned long long)q.ldw * 2 >= (1ull << 32)) return false;
     }
     return true;
+}
+
+// GEMM rows per tile the launcher will use for these EPI_CONV problems (= the row count of GemmProblem::gn_part is ceil(M / this))
+int gemm256s_conv_tile_rows(const GemmProblem* probs, int nprob) {
+    if (nprob == 1 && probs[0].N <= 128) return 512;
+    return 32 * gemm256_pick_ni(probs, nprob);
 }
 
 // returns 0 ok / 1 unsupported problem / 2 launch error; the caller has validated the problems

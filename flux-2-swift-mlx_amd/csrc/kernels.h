@@ -75,6 +75,12 @@ struct GemmProblem {
     int conv_seg;
     long long conv_row_jump;
     int conv_wp, conv_w, conv_up, conv_py, conv_px, conv_out_padded;
+    // EPI_CONV, optional: GroupNorm statistics of the OUTPUT from the epilogue.  Row (tile_m of this problem) of gn_part f32
+    // [rows][N][2] receives, per output channel, (sum, sum of squares) of the tile's valid pixels — the f32 values in front of their bf16
+    // rounding, lanes / waves combined in a fixed order through LDS.  gn_part has ceil(M / gemm256s_conv_tile_rows()) rows, every one
+    // written; launch_groupnorm_finalize_channels turns it into the affine: the consumer's GroupNorm then needs no pass over the
+    // tensor for its statistics.  nullptr = off.
+    float* gn_part;
 };
 struct GemmBatch {
     GemmProblem p[2];
@@ -85,6 +91,8 @@ struct GemmBatch {
     int splits;   // 128x128 kernel: K ranges per tile (1 = whole K in one workgroup)
 };
 int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob);
+// GEMM rows per tile launch_gemm will use for these EPI_CONV problems: GemmProblem::gn_part has ceil(M / rows) rows per problem
+int gemm256s_conv_tile_rows(const GemmProblem* probs, int nprob);
 // Workspace launch_gemm wants in GemmProblem::splitk_ws to split the K dimension of a bf16 [M,K] x [N,K]^T product (0 = it would not split)
 size_t gemm_splitk_ws_bytes(int M, int N, int K);
 
@@ -227,6 +235,10 @@ int launch_groupnorm_stats(hipStream_t stream, const uint16_t* x, int64_t pixels
                            const float* gamma, const float* beta, float eps, float* partial /* scratch */,
                            float* ab /* [2*C] */);
 int groupnorm_partial_floats(int64_t pixels, int groups);
+// The same affine from per-channel partial sums f32 [rows][C][2] (GemmProblem::gn_part, written by the producing convolution's
+// epilogue): one workgroup per group, rows combined in f64 in a fixed order.  pixels = the tensor's pixel count.
+int launch_groupnorm_finalize_channels(hipStream_t stream, const float* part, int rows, int64_t pixels, int C, int groups,
+                                       const float* gamma, const float* beta, float eps, float* ab /* [2*C] */);
 int launch_groupnorm_apply(hipStream_t stream, const uint16_t* x, uint16_t* y, int64_t pixels, int C,
                            const float* ab, int silu);
 // the same, written as a zero-haloed image [(H + 2)][(W + 2)][C] (every pixel of the padded extent, the halo as zeros): the operand of

@@ -73,6 +73,7 @@ struct flux2mi_vae {
     DevBuf act[4];                      // A, B, C, D ping-pong activations
     DevBuf aq, ak, av, avt, scores, probs;
     DevBuf gn_partial, gn_ab, zin;
+    DevBuf gn_chan;                     // per-channel GroupNorm partial sums written by the GEMM convolutions' epilogues
 };
 
 namespace {
@@ -236,7 +237,7 @@ extern "C" int flux2mi_vae_destroy(flux2mi_vae* v) {
     for (Param& p : v->params)
         if (p.ptr) (void)hipFree(p.ptr);
     DevBuf* bufs[] = {&v->stage_raw, &v->stage_bf16, &v->act[0], &v->act[1], &v->act[2], &v->act[3], &v->aq, &v->ak,
-                      &v->av, &v->avt, &v->scores, &v->probs, &v->gn_partial, &v->gn_ab, &v->zin, &v->img_in};
+                      &v->av, &v->avt, &v->scores, &v->probs, &v->gn_partial, &v->gn_ab, &v->zin, &v->img_in, &v->gn_chan};
     for (DevBuf* b : bufs) b->release();
     delete v;
     return FLUX2MI_OK;
@@ -319,6 +320,9 @@ namespace {
 struct Dec {
     flux2mi_vae* v;
     hipStream_t st;
+    // GroupNorm statistics that came out of a GEMM convolution's epilogue: valid for the tensor at `of` until it is rewritten
+    const uint16_t* stats_of = nullptr;
+    int stats_rows = 0;
     const uint16_t* W(int i) const { return reinterpret_cast<const uint16_t*>(v->params[i].ptr); }
     const float* F(int i) const { return reinterpret_cast<const float*>(v->params[i].ptr); }
 
@@ -331,6 +335,7 @@ struct Dec {
         a.Hin = Hin; a.Win = Win; a.Cin = c.cin; a.Cout = c.cout; a.ks = c.ks;
         a.upsample = resample > 0; a.downsample = resample < 0;
         a.w_phase = resample > 0 ? w_phase : nullptr;
+        if (y == stats_of) stats_of = nullptr;
         const double ho = resample > 0 ? 2.0 * Hin : resample < 0 ? 0.5 * Hin : Hin;
         const double wo = resample > 0 ? 2.0 * Win : resample < 0 ? 0.5 * Win : Win;
         prof_before(v->ctx, PROF_VAE_CONV);
@@ -339,12 +344,33 @@ struct Dec {
         F2_LAUNCH(r, "conv2d");
         return FLUX2MI_OK;
     }
-    int gn(const GNW& g, const uint16_t* x, uint16_t* y, int64_t pixels, int silu) {
-        F2_TRY(v->gn_partial.reserve((size_t)groupnorm_partial_floats(pixels, v->cfg.groups) * 4));
+    // the per-channel affine of GroupNorm(x): from the producing convolution's epilogue sums when x has them, else two passes
+    int gn_affine(const GNW& g, const uint16_t* x, int64_t pixels) {
         F2_TRY(v->gn_ab.reserve((size_t)2 * g.c * 4));
+        static const bool fuse = [] {
+            const char* e = F2_DEV_ENV("FLUX2MI_VAE_GN_FUSE");
+            return e ? atoi(e) != 0 : true;
+        }();
+        if (fuse && stats_of == x && stats_rows > 0) {
+            F2_LAUNCH(launch_groupnorm_finalize_channels(st, v->gn_chan.as<float>(), stats_rows, pixels, g.c, v->cfg.groups, F(g.g), F(g.b), 1e-6f,
+                                                         v->gn_ab.as<float>()), "groupnorm_finalize_channels");
+            return FLUX2MI_OK;
+        }
+        F2_TRY(v->gn_partial.reserve((size_t)groupnorm_partial_floats(pixels, v->cfg.groups) * 4));
         F2_LAUNCH(launch_groupnorm_stats(st, x, pixels, g.c, v->cfg.groups, F(g.g), F(g.b), 1e-6f,
                                          v->gn_partial.as<float>(), v->gn_ab.as<float>()), "groupnorm_stats");
+        return FLUX2MI_OK;
+    }
+    int gn(const GNW& g, const uint16_t* x, uint16_t* y, int64_t pixels, int silu) {
+        F2_TRY(gn_affine(g, x, pixels));
         F2_LAUNCH(launch_groupnorm_apply(st, x, y, pixels, g.c, v->gn_ab.as<float>(), silu), "groupnorm_apply");
+        if (y == stats_of) stats_of = nullptr;
+        return FLUX2MI_OK;
+    }
+    // room for the epilogue sums of `problems` convolution problems of `rows` partial rows x n channels each
+    int stats_room(int rows, int n, int problems, float** out) {
+        F2_TRY(v->gn_chan.reserve((size_t)rows * problems * n * 2 * 4));
+        *out = v->gn_chan.as<float>();
         return FLUX2MI_OK;
     }
     // ---- the heavy 3x3 convolutions as plain GEMMs on the one-wave-per-SIMD kernel (gemm256s.hip, GemmProblem::conv_*): the input is
@@ -363,12 +389,9 @@ struct Dec {
     }
     // GroupNorm(+SiLU) of plain x -> zero-haloed y
     int gn_padded(const GNW& g, const uint16_t* x, uint16_t* y, int H, int Wd, int silu) {
-        const int64_t pixels = (int64_t)H * Wd;
-        F2_TRY(v->gn_partial.reserve((size_t)groupnorm_partial_floats(pixels, v->cfg.groups) * 4));
-        F2_TRY(v->gn_ab.reserve((size_t)2 * g.c * 4));
-        F2_LAUNCH(launch_groupnorm_stats(st, x, pixels, g.c, v->cfg.groups, F(g.g), F(g.b), 1e-6f,
-                                         v->gn_partial.as<float>(), v->gn_ab.as<float>()), "groupnorm_stats");
+        F2_TRY(gn_affine(g, x, (int64_t)H * Wd));
         F2_LAUNCH(launch_groupnorm_apply_padded(st, x, y, H, Wd, g.c, v->gn_ab.as<float>(), silu), "groupnorm_apply_padded");
+        if (y == stats_of) stats_of = nullptr;
         return FLUX2MI_OK;
     }
     // 3x3 convolution of the zero-haloed xp -> y (plain [H][W][Cout], or zero-haloed when y_padded); resid plain
@@ -376,11 +399,17 @@ struct Dec {
         const int wp = Wd + 2;
         GemmProblem p;
         memset(&p, 0, sizeof p);
+        if (y == stats_of) stats_of = nullptr;
         p.A = xp; p.lda = c.cin; p.W = W(c.w); p.ldw = 9 * c.cin; p.C = y; p.ldc = c.cout;
         p.M = H * wp - 2; p.N = c.cout; p.K = 9 * c.cin; p.epi = EPI_CONV; p.alpha = 1.0f;
         p.vec = F(c.b); p.resid = resid; p.ldr = c.cout;
         p.conv_seg = 3 * (c.cin / 64); p.conv_row_jump = (long long)(wp - 3) * c.cin * 2;
         p.conv_wp = wp; p.conv_w = Wd; p.conv_out_padded = y_padded ? 1 : 0;
+        int srows = 0;
+        if (!y_padded) {   // a plain output feeds a GroupNorm next: its statistics come out of this launch's epilogue
+            srows = (p.M + gemm256s_conv_tile_rows(&p, 1) - 1) / gemm256s_conv_tile_rows(&p, 1);
+            F2_TRY(stats_room(srows, c.cout, 1, &p.gn_part));
+        }
         if (y_padded) {   // the halo pixels in front of the first / behind the last GEMM row: rows 0 and H + 1, plus one pixel each
             const size_t edge = (size_t)(wp + 1) * c.cout * 2;
             F2_CHECK_HIP(hipMemsetAsync(y, 0, edge, st));
@@ -390,11 +419,23 @@ struct Dec {
         const int r = launch_gemm(st, &p, 1);
         prof_after(v->ctx, PROF_VAE_CONV, 2.0 * H * Wd * (double)c.cout * c.cin * 9);
         F2_LAUNCH(r, "conv2d(gemm)");
+        if (srows > 0) { stats_of = y; stats_rows = srows; }
         return FLUX2MI_OK;
     }
     // nearest-2x + 3x3 convolution = four 2x2 convolutions on the zero-haloed SOURCE xp (w_phase), two phases per launch -> plain [2H][2W][Cout]
     int upsample_gemm(const ConvW& c, const uint16_t* xp, int H, int Wd, const uint16_t* w_phase, uint16_t* y) {
         const int wp = Wd + 2, cout_pad = pad32(c.cout);
+        if (y == stats_of) stats_of = nullptr;
+        float* part = nullptr;
+        int srows = 0;
+        {   // the four phase problems are the same size: two per launch, one tile height for both launches
+            GemmProblem probe[2];
+            memset(probe, 0, sizeof probe);
+            for (int k = 0; k < 2; ++k) { probe[k].M = H * wp - 2; probe[k].N = c.cout; probe[k].K = 4 * c.cin; probe[k].epi = EPI_CONV; }
+            const int tr = gemm256s_conv_tile_rows(probe, 2);
+            srows = (H * wp - 2 + tr - 1) / tr;
+            F2_TRY(stats_room(srows, c.cout, 4, &part));
+        }
         for (int half = 0; half < 2; ++half) {
             GemmProblem p[2];
             memset(p, 0, sizeof p);
@@ -407,12 +448,14 @@ struct Dec {
                 q.vec = F(c.b); q.ldr = c.cout;
                 q.conv_seg = 2 * (c.cin / 64); q.conv_row_jump = (long long)(wp - 2) * c.cin * 2;
                 q.conv_wp = wp; q.conv_w = Wd; q.conv_up = 1; q.conv_py = py; q.conv_px = px;
+                q.gn_part = part + (size_t)ph * srows * c.cout * 2;
             }
             prof_before(v->ctx, PROF_VAE_CONV);
             const int r = launch_gemm(st, p, 2);
             prof_after(v->ctx, PROF_VAE_CONV, 2.0 * 2 * H * Wd * (double)c.cout * c.cin * 4);
             F2_LAUNCH(r, "upsample(gemm)");
         }
+        stats_of = y; stats_rows = 4 * srows;
         return FLUX2MI_OK;
     }
     // x (A) -> A in place (or, with out_padded, -> out_padded as a zero-haloed image: the operand of a following upsample_gemm);
@@ -442,6 +485,7 @@ struct Dec {
         return FLUX2MI_OK;
     }
     int lin(const LinW& l, const uint16_t* x, uint16_t* y, int M, int C, const uint16_t* resid) {
+        if (y == stats_of) stats_of = nullptr;
         GemmProblem p;
         memset(&p, 0, sizeof p);
         p.A = x; p.lda = C; p.W = W(l.w); p.ldw = C; p.C = y; p.ldc = C; p.M = M; p.N = C; p.K = C;

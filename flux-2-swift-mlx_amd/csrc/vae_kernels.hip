@@ -397,6 +397,45 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
+// Statistics from the producing convolution's epilogue (GemmProblem::gn_part): part f32 [rows][C][2].  One workgroup per group;
+// thread t adds rows t, t + 256, ... of the group's channels in f64, the 256 threads are combined in a fixed order.
+__global__ __launch_bounds__(256) void gn_finalize_channels_kernel(const float* __restrict__ part, int rows, int64_t pixels, int C, int groups,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                   float* __restrict__ ab) {
+    __shared__ double ps[256], pq[256];
+    __shared__ float s_mean, s_rstd;
+    const int g = blockIdx.x, cpg = C / groups, t = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int r = t; r < rows; r += 256) {
+        const float2* pp = reinterpret_cast<const float2*>(part + ((size_t)r * C + (size_t)g * cpg) * 2);
+        for (int c = 0; c < cpg; ++c) {
+            const float2 v = pp[c];
+            s += (double)v.x; q += (double)v.y;
+        }
+    }
+    ps[t] = s; pq[t] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) { ps[t] += ps[t + w]; pq[t] += pq[t + w]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double n = (double)pixels * (double)cpg;
+        const double mean = ps[0] / n;
+        double var = pq[0] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean = (float)mean;
+        s_rstd = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    if (t < cpg) {
+        const int c = g * cpg + t;
+        const float a = s_rstd * gamma[c];
+        ab[c] = a;
+        ab[C + c] = beta[c] - s_mean * a;
+    }
+}
+
 // The grid is sized so that (total threads) % cpb == 0: a thread then sees the same 8 channels in every
 // iteration, its 16 affine coefficients stay in registers and no per-chunk modulo is needed (the 64-bit
 // `i % cpb` + 16 dependent loads of the first form ran at a quarter of the HBM rate).
@@ -659,6 +698,12 @@ int launch_groupnorm_stats(hipStream_t stream, const uint16_t* x, int64_t pixels
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nblocks), dim3(256), 0, stream, x, pixels, C, groups, ppb, partial);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, nblocks, pixels, C, groups, gamma,
                        beta, eps, ab);
+    VK_DONE();
+}
+int launch_groupnorm_finalize_channels(hipStream_t stream, const float* part, int rows, int64_t pixels, int C, int groups,
+                                       const float* gamma, const float* beta, float eps, float* ab) {
+    if (!part || rows <= 0 || pixels <= 0 || C <= 0 || groups <= 0 || C % groups || C / groups > 256) return 1;
+    hipLaunchKernelGGL(gn_finalize_channels_kernel, dim3(groups), dim3(256), 0, stream, part, rows, pixels, C, groups, gamma, beta, eps, ab);
     VK_DONE();
 }
 int launch_groupnorm_apply(hipStream_t stream, const uint16_t* x, uint16_t* y, int64_t pixels, int C,

@@ -52,7 +52,13 @@ def blocks(body):
     parts = re.split(r"\n(\.LBB\d+_\d+):", body)
     for k in range(1, len(parts), 2):
         ins = [l.split(";")[0].strip() for l in parts[k + 1].split("\n") if l.startswith("\t") and not l.lstrip().startswith((";", "."))]
-        yield parts[k], [i for i in ins if i]
+        ins = [i for i in ins if i]
+        # a loop body ends at its backward branch: what follows (a fall-through block hipcc gave no .LBB label) is not part of it
+        for n, i in enumerate(ins):
+            if i.startswith("s_cbranch") and i.split()[-1] == parts[k]:
+                ins = ins[:n + 1]
+                break
+        yield parts[k], ins
 
 
 def meta(text, kname, key):
