@@ -244,6 +244,10 @@ int launch_groupnorm_apply(hipStream_t stream, const uint16_t* x, uint16_t* y, i
 // the same, written as a zero-haloed image [(H + 2)][(W + 2)][C] (every pixel of the padded extent, the halo as zeros): the operand of
 // the implicit-GEMM convolution (GemmProblem::conv_*)
 int launch_groupnorm_apply_padded(hipStream_t stream, const uint16_t* x, uint16_t* y_padded, int H, int W, int C, const float* ab, int silu);
+// The decoder's tail in one kernel: y = conv3x3(SiLU(a_c x + b_c)) to <= 3 channels (C = 128 or 96; w OHWI bf16 with >= 16 rows, rows >=
+// cout zero), f32 NCHW and / or u8 HWC (clip((v + 1) 127.5), truncated).  Returns 1 when the shape is not this kernel's.
+int launch_conv_out_fused(hipStream_t stream, const uint16_t* x, const float* ab, const uint16_t* w, const float* bias, int H, int W, int C,
+                          int cout, float* y_f32_nchw, uint8_t* y_u8_hwc);
 int launch_nchw_f32_to_nhwc_bf16(hipStream_t stream, const float* in, uint16_t* out, int C, int H, int W);
 // same, output channel count C_pad >= C with zeros in the padding (conv_in of the encoder: 3 -> 32)
 int launch_nchw_f32_to_nhwc_bf16_padded(hipStream_t stream, const float* in, uint16_t* out, int C, int C_pad, int H, int W);

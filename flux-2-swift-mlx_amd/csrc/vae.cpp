@@ -578,6 +578,22 @@ extern "C" int flux2mi_vae_decode(flux2mi_vae* v, const float* z, int h, int w, 
             W *= 2;
         }
     }
+    // conv_norm_out -> SiLU -> conv_out: one kernel at the production widths (the normalised tensor is never written), two otherwise
+    {
+        static const bool tail_fuse = [] {
+            const char* e = F2_DEV_ENV("FLUX2MI_VAE_TAIL_FUSE");
+            return e ? atoi(e) != 0 : true;
+        }();
+        const ConvW& co = v->conv_out;
+        if (tail_fuse && (co.cin == 128 || co.cin == 96) && co.cout <= 3 && co.ks == 3) {
+            F2_TRY(d.gn_affine(v->norm_out, A, (int64_t)H * W));
+            prof_before(v->ctx, PROF_VAE_CONV);
+            const int r = launch_conv_out_fused(d.st, A, v->gn_ab.as<float>(), d.W(co.w), d.F(co.b), H, W, co.cin, co.cout, out_f32, out_u8);
+            prof_after(v->ctx, PROF_VAE_CONV, 2.0 * H * W * (double)co.cout * co.cin * 9);
+            F2_LAUNCH(r, "conv_out(fused)");
+            return FLUX2MI_OK;
+        }
+    }
     F2_TRY(d.gn(v->norm_out, A, B, (int64_t)H * W, 1));
     F2_TRY(d.conv(v->conv_out, B, H, W, 0, nullptr, nullptr, out_f32, out_u8));
     return FLUX2MI_OK;

@@ -496,6 +496,109 @@ __global__ __launch_bounds__(256) void gn_apply_padded_kernel(const uint16_t* __
     }
 }
 
+// ---------------------------------------------------------------- conv_out with the final GroupNorm folded in
+// decoder tail (VAEDecoder.swift:112-121): conv_norm_out -> SiLU -> conv_out 3x3 C -> 3, at full resolution.  As two kernels that is a
+// pass writing the activated [H][W][C] tensor (268 MB at 1024^2 x 128) and a convolution whose 3 output channels leave 29 of the 32
+// columns of its tile idle (352 us).  Here: one workgroup per 8 x 32 output pixels stages the 10 x 34 halo tile of the RAW input through
+// registers — affine of the GroupNorm (a_c x + b_c), SiLU, bf16 — into LDS (zero outside the image: the convolution pads the ACTIVATED
+// tensor), keeps the 9 x C/32 weight fragments of the 16 (3 live) output channels in registers, and runs 36 MFMA 16x16x32 per 16 pixels
+// with the weights as the A operand: lanes fq = 0 end up with channels 0..2 of pixel frow.  Epilogue as conv2d_kernel's (f32 NCHW and /
+// or clip((v + 1) 127.5) truncated to u8 HWC, Flux2Pipeline.swift:2438-2444).
+template <int C>
+__global__ __launch_bounds__(256) void conv_out_fused_kernel(const uint16_t* __restrict__ x, const float* __restrict__ ab,
+                                                             const uint16_t* __restrict__ w, const float* __restrict__ bias, int H, int W,
+                                                             int cout, float* __restrict__ y_f32_nchw, uint8_t* __restrict__ y_u8_hwc) {
+    constexpr int TY = 8, TX = 32, HY = TY + 2, HX = TX + 2, CP = C / 8, PITCH = (C + 8) * 2, NCB = C / 32;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[HY * HX * PITCH];
+    __shared__ float s_ab[2 * C];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6, frow = lane & 15, fq = lane >> 4;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    for (int i = t; i < 2 * C; i += 256) s_ab[i] = ab[i];
+    // weight fragments: lane (frow = output channel, fq) holds w[frow][tap][cb*32 + fq*8 .. +8]  (OHWI, O zero-padded to 32 rows)
+    bf16x8 wf[9][NCB];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+            wf[tap][cb] = *reinterpret_cast<const bf16x8*>(w + ((size_t)frow * 9 + tap) * C + cb * 32 + fq * 8);
+    __syncthreads();
+    // staging in batches of UNR chunks per thread: the batch's global loads are all in flight before the first is consumed (one by one
+    // the 22 loads of a thread are 22 exposed latencies: 20 us per tile)
+    constexpr int NCH = HY * HX * CP, UNR = 6;
+    for (int base = 0; base < NCH; base += 256 * UNR) {
+        uint4 v[UNR];
+        bool inb[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int idx = base + u * 256 + t;
+            const int px = idx / CP, ch = idx - px * CP;
+            const int ty = px / HX, tx = px - ty * HX;
+            const int gy = y0 + ty - 1, gx = x0 + tx - 1;
+            inb[u] = idx < NCH && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            v[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (inb[u]) v[u] = *reinterpret_cast<const uint4*>(x + ((size_t)gy * W + gx) * C + ch * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int idx = base + u * 256 + t;
+            if (idx >= NCH) break;
+            const int px = idx / CP, ch = idx - px * CP;
+            uint4 o = make_uint4(0u, 0u, 0u, 0u);
+            if (inb[u]) {
+                float f[8] = {lo_bf16(v[u].x), hi_bf16(v[u].x), lo_bf16(v[u].y), hi_bf16(v[u].y), lo_bf16(v[u].z), hi_bf16(v[u].z), lo_bf16(v[u].w), hi_bf16(v[u].w)};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = silu_f(s_ab[ch * 8 + j] * f[j] + s_ab[C + ch * 8 + j]);
+                o.x = pack_bf16x2(f[0], f[1]); o.y = pack_bf16x2(f[2], f[3]);
+                o.z = pack_bf16x2(f[4], f[5]); o.w = pack_bf16x2(f[6], f[7]);
+            }
+            *reinterpret_cast<uint4*>(tile + px * PITCH + ch * 16) = o;
+        }
+    }
+    __syncthreads();
+    // wave `wid`: tile rows 2 wid, 2 wid + 1; two groups of 16 pixels per row
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc[r][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // step s = (tap, cb): the four pixel fragments of step s + 1 are read while the MFMAs of step s run
+    const int lane_off = frow * PITCH + fq * 16;
+    auto frag = [&](int s_, int r, int g) -> bf16x8 {
+        const int tap = s_ / NCB, cb = s_ - tap * NCB, ky = tap / 3, kx = tap - ky * 3;
+        return *reinterpret_cast<const bf16x8*>(tile + ((2 * wid + r + ky) * HX + g * 16 + kx) * PITCH + cb * 64 + lane_off);
+    };
+    bf16x8 pv[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pv[0][k] = frag(0, k >> 1, k & 1);
+#pragma unroll
+    for (int s_ = 0; s_ < 9 * NCB; ++s_) {
+        if (s_ + 1 < 9 * NCB) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pv[(s_ + 1) & 1][k] = frag(s_ + 1, k >> 1, k & 1);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            acc[k >> 1][k & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s_ / NCB][s_ % NCB], pv[s_ & 1][k], acc[k >> 1][k & 1], 0, 0, 0);
+    }
+    if (fq == 0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int gy = y0 + 2 * wid + r, gx = x0 + g * 16 + frow;
+                if (gy >= H || gx >= W) continue;
+                const size_t p = (size_t)gy * W + gx, P = (size_t)H * W;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (c >= cout) break;
+                    const float v = acc[r][g][c] + bias[c];
+                    if (y_f32_nchw) y_f32_nchw[(size_t)c * P + p] = v;
+                    if (y_u8_hwc) y_u8_hwc[p * cout + c] = (uint8_t)fminf(fmaxf((v + 1.0f) * 127.5f, 0.0f), 255.0f);
+                }
+            }
+    }
+}
+
 // ---------------------------------------------------------------- layout helpers
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int C, int HW) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < C * HW; i += gridDim.x * blockDim.x) {
@@ -731,6 +834,15 @@ int launch_groupnorm_apply_padded(hipStream_t stream, const uint16_t* x, uint16_
     uint32_t ppb = (uint32_t)ppi * 8u;
     while ((total + ppb - 1) / ppb > 16384u) ppb *= 2u;
     hipLaunchKernelGGL(gn_apply_padded_kernel, dim3((total + ppb - 1) / ppb), dim3(ppi * cpb), 0, stream, x, y_padded, H, W, cpb, ppi, ab, C, silu, ppb);
+    VK_DONE();
+}
+// GroupNorm affine + SiLU + 3x3 convolution to <= 3 channels in one kernel (conv_out_fused_kernel).  1 = not this kernel's case.
+int launch_conv_out_fused(hipStream_t stream, const uint16_t* x, const float* ab, const uint16_t* w, const float* bias, int H, int W, int C,
+                          int cout, float* y_f32_nchw, uint8_t* y_u8_hwc) {
+    if (!x || !ab || !w || !bias || H <= 0 || W <= 0 || cout < 1 || cout > 3 || (C != 128 && C != 96) || (!y_f32_nchw && !y_u8_hwc)) return 1;
+    const dim3 grid((W + 31) / 32, (H + 7) / 8);
+    if (C == 128) hipLaunchKernelGGL(conv_out_fused_kernel<128>, grid, dim3(256), 0, stream, x, ab, w, bias, H, W, cout, y_f32_nchw, y_u8_hwc);
+    else hipLaunchKernelGGL(conv_out_fused_kernel<96>, grid, dim3(256), 0, stream, x, ab, w, bias, H, W, cout, y_f32_nchw, y_u8_hwc);
     VK_DONE();
 }
 int launch_nchw_f32_to_nhwc_bf16(hipStream_t stream, const float* in, uint16_t* out, int C, int H, int W) {
