@@ -25,26 +25,7 @@
 #include <stdlib.h>
 #include <algorithm>
 
-#ifndef ATTN_DIAG
-#define ATTN_DIAG 0
-#endif
-#if ATTN_DIAG
-// timing-only diagnostic build (hipcc -DATTN_DIAG=1 -> libflux2mi_diag.so, read by tools/attn_diag.py;
-// never shipped): s_memtime stamps around the segments of a tile, summed per wave into a buffer no
-// kernel reads.  Read the SHARES, not the length: the stamps fence the schedule.
-__device__ unsigned long long g_attn_dbg[8];
-#define ATTN_STAMP(acc_)                                                                  \
-    {                                                                                     \
-        unsigned long long n__;                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n__)::"memory");      \
-        __builtin_amdgcn_sched_barrier(0);                                                \
-        acc_ += n__ - dg_t;                                                               \
-        dg_t = n__;                                                                       \
-    }
-#else
 #define ATTN_STAMP(acc_)
-#endif
 namespace {
 
 constexpr int BKV = 64, HD = 128;   // BQ = 32 query rows per wave x NW waves
@@ -192,10 +173,6 @@ __device__ __forceinline__ void attn_item(uint8_t* smem, const uint16_t* __restr
     for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
     __syncthreads();
 
-#if ATTN_DIAG
-    unsigned long long dg_t = 0, dg_qk = 0, dg_sm = 0, dg_pv = 0, dg_st = 0;
-    { unsigned long long z = 0; ATTN_STAMP(z) }
-#endif
     for (int kt = kt0; kt < nt; ++kt) {
         const int buf = (kt - kt0) & 1;
         const int ktn = min(kt + 1, nt - 1);   // the last tile re-fetches itself: harmless, keeps the loop branch-free
@@ -324,12 +301,6 @@ __device__ __forceinline__ void attn_item(uint8_t* smem, const uint16_t* __restr
         __syncthreads();
         ATTN_STAMP(dg_st)
     }
-#if ATTN_DIAG
-    if (lane == 0 && !CAUSAL) {
-        atomicAdd(&g_attn_dbg[1], dg_qk); atomicAdd(&g_attn_dbg[2], dg_sm);
-        atomicAdd(&g_attn_dbg[3], dg_pv); atomicAdd(&g_attn_dbg[4], dg_st); atomicAdd(&g_attn_dbg[5], (unsigned long long)nt);
-    }
-#endif
 #undef ATTN_LOAD_PIECE
 
     // ---- a piece of a KV-split item: raw state for attn_combine_kernel
@@ -562,15 +533,3 @@ int launch_attention_causal(hipStream_t stream, const uint16_t* q, const uint16_
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-#if ATTN_DIAG
-extern "C" int flux2mi_debug_attn_stamps(double* out6, int reset) {
-    unsigned long long h[8] = {0};
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_attn_dbg), sizeof h) != hipSuccess) return 2;
-    for (int i = 0; i < 6; ++i) out6[i] = (double)h[i];
-    if (reset) {
-        unsigned long long z[8] = {0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg), z, sizeof z);
-    }
-    return 0;
-}
-#endif

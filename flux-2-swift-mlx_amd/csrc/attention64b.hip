@@ -1,9 +1,9 @@
-// attention64b.hip — attention64.hip's structure (one wave per SIMD, 4 waves x 64 query rows, LDS-DMA rings, hand-placed tile
+// attention64b.hip — the blocks' attention (one wave per SIMD, 4 waves x 64 query rows, LDS-DMA rings, hand-placed tile
 // loop) on v_mfma_f32_16x16x32_bf16 instead of 32x32x16.
 //
 // Why: at 88 % MFMA issue efficiency attention64 is power-bound (in-loop clock 1.67 GHz), and register-only streams on these
 // boxes sustain 1.94 PF with the 16x16x32 shape against 1.71 PF with 32x32x16 under the same softmax fillers
-// (csrc/experimental/mfma_power_probe.hip, profiles/r02_g_mfma_power_probe.log): the larger shape costs ~13 % more energy per FLOP.
+// (a register-only probe of round 2, profiles/r02_g_mfma_power_probe.log): the larger shape costs ~13 % more energy per FLOP.
 //
 // Operand geometry (lane = (c16 = lane & 15, g4 = lane >> 4)):
 //   S^T tile = K fragment (A: 16 key rows x 32 d) x Q fragment (B: 32 d x 16 queries): lane holds S[q = c16][4 key rows 4 g4 + r].
@@ -13,7 +13,7 @@
 //   every 16-group permuted to 8h + 4a + b): chunk 4 st + g4.  So P^T (B operand of O^T += V^T P^T) is built in the lane from its own
 //   S registers, the V^T fragment (A: 16 d rows x 32 keys) is one ds_read_b128, and no producer changes.
 //   K tile in LDS: [64 keys][256 B], chunk c of row r at c ^ ((r & 7) | ((r >> 4) & 1) << 3) (the 16 rows of a fragment get 16
-//   different keys); V^T tile: [128 d][128 B], chunk c at c ^ ((r >> 1) & 7), as in attention64.hip.
+//   different keys); V^T tile: [128 d][128 B], chunk c at c ^ ((r >> 1) & 7).
 // Per wave: O^T 8 x 4 accumulators (128 AGPRs), K fragments of a tile (64 AGPRs), Q blocks 0, 1 (32 AGPRs), Q blocks 2, 3 (32 VGPRs),
 // S 4 x 4 (64 VGPRs), P 2 x 4 (32), V^T fragments of a tile (64).
 // One iteration i = 136 MFMAs (16 cycles each): QK^T of tile i+1 for query blocks 0, 1 (gaps 0-31) and 2, 3 (32-63), PV of tile i

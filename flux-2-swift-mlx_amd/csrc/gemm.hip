@@ -371,7 +371,7 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
         }
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
-    // large problems -> 256x256 LDS-DMA kernel (gemm256.hip); FLUX2MI_GEMM=128|256 forces a kernel
+    // large problems -> 256x256 LDS-DMA kernel (gemm256s.hip); FLUX2MI_GEMM=128|256 forces a kernel
     {
         static const int force = [] {
             const char* e = F2_DEV_ENV("FLUX2MI_GEMM");

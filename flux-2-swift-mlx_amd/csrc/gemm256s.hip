@@ -1,7 +1,7 @@
 // gemm256s.hip — the large-tile bf16 GEMM with ONE WAVE PER SIMD: 256x256x64 tile, 4 waves of 128x128, the accumulators
 // in AGPRs, operands by LDS-DMA, every instruction of the K loop hand-placed (inline asm in issue order).
 //
-// Same contract, tile order and epilogues as the 8-wave kernel it replaces (csrc/experimental/gemm256.hip, dev library only):
+// Same contract, tile order and epilogues as the 8-wave kernel of round 1 it replaced (removed in round 3; profiles/NOTEBOOK.md):
 // C = A W^T, W [out,in], bf16 or e4m3 (FP8 instantiation) operands.  Why (measured, profiles/r02_f_*): per K-tile the 8-wave form reads
 // 192 KB of fragments from LDS and crosses 8 barriers; with 128x128 wave tiles it is 128 KB and 2 barriers, and with one
 // wave per SIMD the MFMAs issue back to back (16 cycles each) with the auxiliary instructions in the gaps: 2180-2290
@@ -14,7 +14,7 @@
 //     LDS-DMA writes lane-linear, so the swizzle is applied to the per-lane SOURCE address (and to the fragment reads).
 //   * a K-tile is 16 LDS-DMA pieces per wave (global_load_lds_dwordx4, 1 KB each: 8 rows x 128 B; scalar base + 32-bit
 //     lane offset); piece j of wave w covers rows (4j + w) 8 .. + 8 of its part.  Tile heights 224 / 192 / 160 (NI 7 / 6 /
-//     5: wave quantisation, see gemm256.hip) keep the LDS image; for NI <= 6 the two A pieces no wave reads are skipped.
+//     5: wave quantisation, gemm256_pick_ni) keep the LDS image; for NI <= 6 the two A pieces no wave reads are skipped.
 //
 // Schedule of one K-tile u (T = 16 NI MFMAs per wave; fragments of BOTH K-steps live in registers, so a stage is free
 // after the first reads of the iteration and every piece has more than a K-tile to land):
@@ -56,7 +56,7 @@ __device__ __forceinline__ void tile_coords_s(int local, int ntiles, int tiles_m
     tn = in_g / gsz;
 }
 
-// v_permlane16_swap_b32 / v_permlane32_swap_b32: see gemm256.hip
+// v_permlane16_swap_b32 / v_permlane32_swap_b32: rows of 16 lanes traded between two registers (odd rows of a <-> even rows of b; 32: halves)
 __device__ __forceinline__ void s_swap16(uint32_t& a, uint32_t& b) {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     __builtin_amdgcn_sched_barrier(0);   // the epilogue's address arithmetic stays behind the K loop (hoisted into the last K-tile it costs the
                                          // registers the fp8 operands need: spills)
 
-    // ---- epilogue (the code of gemm256.hip's, with a wave's 128 columns taken as two 64-column halves h = 0, 1:
+    // ---- epilogue (with a wave's 128 columns taken as two 64-column halves h = 0, 1:
     // its `wn` is wn*2 + h here and its acc[i][j] is acc[i][4h + j]).  Lane (frow, fq) holds, for output row
     // m0 + wm*WROWS + i*16 + frow, the FOUR CONSECUTIVE columns n0 + wn*128 + j*16 + fq*4 + r of block j = 0..7.
     const int row_base = m0 + wm * WROWS + frow;

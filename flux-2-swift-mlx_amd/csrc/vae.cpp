@@ -385,7 +385,10 @@ struct Dec {
         }();
         // 256-column tiles at least 3/4 used, or <= 128 columns on the 512 x 128 tile (at least 3/4 used as well)
         const bool n_ok = c.cout >= 192 || (c.cout <= 128 && c.cout >= 96);
-        return on && c.ks == 3 && c.cin % 64 == 0 && c.cout % 4 == 0 && n_ok && H >= 8 && Wd >= 8 && (long)H * Wd >= 4096;
+        // the kernel's per-lane source offsets are 32-bit: the zero-haloed operand must stay under 4 GB (2048^2 x 256 channels does; larger
+        // images take the gather kernels)
+        const bool off_ok = (unsigned long long)(H + 2) * (unsigned long long)(Wd + 2) * (unsigned long long)c.cin * 2ull < (1ull << 32);
+        return on && c.ks == 3 && c.cin % 64 == 0 && c.cout % 4 == 0 && n_ok && off_ok && H >= 8 && Wd >= 8 && (long)H * Wd >= 4096;
     }
     // GroupNorm(+SiLU) of plain x -> zero-haloed y
     int gn_padded(const GNW& g, const uint16_t* x, uint16_t* y, int H, int Wd, int silu) {

@@ -72,6 +72,19 @@ def test_vae_standard_decoder_ragged_upsample_phases(flux2mi, ctx):
     _check(of, ou, ref)
 
 
+@pytest.mark.parametrize("variant,h,w", [("standard", 65, 67), ("small", 66, 70)])
+def test_vae_decoder_gemm_convolutions_ragged(flux2mi, ctx, variant, h, w):
+    """The 3x3 convolutions as implicit GEMMs over zero-haloed images (gemm256s.hip, GemmProblem::conv_*; vae.cpp conv_gemm /
+    upsample_gemm; taken from 4096 pixels on) at sizes where nothing is aligned: an odd, non-square latent (65 x 67: padded pitch 69)
+    — every level has a partial last tile, halo columns inside tiles, all four phases of the upsampling GEMMs touching all borders,
+    GroupNorm statistics from partial tiles' epilogues, the 512 x 128 tile at the last level, the fused conv_out tail with ragged 8 x 32
+    tiles — against the oracle's plain restatement (VAEDecoder.swift:91-121, ResnetBlock.swift:122-254)."""
+    from flux2mi import synthetic as syn
+    of, ou, ref = _decode_both(flux2mi, ctx, syn.VAE_PRESETS[variant], h, w)
+    assert tuple(of.shape) == (1, 3, 8 * h, 8 * w)
+    _check(of, ou, ref)
+
+
 # ---- encoder (SURVEY §8f rank 2: VAE encoder + encodeImageToPackedSequence) ---------------------
 def _image(h, w, seed=3):
     g = torch.Generator().manual_seed(seed)

@@ -5,7 +5,7 @@
   their own vmcnt / lgkmcnt, and own M0.  That is only sound while, INSIDE the steady-state loops, hipcc adds nothing of its own:
     * no register copies (v_mov / v_accvgpr_*): a copy of a fragment register could read it before its ds_read has landed
     * no scratch traffic, no vector-memory instruction besides the LDS-DMA pieces (they would shift the counted vmcnt)
-    * no M0 reference besides the DMA setup (tools/check_m0.sh checks the whole object)
+    * no M0 reference besides the DMA setup (check_m0 below: the whole object)
     * exactly the instruction mix the schedule tables describe (MFMA / ds_read / DMA counts per trip)
   and the kernels use no scratch at all; in particular no block that issues an MFMA may touch scratch: a spill store of an accumulator
   placed behind the asm MFMA that writes it stores a register whose result is still in flight.
