@@ -36,7 +36,10 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # the container hostname may not resolve
+            # one node, rendezvous on loopback: the container hostname may not resolve, so both bootstraps (gloo's, and RCCL's
+            # out-of-band socket for the unique id exchange) are pinned to `lo`; the data path is xGMI either way
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     return rank, world, local
 
