@@ -190,6 +190,7 @@ PROTOTYPES = {
     "flux2mi_op_groupnorm_silu": (_I, [_P, _P, _P, C.c_longlong, _I, _I, _P, _P, _F, _I]),
     "flux2mi_op_attention": (_I, [_P, _P, _P, _I, _I]),
     "flux2mi_op_attention_prescaled": (_I, [_P, _P, _P, _I, _I, C.c_float]),
+    "flux2mi_op_attention_qk8": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float]),
     "flux2mi_op_attention_prescaled_range": (_I, [_P, _P, _P, _I, _I, C.c_float, _I, _I, _I]),
 }
 

@@ -409,6 +409,19 @@ class Context:
         self._exit()
         return out
 
+    def op_attention_qk8(self, q8: torch.Tensor, k8: torch.Tensor, v: torch.Tensor, heads: int, q_exp: int, k_exp: int, score_bound_log2: float) -> torch.Tensor:
+        """q8 / k8: e4m3 bytes (torch.float8_e4m3fn or uint8) [S, heads*128], q8 = q 2^q_exp with q pre-scaled by log2(e)/sqrt(128),
+        k8 = k 2^k_exp; v bf16 [S, heads*128]: the fp8 models' attention."""
+        s = v.shape[0]
+        q8 = q8.view(torch.uint8).contiguous()
+        k8 = k8.view(torch.uint8).contiguous()
+        v = _req(v, torch.bfloat16, "v")
+        out = torch.empty((s, heads * 128), dtype=torch.bfloat16, device=v.device)
+        self._enter()
+        check(lib().flux2mi_op_attention_qk8(self.handle, _ptr(q8), _ptr(k8), _ptr(v), _ptr(out), s, heads, q_exp, k_exp, float(score_bound_log2)))
+        self._exit()
+        return out
+
     def op_attention_prescaled_range(self, qkv: torch.Tensor, heads: int, score_bound_log2: float, q0: int, nq: int, nk: int) -> torch.Tensor:
         """Queries [q0, q0+nq) against the key prefix [0, nk) of the full V^T image (the KV-extraction pass's launch shape);
         rows outside the query range come back zero."""

@@ -43,7 +43,7 @@ __device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, I...>)
     (f(ic<I>{}), ...);
 }
 #define B64_INLINE __attribute__((always_inline))
-#define B64_USE (void)o; (void)s; (void)p; (void)kf; (void)vf; (void)qf; (void)lacc; (void)ones; (void)pmask; (void)kfa; (void)vfa; (void)negm;
+#define B64_USE (void)o; (void)s; (void)p; (void)kf; (void)vf; (void)qf; (void)lacc; (void)ones; (void)pmask; (void)kfa; (void)vfa; (void)negm; (void)kf8; (void)qf8; (void)sc_q; (void)sc_k;
 
 // ---- the schedule (gap = the slot behind MFMA number g of the iteration; >= T: the same slot of the NEXT iteration)
 // softmax element e of a half (query blocks 2H, 2H+1): e = st*16 + qh*8 + u*4 + r -> s[2 st + u][2H + qh][r]; pack c = e / 2
@@ -59,6 +59,7 @@ constexpr int BAR_GAP = 64;
 // immediate offsets of the fragments inside a tile image
 constexpr int kimm(int n) { return ((n % 4) / 2) * 8192 + ((n % 4) % 2) * 2048; }   // K fragment kb = n % 4 = 2 st + u: rows 32 st + 8 u
 constexpr int vimm(int n) { return (n % 8) * 2048; }                                // d block n % 8
+constexpr int kimm8(int kb) { return (kb / 2) * 4096 + (kb % 2) * 1024; }           // QK8: K operand kb = 2 st + u of the [64][128 B] tile: rows 32 st + 8 u
 static_assert(x1_gap(31) == T + 24 && c1_gap(15) == T + 31 && vr_gap(15) == 135 && kr_gap(15) == 95 && c0_gap(15) == 131, "schedule");
 
 // DOFF = false: p = 2^s (the caller guarantees |s| <= 80: attention_uses_fixed_offset).  DOFF = true: any scores.  p = 2^(s - m_q) with a
@@ -68,10 +69,15 @@ static_assert(x1_gap(31) == T + 24 && c1_gap(15) == T + 31 && vr_gap(15) == 135 
 // m_q by more than 90 (62 in natural units) shows up in its row sum (>= 2^90, inf or NaN), which the ones-MFMA computes anyway: the
 // workgroup then repeats its pass with that query's offset raised (by log2 of the sum, or by 100 when it overflowed).  Exact for any
 // input; the repeat is a safety net that trained attention does not reach.
-template <bool DOFF>
+// QK8 (fp8 models, plain forwards): Q and K arrive as OCP e4m3 bytes (q8 = q x 2^qe, k8 = k x 2^ke, written by the QK norm + RoPE
+// kernel; `q`, `k` then point at BYTES and ldqk is a byte stride), and S^T = K Q^T is ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16
+// block (K = 128 = the head dim; 32 cycles) instead of four 16x16x32 bf16 MFMAs (64): the power-of-two scales are undone for free by
+// the instruction's e8m0 scale operands.  Everything behind the scores (exp2, P, PV in bf16, row sums) is unchanged, and so is the
+// slot structure of the iteration: the QK^T part keeps its 64 slots, of which every fourth carries an MFMA.
+template <bool DOFF, bool QK8 = false>
 __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, int ldqk,
                                                          const uint16_t* __restrict__ vt, int s_pad, uint16_t* __restrict__ out,
-                                                         int ldo, int Sq, int S, unsigned long long* trace) {
+                                                         int ldo, int Sq, int S, unsigned long long* trace, int qk8_exps) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[3 * KT + 3 * VT];
     __shared__ int s_again;               // DOFF: some wave of the workgroup asks for another pass
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -93,16 +99,31 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = qb*16 + c16][d = 32 ks + 8 g4 + j]; loaded by asm straight into
     // their registers (blocks 0, 1 in AGPRs, 2, 3 in VGPRs); the loads are older than every DMA piece: the prologue's vmcnt covers them
-    bf16x8 qf[4][4];
+    typedef uint32_t b64_u32x8 __attribute__((ext_vector_type(8)));
+    bf16x8 qf[QK8 ? 1 : 4][4];
+    b64_u32x8 qf8[4];            // QK8: lane holds the 32 bytes d = 32 g4 .. of query qb*16 + c16 (B operand of the 16x16x128 MFMA)
+    (void)qf8;
+    if constexpr (!QK8) {
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) {
-        const uint16_t* qp = q + (size_t)min(q0 + qb * 16 + c16, Sq - 1) * ldqk + head * HD + g4 * 8;
+        for (int qb = 0; qb < 4; ++qb) {
+            const uint16_t* qp = q + (size_t)min(q0 + qb * 16 + c16, Sq - 1) * ldqk + head * HD + g4 * 8;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (qb < 2) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(qf[qb][ks]) : "v"(qp), "i"(ks * 64) : "memory");
-            else asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qf[qb][ks]) : "v"(qp), "i"(ks * 64) : "memory");
+            for (int ks = 0; ks < 4; ++ks) {
+                if (qb < 2) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(qf[qb][ks]) : "v"(qp), "i"(ks * 64) : "memory");
+                else asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qf[qb][ks]) : "v"(qp), "i"(ks * 64) : "memory");
+            }
+        }
+    } else {
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            const uint8_t* qp = reinterpret_cast<const uint8_t*>(q) + (size_t)min(q0 + qb * 16 + c16, Sq - 1) * ldqk + head * HD + g4 * 32;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf8[qb].lo) : "v"(qp) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(qf8[qb].hi) : "v"(qp) : "memory");
         }
     }
+    // QK8: the e8m0 scale operands that undo q8 = q 2^qe, k8 = k 2^ke (qk8_exps = qe | ke << 8), in every byte
+    uint32_t sc_q = 0x01010101u * (uint32_t)(127 - (qk8_exps & 0xff)), sc_k = 0x01010101u * (uint32_t)(127 - ((qk8_exps >> 8) & 0xff));
+    asm volatile("" : "+v"(sc_q), "+v"(sc_k));
 
     // ---- LDS-DMA sources.  K piece j of wave w: rows 16 j + 4 w + (lane >> 4), LDS chunk lane & 15 <- global chunk (lane & 15) ^ f(row),
     // f(row) = (row & 7) | ((row >> 4) & 1) << 3; V^T piece j: rows 32 j + 8 w + (lane >> 3), LDS chunk lane & 7 <- global chunk
@@ -114,14 +135,23 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
         for (int j = 0; j < 4; ++j) {
             const int krow = j * 16 + kr, vrow = j * 32 + vr;
             const int fk = (krow & 7) | (((krow >> 4) & 1) << 3);
-            voffK[j] = (uint32_t)krow * (uint32_t)ldqk * 2u + (uint32_t)(((lane & 15) ^ fk) << 4);
-            kmax[j] = (uint32_t)(S - 1) * (uint32_t)ldqk * 2u + (uint32_t)(((lane & 15) ^ fk) << 4);
+            if constexpr (!QK8) {
+                voffK[j] = (uint32_t)krow * (uint32_t)ldqk * 2u + (uint32_t)(((lane & 15) ^ fk) << 4);
+                kmax[j] = (uint32_t)(S - 1) * (uint32_t)ldqk * 2u + (uint32_t)(((lane & 15) ^ fk) << 4);
+            } else {
+                // e4m3 K tile [64 keys][128 B]: piece j (of 2) of wave w = rows 32 j + 8 w + (lane >> 3) — the V^T piece geometry; chunk c
+                // of row r at c ^ f8(r), f8(r) = ((r >> 1) & 3) | ((r >> 4) & 1) << 2 (the 16 rows of a fragment hit 16 different banks)
+                const int r8 = (j & 1) * 32 + vr;
+                const int f8 = ((r8 >> 1) & 3) | (((r8 >> 4) & 1) << 2);
+                voffK[j] = (uint32_t)r8 * (uint32_t)ldqk + (uint32_t)(((lane & 7) ^ f8) << 4);
+                kmax[j] = (uint32_t)(S - 1) * (uint32_t)ldqk + (uint32_t)(((lane & 7) ^ f8) << 4);
+            }
             voffV[j] = (uint32_t)vrow * (uint32_t)s_pad * 2u + (uint32_t)(((lane & 7) ^ ((vrow >> 1) & 7)) << 4);
         }
     }
-    const uint8_t* kb8 = reinterpret_cast<const uint8_t*>(k + head * HD);
+    const uint8_t* kb8 = QK8 ? reinterpret_cast<const uint8_t*>(k) + head * HD : reinterpret_cast<const uint8_t*>(k + head * HD);
     const uint8_t* vb8 = reinterpret_cast<const uint8_t*>(vt + (size_t)head * HD * s_pad);
-    const uint32_t k_tile_bytes = (uint32_t)BKV * (uint32_t)ldqk * 2u;
+    const uint32_t k_tile_bytes = (uint32_t)BKV * (uint32_t)ldqk * (QK8 ? 1u : 2u);
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
     const uint32_t m0_wave = __builtin_amdgcn_readfirstlane(lds_base + wid * 1024);
 
@@ -131,7 +161,13 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
     {
         const int krow = 16 * (c16 >> 3) + 4 * ((c16 >> 2) & 1) + (c16 & 3);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) kfa[ks] = lds_base + krow * 256 + (((ks * 4 + g4) ^ c16) << 4);
+        for (int ks = 0; ks < 4; ++ks) {
+            if constexpr (!QK8) kfa[ks] = lds_base + krow * 256 + (((ks * 4 + g4) ^ c16) << 4);
+            else {   // QK8: kfa[h], h = 0, 1: the two 16-byte halves of the lane's 32 bytes (d = 32 g4 ..) of key row krow
+                const int f8 = ((krow >> 1) & 3) | (((krow >> 4) & 1) << 2);
+                kfa[ks] = lds_base + krow * 128 + ((((2 * g4 + (ks & 1)) ^ f8)) << 4);
+            }
+        }
 #pragma unroll
         for (int st = 0; st < 2; ++st) vfa[st] = lds_base + VRING + c16 * 128 + (((st * 4 + g4) ^ ((c16 >> 1) & 7)) << 4);
     }
@@ -139,7 +175,9 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
     f32x4 o[8][4];               // O^T accumulators [d block][query block]
     f32x4 s[4][4];               // scores [K fragment kb = 2 st + u][query block]
     u32x4 p[2][4];               // P^T operands [k-step of 32 keys][query block]
-    bf16x8 kf[16], vf[16];       // K fragments n = 4 ks + kb (AGPRs), V^T fragments n = 8 st + db
+    bf16x8 kf[QK8 ? 1 : 16], vf[16];   // K fragments n = 4 ks + kb (AGPRs), V^T fragments n = 8 st + db
+    b64_u32x8 kf8[4];            // QK8: K operand kb = 2 st + u (16 key rows x 128 d bytes), halves written by their own ds_read_b128
+    (void)kf8;
     f32x4 lacc[4];               // row sums: every row of the accumulator holds sum_k P[q = c16][k] (A operand = ones)
     f32x4 negm[4];               // DOFF: -m_q of query (qb, c16) in all four components (the C operand that starts an S block)
 #pragma unroll
@@ -192,6 +230,7 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
         const uint32_t mm = pc < 4 ? m0_wave + slot * KT + pc * 4096 : m0_wave + VRING + slot * VT + (pc - 4) * 4096;
         asm volatile("s_mov_b32 m0, %0" ::"s"(mm) : "memory");
     };
+    constexpr int NKP = QK8 ? 2 : 4;   // K pieces per wave and tile (pieces NKP..3 do not exist)
     auto dma_go = [&](auto pc_c, uint32_t tile_off) B64_INLINE {
         constexpr int pc = decltype(pc_c)::value;
         (void)voffK; (void)voffV; (void)kmax; (void)k_srd; (void)v_srd;
@@ -207,6 +246,15 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
 
     // ---- one iteration i: QK^T of tile i+1 (HAS_QK), PV of tile i (HAS_PV); R = i mod 3 (2 for i = -1), -1 = run-time ring slots
     // (defined in front of the pass loop; the MFMA of S block (kb, qb), k-step ks, is also what the offset estimate issues)
+    // QK8: the whole S block (kb, qb) in one MFMA
+    auto qk8_mfma = [&](auto kb_c, auto qb_c, auto off_c) B64_INLINE {
+        constexpr int kb = decltype(kb_c)::value, qb = decltype(qb_c)::value;
+        constexpr bool off = decltype(off_c)::value;
+        B64_USE
+        // (operands in VGPRs: a half-written 8-register AGPR tuple makes hipcc assemble it through v_accvgpr copies)
+        if constexpr (off) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %3, %4, %5 op_sel_hi:[0,0,0]" : "=&v"(s[kb][qb]) : "v"(kf8[kb]), "v"(qf8[qb]), "v"(negm[qb]), "v"(sc_k), "v"(sc_q));
+        else asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0]" : "=&v"(s[kb][qb]) : "v"(kf8[kb]), "v"(qf8[qb]), "v"(sc_k), "v"(sc_q));
+    };
     auto qk_mfma = [&](auto kb_c, auto qb_c, auto ks_c, auto off_c) B64_INLINE {
         constexpr int kb = decltype(kb_c)::value, qb = decltype(qb_c)::value, ks = decltype(ks_c)::value;
         constexpr bool off = decltype(off_c)::value;   // start the block from -m_q instead of 0
@@ -219,6 +267,17 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
             if constexpr (ks == 0 && off) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "v"(qf[qb][ks]), "v"(negm[qb]));
             else if constexpr (ks == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "v"(qf[qb][ks]));
             else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(s[kb][qb]) : "a"(kf[4 * ks + kb]), "v"(qf[qb][ks]));
+        }
+    };
+    // the QK^T slot g (0..63) of an iteration: bf16 = MFMA (ks, kb, qb) of the slot; QK8 = every fourth slot, one whole block
+    auto qk_slot = [&](auto gc, auto off_c) B64_INLINE {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (!QK8) {
+            constexpr int H = g / 32, ks = (g % 32) / 8, kb = (g % 8) / 2, qb = 2 * H + g % 2;
+            qk_mfma(ic<kb>{}, ic<qb>{}, ic<ks>{}, off_c);
+        } else if constexpr (g % 4 == 0) {
+            constexpr int idx = g / 4, H = idx / 8, kb = (idx % 8) / 2, qb = 2 * H + idx % 2;
+            qk8_mfma(ic<kb>{}, ic<qb>{}, off_c);
         }
     };
     // Between the code regions below hipcc may re-assign registers (copies at the region's end): every fragment read and every
@@ -240,33 +299,40 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
             dma_m0(pc, ic<0>{});
             asm volatile("s_nop 0" ::: "memory");
             dma_go(pc, koff(0));
-        }, std::make_integer_sequence<int, 4>{});
+        }, std::make_integer_sequence<int, NKP>{});
         for_seq([&](auto pc) B64_INLINE {
             constexpr int pp = decltype(pc)::value;
-            dma_m0(pc, ic<(pp < 4 ? 1 : 0)>{});
-            asm volatile("s_nop 0" ::: "memory");
-            dma_go(pc, pp < 4 ? koff(1) : voff(0));
+            if constexpr (pp < NKP || pp >= 4) {
+                dma_m0(pc, ic<(pp < 4 ? 1 : 0)>{});
+                asm volatile("s_nop 0" ::: "memory");
+                dma_go(pc, pp < 4 ? koff(1) : voff(0));
+            }
         }, std::make_integer_sequence<int, 8>{});
         for_seq([&](auto pc) B64_INLINE {
             dma_m0(pc, ic<2>{});
             asm volatile("s_nop 0" ::: "memory");
             dma_go(pc, koff(2));
-        }, std::make_integer_sequence<int, 4>{});
-        asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");   // the Q fragments and K(0) have landed everywhere
-        for_seq([&](auto nc) B64_INLINE {
-            constexpr int n = decltype(nc)::value;
-            B64_USE
-            B64_DSR(kf[n], "=a", kfa[n / 4], kimm(n));
-        }, std::make_integer_sequence<int, 16>{});
+        }, std::make_integer_sequence<int, NKP>{});
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(2 * NKP + 4) : "memory");   // the Q fragments and K(0) have landed everywhere
+        if constexpr (!QK8) {
+            for_seq([&](auto nc) B64_INLINE {
+                constexpr int n = decltype(nc)::value;
+                B64_USE
+                B64_DSR(kf[n], "=a", kfa[n / 4], kimm(n));
+            }, std::make_integer_sequence<int, 16>{});
+        } else {
+            for_seq([&](auto nc) B64_INLINE {
+                constexpr int n = decltype(nc)::value, kb = n / 2;
+                B64_USE
+                if constexpr (n % 2 == 0) B64_DSR(kf8[kb].lo, "=v", kfa[0], kimm8(kb));
+                else B64_DSR(kf8[kb].hi, "=v", kfa[1], kimm8(kb));
+            }, std::make_integer_sequence<int, 8>{});
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if constexpr (DOFF) {
         if (pass == 0) {   // m_q = max over KV tile 0 of the query's scores (S(0) from zero; iteration -1 computes it again from -m_q)
-            for_seq([&](auto gc) B64_INLINE {
-                constexpr int g = decltype(gc)::value;
-                constexpr int H = g / 32, ks = (g % 32) / 8, kb = (g % 8) / 2, qb = 2 * H + g % 2;
-                qk_mfma(ic<kb>{}, ic<qb>{}, ic<ks>{}, bc<false>{});
-            }, std::make_integer_sequence<int, 64>{});
+            for_seq([&](auto gc) B64_INLINE { qk_slot(gc, bc<false>{}); }, std::make_integer_sequence<int, 64>{});
             drain();
             // the compiler's own instructions read S only behind the drain: they hang on these (empty) statements' outputs
 #pragma unroll
@@ -310,15 +376,14 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
             if constexpr (g == 60) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // ---- the MFMA
             if constexpr (g < 64) {
-                if constexpr (HAS_QK) {
-                    constexpr int H = g / 32, ks = (g % 32) / 8, kb = (g % 8) / 2, qb = 2 * H + g % 2;
-                    qk_mfma(ic<kb>{}, ic<qb>{}, ic<ks>{}, bc<DOFF>{});
-                }
+                if constexpr (HAS_QK) qk_slot(ic<g>{}, bc<DOFF>{});
             } else if constexpr (HAS_PV) {
                 constexpr int H = (g - 64) / 36, st = ((g - 64) % 36) / 18, m = ((g - 64) % 36) % 18;
                 if constexpr (m < 16) {
                     constexpr int db = m / 2, qb = 2 * H + m % 2;
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(o[db][qb]) : "v"(vf[8 * st + db]), "v"(p[st][qb]));
+                    // (QK8: the e4m3 K / Q operands live in VGPRs — see qk8_mfma — so the V^T fragments take the AGPRs they left)
+                    if constexpr (QK8) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(o[db][qb]) : "a"(vf[8 * st + db]), "v"(p[st][qb]));
+                    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(o[db][qb]) : "v"(vf[8 * st + db]), "v"(p[st][qb]));
                 } else {
                     constexpr int qb = 2 * H + (m - 16);
                     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(lacc[qb]) : "v"(ones), "v"(p[st][qb]));
@@ -332,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
                 asm volatile("v_and_b32 %0, %0, %1" : "+v"(p[(n0 + 1) / 16][((n0 + 1) / 4) % 4][(n0 + 1) % 4]) : "v"(pmask[(n0 + 1) / 16][(n0 + 1) % 4]));
             }
             // ---- fillers, in issue order
-            if constexpr (g == BAR_GAP) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            if constexpr (g == BAR_GAP) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(NKP + 4) : "memory");
             for_seq([&](auto ec) B64_INLINE {
                 constexpr int e = decltype(ec)::value;
                 B64_USE
@@ -357,19 +422,30 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
             for_seq([&](auto nc) B64_INLINE {
                 constexpr int n = decltype(nc)::value;
                 B64_USE (void)kslot_rt; (void)vslot_rt; (void)vslot_prev_rt;
-                if constexpr (HAS_QK && kr_gap(n) == g) { const uint32_t a = kfa[n / 4] + kslot_rt; B64_DSR(kf[n], "=a", a, kslot + kimm(n)); }
-                if constexpr (HAS_QK && vr_gap(n) == g) { const uint32_t a = vfa[n / 8] + vslot_rt; B64_DSR(vf[n], "=v", a, vslot + vimm(n)); }
-                if constexpr (HAS_PV && vr_gap(n) == g + T) { const uint32_t a = vfa[n / 8] + vslot_prev_rt; B64_DSR(vf[n], "=v", a, vslot_prev + vimm(n)); }
+                if constexpr (!QK8 && HAS_QK && kr_gap(n) == g) { const uint32_t a = kfa[n / 4] + kslot_rt; B64_DSR(kf[n], "=a", a, kslot + kimm(n)); }
+                if constexpr (QK8 && HAS_QK && n < 8 && kr_gap(n) == g) {   // operand n / 2 (last read at slot 36 + 8 (n / 2) <= 60), half n % 2
+                    const uint32_t a = kfa[n % 2] + kslot_rt;
+                    if constexpr (n % 2 == 0) B64_DSR(kf8[n / 2].lo, "=v", a, kslot + kimm8(n / 2));
+                    else B64_DSR(kf8[n / 2].hi, "=v", a, kslot + kimm8(n / 2));
+                }
+                if constexpr (HAS_QK && vr_gap(n) == g) {
+                    const uint32_t a = vfa[n / 8] + vslot_rt;
+                    if constexpr (QK8) B64_DSR(vf[n], "=a", a, vslot + vimm(n)); else B64_DSR(vf[n], "=v", a, vslot + vimm(n));
+                }
+                if constexpr (HAS_PV && vr_gap(n) == g + T) {
+                    const uint32_t a = vfa[n / 8] + vslot_prev_rt;
+                    if constexpr (QK8) B64_DSR(vf[n], "=a", a, vslot_prev + vimm(n)); else B64_DSR(vf[n], "=v", a, vslot_prev + vimm(n));
+                }
             }, std::make_integer_sequence<int, 16>{});
             // LDS-DMA: M0 two gaps ahead of the piece
             for_seq([&](auto pc) B64_INLINE {
                 constexpr int pp = decltype(pc)::value;
                 (void)vA; (void)kB; (void)ri;
-                if constexpr (HAS_QK && pp < 4 && dma_gap(pp) - 2 == g) {
+                if constexpr (HAS_QK && pp < NKP && dma_gap(pp) - 2 == g) {
                     if constexpr (CT) dma_m0(pc, ic<(R + 4) % 3>{});
                     else dma_m0_rt(pc, (ri + 1) % 3);
                 }
-                if constexpr (HAS_QK && pp < 4 && dma_gap(pp) == g) dma_go(pc, kB);
+                if constexpr (HAS_QK && pp < NKP && dma_gap(pp) == g) dma_go(pc, kB);
                 if constexpr (HAS_QK && pp >= 4 && dma_gap(pp) - 2 == g + T) {
                     if constexpr (CT) dma_m0(pc, ic<(R + 5) % 3>{});
                     else dma_m0_rt(pc, (ri + 2) % 3);
@@ -455,30 +531,38 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
 // 0 launched / 1 not this kernel's case (the caller falls back) / 2 launch error.
 // Requires: q pre-multiplied by scale*log2(e); data_offset = false: the fixed zero offset valid (the caller checks), true: any scores;
 // vt finite beyond key S - 1 (up to s_pad): those P^T slots are zero, the values themselves are not used.
-// The two instantiations are separate translation units (attention64b_doff.hip includes this file with ATTN64B_DOFF 1): each takes
-// hipcc ~2.5 minutes, side by side in a parallel build.
+// The four instantiations (softmax offset form x bf16 / e4m3 Q, K) are separate translation units — attention64b_doff.hip,
+// attention64b_qk8.hip, attention64b_qk8_doff.hip include this file with ATTN64B_DOFF / ATTN64B_QK8 set: each takes hipcc ~2.5 minutes,
+// side by side in a parallel build.
 #ifndef ATTN64B_DOFF
 #define ATTN64B_DOFF 0
 #endif
-int launch_attention64b_doff(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
-                             int ldo, int Sq, int S, int heads);
-#if ATTN64B_DOFF
-int launch_attention64b_doff(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
-                             int ldo, int Sq, int S, int heads) {
-#else
-int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
-                        int ldo, int Sq, int S, int heads, bool data_offset) {
-    if (data_offset) return launch_attention64b_doff(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads);
+#ifndef ATTN64B_QK8
+#define ATTN64B_QK8 0
 #endif
+#define A64B_CAT2(a, b, c) a##b##c
+#define A64B_CAT(a, b, c) A64B_CAT2(a, b, c)
+#define A64B_VARIANT A64B_CAT(launch_attention64b_v, ATTN64B_DOFF, ATTN64B_QK8)
+// q, k: bf16 rows of ldqk elements, or (QK8) e4m3 rows of ldqk bytes with qk8_exps = qe | ke << 8 (q8 = q 2^qe, k8 = k 2^ke)
+int launch_attention64b_v00(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int);
+int launch_attention64b_v10(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int);
+int launch_attention64b_v01(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int);
+int launch_attention64b_v11(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int);
+
+int A64B_VARIANT(hipStream_t stream, const void* q, const void* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out, int ldo, int Sq, int S,
+                 int heads, int qk8_exps) {
     if (S < 1 || Sq <= 0 || s_pad < ((S + BKV - 1) / BKV) * BKV) return 1;
-    if ((unsigned long long)S * (unsigned long long)ldqk * 2 >= (1ull << 31) || (unsigned long long)HD * (unsigned long long)s_pad * 2 >= (1ull << 31)) return 1;
+    const unsigned long long esz = ATTN64B_QK8 ? 1 : 2;
+    if ((unsigned long long)S * (unsigned long long)ldqk * esz >= (1ull << 31) || (unsigned long long)HD * (unsigned long long)s_pad * 2 >= (1ull << 31)) return 1;
+    if (ATTN64B_QK8 && ((ldqk & 15) || (reinterpret_cast<uintptr_t>(q) & 15) || (reinterpret_cast<uintptr_t>(k) & 15))) return 1;
     const dim3 grid((Sq + 255) / 256, heads), block(256);
     unsigned long long* trace = nullptr;
     static const char* trace_env = F2_DEV_ENV("FLUX2MI_ATTN_TRACE");
     static int seen = 0;
     const size_t tn = (size_t)grid.x * grid.y * 4 * 2;
     if (trace_env && ++seen % 8 == 0 && hipMalloc((void**)&trace, tn * 8) != hipSuccess) trace = nullptr;
-    hipLaunchKernelGGL(attn64b_kernel<(ATTN64B_DOFF != 0)>, grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, trace);
+    hipLaunchKernelGGL((attn64b_kernel<(ATTN64B_DOFF != 0), (ATTN64B_QK8 != 0)>), grid, block, 0, stream, reinterpret_cast<const uint16_t*>(q),
+                       reinterpret_cast<const uint16_t*>(k), ldqk, vt, s_pad, out, ldo, Sq, S, trace, qk8_exps);
     if (trace) {
         std::vector<unsigned long long> h(tn);
         (void)hipStreamSynchronize(stream);
@@ -487,8 +571,23 @@ int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k
         double cyc = 0, rt = 0;
         for (size_t w = 0; w < tn / 2; ++w) { cyc += (double)h[2 * w]; rt += (double)h[2 * w + 1]; }
         const double tiles = (double)(tn / 2) * ((S + BKV - 1) / BKV + 1);
-        fprintf(stderr, "[attn64b trace%s] S %d heads %d: %.0f shader cycles per KV tile (136 MFMAs = 2176), in-loop clock %.0f MHz, %.3f us per tile\n",
-                ATTN64B_DOFF ? ", data offset" : "", S, heads, cyc / tiles, cyc / rt * 100.0, rt / tiles * 0.01);
+        fprintf(stderr, "[attn64b trace%s%s] S %d heads %d: %.0f shader cycles per KV tile (136 MFMAs = 2176; e4m3 QK^T: 88 MFMAs = 1664), in-loop clock %.0f MHz, %.3f us per tile\n",
+                ATTN64B_DOFF ? ", data offset" : "", ATTN64B_QK8 ? ", e4m3 Q K" : "", S, heads, cyc / tiles, cyc / rt * 100.0, rt / tiles * 0.01);
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
+
+#if !ATTN64B_DOFF && !ATTN64B_QK8
+int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
+                        int ldo, int Sq, int S, int heads, bool data_offset) {
+    return data_offset ? launch_attention64b_v10(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads, 0)
+                       : launch_attention64b_v00(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads, 0);
+}
+int launch_attention64b_qk8(hipStream_t stream, const uint8_t* q8, const uint8_t* k8, int ld8, int q_exp, int k_exp, const uint16_t* vt, int s_pad,
+                            uint16_t* out, int ldo, int Sq, int S, int heads, bool data_offset) {
+    if (q_exp < 0 || q_exp > 60 || k_exp < 0 || k_exp > 60) return 1;
+    const int exps = q_exp | (k_exp << 8);
+    return data_offset ? launch_attention64b_v11(stream, q8, k8, ld8, vt, s_pad, out, ldo, Sq, S, heads, exps)
+                       : launch_attention64b_v01(stream, q8, k8, ld8, vt, s_pad, out, ldo, Sq, S, heads, exps);
+}
+#endif

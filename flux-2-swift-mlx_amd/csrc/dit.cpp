@@ -82,15 +82,17 @@ struct flux2mi_dit {
     uint16_t *mod_img = nullptr, *mod_txt = nullptr, *mod_single = nullptr, *final_mod = nullptr, *final_lin = nullptr;
     struct W { const uint16_t* w = nullptr; const float* scale = nullptr; };  // bf16 pointer, or e4m3 bytes + scales
     // score_bound: upper bound of |q.k| / sqrt(128) * log2(e) after the block's QK-RMSNorm (see finalize)
-    struct Dbl { W qkv[2], proj[2], mlp_in[2], mlp_out[2]; uint16_t *qn[2], *kn[2]; float score_bound = 0.f; };  // [0]=txt, [1]=img
-    struct Sgl { W lin1, lin2; uint16_t *qn, *kn; float score_bound = 0.f; };
+    // q8_exp / k8_exp (fp8 models): e4m3 Q / K of the attention are q 2^q8_exp / k 2^k8_exp, the largest powers of two that keep the
+    // RMSNorm-bounded elements (|x_d| <= sqrt(128) max|w|) inside e4m3's 448 (finalize)
+    struct Dbl { W qkv[2], proj[2], mlp_in[2], mlp_out[2]; uint16_t *qn[2], *kn[2]; float score_bound = 0.f; int q8_exp = 0, k8_exp = 0; };  // [0]=txt, [1]=img
+    struct Sgl { W lin1, lin2; uint16_t *qn, *kn; float score_bound = 0.f; int q8_exp = 0, k8_exp = 0; };
     std::vector<Dbl> dbl;
     std::vector<Sgl> sgl;
 
     // staging for ingestion
     DevBuf stage_raw, stage_bf16, stage_w, stage_d, stage_q8;
     // forward workspace
-    DevBuf hs, xn, qkv, vt, comb, mods, rope, lat_bf16, xq, xs;
+    DevBuf hs, xn, qkv, vt, comb, mods, rope, lat_bf16, xq, xs, qk8;
     DevBuf splitk_ws;   // proj_out ([s_out, d] x [128, d]^T: 32 tiles of 128x128 at 1024^2, 48 K-tiles): split-K workspace (kernels.h)
     int ws_S = 0;
 };
@@ -517,15 +519,22 @@ extern "C" int flux2mi_dit_finalize(flux2mi_dit* m) {
             return FLUX2MI_OK;
         };
         const float c = 128.0f / sqrtf(128.0f) * 1.4426950408889634f * 1.03f;
+        // e4m3 exponents: |q_d| <= sqrt(128) max|w_q| q_mul (q carries the score scale log2(e) / sqrt(128)), |k_d| <= sqrt(128) max|w_k|
+        auto e8 = [](float bound) { return bound > 0.f ? std::max(0, std::min(30, (int)floorf(log2f(448.0f / bound)))) : 0; };
+        const float qm = 1.4426950408889634f / sqrtf(128.0f), r128 = sqrtf(128.0f);
         for (auto& b : m->dbl) {
             float q0, q1, k0, k1;
             F2_TRY(wmax(b.qn[0], q0)); F2_TRY(wmax(b.qn[1], q1)); F2_TRY(wmax(b.kn[0], k0)); F2_TRY(wmax(b.kn[1], k1));
             b.score_bound = c * fmaxf(q0, q1) * fmaxf(k0, k1);
+            b.q8_exp = e8(r128 * fmaxf(q0, q1) * qm);
+            b.k8_exp = e8(r128 * fmaxf(k0, k1));
         }
         for (auto& b : m->sgl) {
             float q, k;
             F2_TRY(wmax(b.qn, q)); F2_TRY(wmax(b.kn, k));
             b.score_bound = c * q * k;
+            b.q8_exp = e8(r128 * q * qm);
+            b.k8_exp = e8(r128 * k);
         }
     }
     m->stage_raw.release();
@@ -711,6 +720,7 @@ int ensure_workspace(flux2mi_dit* m, int S, int s_img) {
     if (m->cfg.weight_format == 1) {
         F2_TRY(m->xq.reserve(Sz * 4 * d));
         F2_TRY(m->xs.reserve(Sz * 4));
+        F2_TRY(m->qk8.reserve(Sz * 2 * d));   // e4m3 [S][q | k] of the current block (attention64b.hip, QK8)
     }
     m->ws_S = S;
     return FLUX2MI_OK;
@@ -902,8 +912,24 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         return e ? atoi(e) != 0 : true;
     }();
     const float q_mul = q_pre ? 1.4426950408889634f / sqrtf(128.0f) : 1.0f;
-    auto attend = [&](int layer, uint16_t* o_buf, int ldo, float score_bound) -> int {
+    // fp8 models, plain forwards: Q K^T on e4m3 copies of q and k (written by the norm + RoPE kernel in front of this call; the KV-cache
+    // passes restore bf16 reference keys and keep the bf16 form).  FLUX2MI_ATTN_QK8=0 (dev library): bf16 Q K^T for A/B runs
+    static const bool qk8_on = [] {
+        const char* e = F2_DEV_ENV("FLUX2MI_ATTN_QK8");
+        return e ? atoi(e) != 0 : true;
+    }();
+    const bool qk8 = f8 && qk8_on && q_pre && mode == FWD_PLAIN;
+    uint8_t* qk8_buf = qk8 ? m->qk8.as<uint8_t>() : nullptr;
+    auto attend = [&](int layer, uint16_t* o_buf, int ldo, float score_bound, int q8_exp, int k8_exp) -> int {
         if (m->attn_softmax_mode == 1) score_bound = 0.f;   // no bound given: launch_attention takes the data-offset form
+        if (qk8) {
+            prof_before(m->ctx, PROF_ATTENTION);
+            const int ar = launch_attention64b_qk8(st, qk8_buf, qk8_buf + d, 2 * d, q8_exp, k8_exp, vt, s_pad, o_buf, ldo, S, S, H,
+                                                   !attention_uses_fixed_offset(score_bound, true));
+            prof_after(m->ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
+            F2_LAUNCH(ar, "attention(e4m3 QK)");
+            return FLUX2MI_OK;
+        }
         if (mode == FWD_KV_EXTRACT) {
             F2_CHECK_HIP(hipMemcpy2DAsync(cache->k(layer), (size_t)d * 2, qkv + (size_t)s_txt * 3 * d + d, (size_t)3 * d * 2,
                                           (size_t)d * 2, (size_t)s_ref, hipMemcpyDeviceToDevice, st));
@@ -966,6 +992,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
                     p[r].qk_qw = w.qn[r]; p[r].qk_kw = w.kn[r]; p[r].qk_pos = pos_tab;
                     p[r].qk_cols = 2 * d; p[r].qk_row0 = r ? img0 : 0; p[r].qk_qmul = q_mul;
                     p[r].qk_l2t16 = log2f(2000.0f) / 16.0f;
+                    if (qk8) { p[r].qk8 = qk8_buf; p[r].qk8_ld = 2 * d; p[r].qk8_qmul = ldexpf(1.0f, w.q8_exp); p[r].qk8_kmul = ldexpf(1.0f, w.k8_exp); }
                 }
             }
             F2_TRY(run_gemm(m, p, 2, 0, "dbl.qkv"));
@@ -979,8 +1006,8 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
             F2_LAUNCH(launch_v_transpose_only(st, qkv, 3 * d, S, H, vt, s_pad), "v_transpose");
         } else
         F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, s_txt, w.qn[0], w.kn[0], w.qn[1], w.kn[1], cos_tab, sin_tab,
-                                         vt, s_pad, q_mul), "qk_norm_rope");
-        F2_TRY(attend(i, comb, d, w.score_bound));
+                                         vt, s_pad, q_mul, qk8_buf, w.q8_exp, w.k8_exp), "qk_norm_rope");
+        F2_TRY(attend(i, comb, d, w.score_bound, w.q8_exp, w.k8_exp));
         F2_LAUNCH(quant(comb, d, d), "quantize(attn out)");
         {
             GemmProblem p[2];
@@ -1027,6 +1054,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
             p[0].qk_qw = w.qn; p[0].qk_kw = w.kn; p[0].qk_pos = pos_tab;
             p[0].qk_cols = 2 * d; p[0].qk_row0 = 0; p[0].qk_qmul = q_mul;
             p[0].qk_l2t16 = log2f(2000.0f) / 16.0f;
+            if (qk8) { p[0].qk8 = qk8_buf; p[0].qk8_ld = 2 * d; p[0].qk8_qmul = ldexpf(1.0f, w.q8_exp); p[0].qk8_kmul = ldexpf(1.0f, w.k8_exp); }
             p[1] = blk(xn, d, 0, wrows(w.lin1, 3 * d, d), nullptr, 0, S, 6 * d, d, EPI_SWIGLU);
             p[1].C2 = comb + d;
             p[1].ldc2 = 4 * d;
@@ -1045,6 +1073,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
                     p[r].qk_qw = w.qn; p[r].qk_kw = w.kn; p[r].qk_pos = pos_tab;
                     p[r].qk_cols = 2 * d; p[r].qk_row0 = rng0[r]; p[r].qk_qmul = q_mul;
                     p[r].qk_l2t16 = log2f(2000.0f) / 16.0f;   // theta 2000, 16 frequencies per axis (Flux2RoPE.swift:129-169)
+                    if (qk8) { p[r].qk8 = qk8_buf; p[r].qk8_ld = 2 * d; p[r].qk8_qmul = ldexpf(1.0f, w.q8_exp); p[r].qk8_kmul = ldexpf(1.0f, w.k8_exp); }
                 }
             }
             F2_TRY(run_gemm(m, p, n_rng, PROF_LINEAR1, "single.linear1"));
@@ -1053,9 +1082,9 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         } else if (qk_fuse) {
             F2_LAUNCH(launch_v_transpose_only(st, qkv, 3 * d, S, H, vt, s_pad), "v_transpose");
         } else
-        F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, 0, w.qn, w.kn, w.qn, w.kn, cos_tab, sin_tab, vt, s_pad, q_mul),
-                  "qk_norm_rope");
-        F2_TRY(attend(m->cfg.n_double + i, comb, 4 * d, w.score_bound));
+        F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, 0, w.qn, w.kn, w.qn, w.kn, cos_tab, sin_tab, vt, s_pad, q_mul, qk8_buf, w.q8_exp,
+                                         w.k8_exp), "qk_norm_rope");
+        F2_TRY(attend(m->cfg.n_double + i, comb, 4 * d, w.score_bound, w.q8_exp, w.k8_exp));
         F2_LAUNCH(quant(comb, 4 * d, 4 * d), "quantize(attn | ff hidden)");
         {
             GemmProblem p[2];
@@ -1298,6 +1327,23 @@ extern "C" int flux2mi_op_attention_prescaled(flux2mi_ctx* ctx, const void* qkv_
                                    nullptr, 0);
     prof_after(ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
     F2_LAUNCH(r, "op_attention_prescaled");
+    return FLUX2MI_OK;
+}
+
+// The fp8 models' form: Q K^T on e4m3 q8 = q 2^q_exp, k8 = k 2^k_exp (device bytes [S, heads*128] each; q pre-scaled like above), V bf16
+// [S, heads*128]; P, O as in the bf16 form (attention64b.hip, QK8).  score_bound_log2 as flux2mi_op_attention_prescaled.
+extern "C" int flux2mi_op_attention_qk8(flux2mi_ctx* ctx, const void* q8, const void* k8, const void* v, void* out, int S, int heads, int q_exp, int k_exp,
+                                        float score_bound_log2) {
+    F2_REQUIRE(ctx && q8 && k8 && v && out && S > 0 && heads > 0, FLUX2MI_ERR_INVALID_ARG, "op_attention_qk8: bad argument");
+    const int d = heads * 128, s_pad = attn_s_pad(S);
+    F2_TRY(ctx->scratch.reserve((size_t)heads * 128 * s_pad * 2 + 256 * 4));
+    uint16_t* vt = ctx->scratch.as<uint16_t>();
+    F2_CHECK_HIP(hipMemsetAsync(vt, 0, (size_t)heads * 128 * s_pad * 2, ctx->stream));
+    // v_transpose reads V at column v_col0 = 2 * heads * 128 of a [S, ldqkv] matrix: hand it the V matrix shifted back by that
+    F2_LAUNCH(launch_v_transpose_only(ctx->stream, reinterpret_cast<const uint16_t*>(v) - 2 * d, d, S, heads, vt, s_pad), "v_transpose");
+    const int r = launch_attention64b_qk8(ctx->stream, reinterpret_cast<const uint8_t*>(q8), reinterpret_cast<const uint8_t*>(k8), d, q_exp, k_exp, vt, s_pad,
+                                          reinterpret_cast<uint16_t*>(out), d, S, S, heads, !attention_uses_fixed_offset(score_bound_log2, true));
+    F2_LAUNCH(r, "op_attention_qk8");
     return FLUX2MI_OK;
 }
 

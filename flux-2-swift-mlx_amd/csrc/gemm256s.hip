@@ -191,7 +191,11 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
 
     const int bid = blockIdx.x;
     const int pi = (batch.nprob > 1 && bid >= batch.tile_start1) ? 1 : 0;
-    const GemmProblem& p = batch.p[pi];
+    // the descriptor of this tile's problem, read where it lies in the kernel-argument segment (scalar loads): indexing the by-value
+    // copy with `pi` makes hipcc move the whole batch to scratch once the struct is large enough
+    using KProblem = const __attribute__((address_space(4))) GemmProblem;
+    KProblem& p = ((KProblem*)__builtin_amdgcn_kernarg_segment_ptr())[pi];
+    static_assert(offsetof(GemmBatch, p) == 0, "the problems are the first member of the only kernel argument");
     const int local = bid - (pi ? batch.tile_start1 : 0);
     const int tiles_m = (p.M + BMT - 1) / BMT, tiles_n = (p.N + TN - 1) / TN;
     int tm, tn;
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     f32x4 fs_col[8];
     if constexpr (FP8) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) fs_row[i] = p.a_scale[min(row_base + i * 16, p.M - 1)];
+        for (int i = 0; i < NI; ++i) fs_row[i] = p.a_scale[(unsigned)min(row_base + i * 16, p.M - 1)];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -650,34 +654,41 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     if (p.qk_qw != nullptr && epi == EPI_BF16 && n0 < p.qk_cols) {
         // ---- fused QK RMSNorm + RoPE (Flux2Attention.swift:137-157).  A 256-column tile is two heads and a wave holds all
         // 128 columns of one: the sum of squares is the lane's 32 values + the 4 fq lanes of a row (two lane exchanges).
+        int fqo = fq;
+        asm volatile("" : "+v"(fqo));   // values derived from it belong to this path, not to the registers live across the K loop
         const bool is_k = n0 >= (p.qk_cols >> 1);
-        const uint16_t* wv = (is_k ? p.qk_kw : p.qk_qw) + fq * 4;
+        const uint16_t* wv = (is_k ? p.qk_kw : p.qk_qw) + fqo * 4;
         const float qm = is_k ? 1.0f : p.qk_qmul;
-        // the lane's columns inside the head: j*16 + fq*4 + r = axis j >> 1, pair (j & 1)*8 + fq*2 + (r >> 1) of that axis:
+        // the lane's columns inside the head: j*16 + fqo*4 + r = axis j >> 1, pair (j & 1)*8 + fqo*2 + (r >> 1) of that axis:
         // four frequencies per lane, in revolutions (v_sin_f32 / v_cos_f32 take x / 2pi)
         float wrev[2][2];
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr)
-                wrev[jb][pr] = __builtin_amdgcn_exp2f(-(float)(jb * 8 + fq * 2 + pr) * p.qk_l2t16) * 0.15915494309189535f;
-        uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
-        const int wcol = n0 + wn * 128 + (fq & 1) * 16 + (fq >> 1) * 8;
+                wrev[jb][pr] = __builtin_amdgcn_exp2f(-(float)(jb * 8 + fqo * 2 + pr) * p.qk_l2t16) * 0.15915494309189535f;
+        const int wcol = n0 + wn * 128 + (fqo & 1) * 16 + (fqo >> 1) * 8;
+        int rbase = row_base;
+        asm volatile("" : "+v"(rbase));   // the rows of this path are its own values: shared with the scale loads above, hipcc keeps them all live (spills)
+        // one address form for both outputs (bf16 columns of C, or the e4m3 q | k rows of the attention): base + row * stride + jp * step
+        const bool e4 = p.qk8 != nullptr;
+        uint8_t* const obase = e4 ? p.qk8 + (size_t)p.qk_row0 * p.qk8_ld + wcol : reinterpret_cast<uint8_t*>(p.C) + (size_t)wcol * 2;
+        const unsigned ostride = e4 ? (unsigned)p.qk8_ld : (unsigned)p.ldc * 2u, ostep = e4 ? 32u : 64u;
+        const float m8 = is_k ? p.qk8_kmul : p.qk8_qmul;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int row = row_base + i * 16;
-            const float4 ps = *reinterpret_cast<const float4*>(p.qk_pos + (size_t)(p.qk_row0 + min(row, p.M - 1)) * 4);
-            float t2 = 0.f;
+            const int row = rbase + i * 16;
+            uint8_t* const orow = obase + (size_t)((unsigned)row * ostride);
+            const float4 ps = *reinterpret_cast<const float4*>(p.qk_pos + (size_t)(unsigned)(p.qk_row0 + min(row, p.M - 1)) * 4);
+            float ssq = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t2 += accv(i, j)[r] * accv(i, j)[r];
-            t2 += __shfl_xor(t2, 16);
-            t2 += __shfl_xor(t2, 32);
-            const float rinv = rsqrtf(t2 * (1.0f / 128.0f) + 1e-6f);
-            uint32_t pk[8][2];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
+                for (int r = 0; r < 4; ++r) ssq += accv(i, j)[r] * accv(i, j)[r];
+            ssq += __shfl_xor(ssq, 16);
+            ssq += __shfl_xor(ssq, 32);
+            const float rinv = rsqrtf(ssq * (1.0f / 128.0f) + 1e-6f);
+            auto rotated = [&](int j, float& r0, float& r1, float& r2, float& r3) GS_INLINE {
                 const uint2 uw = *reinterpret_cast<const uint2*>(wv + j * 16);
                 const float w0 = lo_bf16(uw.x) * qm, w1 = hi_bf16(uw.x) * qm, w2 = lo_bf16(uw.y) * qm, w3 = hi_bf16(uw.y) * qm;
                 const float pos = (j >> 1) == 0 ? ps.x : (j >> 1) == 1 ? ps.y : (j >> 1) == 2 ? ps.z : ps.w;
@@ -686,16 +697,23 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                 const float c1 = __builtin_amdgcn_cosf(f1), s1 = __builtin_amdgcn_sinf(f1);
                 const float a0 = accv(i, j)[0] * rinv * w0, a1 = accv(i, j)[1] * rinv * w1;
                 const float a2 = accv(i, j)[2] * rinv * w2, a3 = accv(i, j)[3] * rinv * w3;
-                pk[j][0] = pack_bf16x2(a0 * c0 - a1 * s0, a1 * c0 + a0 * s0);
-                pk[j][1] = pack_bf16x2(a2 * c1 - a3 * s1, a3 * c1 + a2 * s1);
-            }
+                r0 = a0 * c0 - a1 * s0, r1 = a1 * c0 + a0 * s0, r2 = a2 * c1 - a3 * s1, r3 = a3 * c1 + a2 * s1;
+            };
 #pragma unroll
             for (int jp = 0; jp < 4; ++jp) {
-                s_swap16(pk[2 * jp][0], pk[2 * jp + 1][0]);
-                s_swap16(pk[2 * jp][1], pk[2 * jp + 1][1]);
-                if (row < p.M)
-                    *reinterpret_cast<uint4*>(C + (size_t)row * p.ldc + wcol + jp * 32) =
-                        make_uint4(pk[2 * jp][0], pk[2 * jp][1], pk[2 * jp + 1][0], pk[2 * jp + 1][1]);
+                float r0, r1, r2, r3, t0, t1, t2, t3;
+                rotated(2 * jp, r0, r1, r2, r3);
+                rotated(2 * jp + 1, t0, t1, t2, t3);
+                if (e4) {   // 8-byte runs after the same lane exchange; the bf16 columns are not needed then
+                    uint32_t e0 = pack_fp8x4(r0 * m8, r1 * m8, r2 * m8, r3 * m8), e1 = pack_fp8x4(t0 * m8, t1 * m8, t2 * m8, t3 * m8);
+                    s_swap16(e0, e1);
+                    if (row < p.M) *reinterpret_cast<uint2*>(orow + jp * ostep) = make_uint2(e0, e1);
+                } else {
+                    uint32_t a0 = pack_bf16x2(r0, r1), a1 = pack_bf16x2(r2, r3), b0 = pack_bf16x2(t0, t1), b1 = pack_bf16x2(t2, t3);
+                    s_swap16(a0, b0);
+                    s_swap16(a1, b1);
+                    if (row < p.M) *reinterpret_cast<uint4*>(orow + jp * ostep) = make_uint4(a0, a1, b0, b1);
+                }
             }
         }
         return;

@@ -63,6 +63,12 @@ struct GemmProblem {
     const float* qk_pos;
     int qk_cols, qk_row0;
     float qk_qmul, qk_l2t16;
+    // fused QK norm + RoPE epilogue, fp8 models: instead of the bf16 q | k columns of C, write their e4m3 copies for the attention's
+    // block-scaled Q K^T (attention64b.hip, QK8): qk8 bytes [rows][qk8_ld], column = the GEMM column (q | k), row = qk_row0 + row; values
+    // times qk8_qmul / qk8_kmul (powers of two).  nullptr = the bf16 store.
+    uint8_t* qk8;
+    int qk8_ld;
+    float qk8_qmul, qk8_kmul;
     // gemm256s, EPI_CONV: a 3x3 (or the 2x2 of an upsample phase) convolution over a ZERO-HALOED NHWC image as a plain GEMM.
     // The image is stored [(H + 2)][Wp = W + 2][Cin] with a zero border; GEMM row r = padded pixel q = Wp + 1 + r (first interior pixel
     // on), M = H*Wp - 2, lda = Cin, A = the padded image's base (+ the phase's (py*Wp + px) pixels).  For tap (ky, kx) every row reads
@@ -117,6 +123,12 @@ int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, i
                      int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads, float score_bound_log2 = 0.f, bool q_prescaled = false,
                      float* split_ws = nullptr, int n_cu = 0);
 static inline int attn_s_pad(int S) { return ((S + 63) / 64) * 64; }
+// The blocks' attention with e4m3 Q and K (fp8 models; attention64b.hip, QK8): q8 / k8 bytes [S][ld8] (head h at column h*128),
+// q8 = q 2^q_exp with q pre-scaled as above, k8 = k 2^k_exp (written by launch_qk_norm_rope_vt); S^T = K Q^T is one block-scaled
+// v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 block, the scales undone by its e8m0 operands; P, V, O stay bf16 / f32.
+// data_offset as launch_attention's softmax forms.  1 = not this kernel's case.
+int launch_attention64b_qk8(hipStream_t stream, const uint8_t* q8, const uint8_t* k8, int ld8, int q_exp, int k_exp, const uint16_t* vt, int s_pad,
+                            uint16_t* out, int ldo, int Sq, int S, int heads, bool data_offset);
 
 // ---------------------------------------------------------------- norms / rope (norm.hip)
 // y bf16[row,:] = LN(x f32[row,:]) * (1 + scale) + shift ; rows < split use (shift0, scale0),
@@ -141,7 +153,8 @@ int launch_quantize_rows_fp8(hipStream_t stream, const uint16_t* x, int ld, uint
 int launch_qk_norm_rope_vt(hipStream_t stream, uint16_t* qkv, int ldqkv, int S, int heads, int split,
                            const uint16_t* qscale0, const uint16_t* kscale0, const uint16_t* qscale1,
                            const uint16_t* kscale1, const float* cos_tab, const float* sin_tab,
-                           uint16_t* vt, int s_pad, float q_mul = 1.0f);
+                           uint16_t* vt, int s_pad, float q_mul = 1.0f,
+                           uint8_t* qk8 = nullptr, int q8_exp = 0, int k8_exp = 0);
 // V half of the above only (standalone attention op).
 int launch_v_transpose_only(hipStream_t stream, const uint16_t* qkv, int ldqkv, int S, int heads, uint16_t* vt,
                             int s_pad);

@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(uint16_t* __restrict_
                                                            const uint16_t* __restrict__ qs1,
                                                            const uint16_t* __restrict__ ks1,
                                                            const float* __restrict__ cos_tab,
-                                                           const float* __restrict__ sin_tab, float q_mul) {
+                                                           const float* __restrict__ sin_tab, float q_mul,
+                                                           uint8_t* __restrict__ qk8, float q8_mul, float k8_mul) {
     const int sub = threadIdx.x & 15;
     const long vec = (long)blockIdx.x * 16 + (threadIdx.x >> 4);  // ((row*2 + which)*heads + head)
     const long total = (long)S * 2 * heads;
@@ -230,6 +231,13 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(uint16_t* __restrict_
         pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]);
         pk.z = pack_bf16x2(o[4], o[5]); pk.w = pack_bf16x2(o[6], o[7]);
         *reinterpret_cast<uint4*>(p) = pk;
+        if (qk8) {   // the e4m3 copy the fp8 models' attention takes for Q K^T (attention64b.hip, QK8): [S][q | k] bytes, power-of-two scales
+            const float m8 = which ? k8_mul : q8_mul;
+            uint2 e;
+            e.x = pack_fp8x4(o[0] * m8, o[1] * m8, o[2] * m8, o[3] * m8);
+            e.y = pack_fp8x4(o[4] * m8, o[5] * m8, o[6] * m8, o[7] * m8);
+            *reinterpret_cast<uint2*>(qk8 + (size_t)row * (2 * heads * 128) + which * heads * 128 + head * 128 + sub * 8) = e;
+        }
     }
 }
 
@@ -404,11 +412,11 @@ int launch_quantize_rows_fp8(hipStream_t stream, const uint16_t* x, int ld, uint
 int launch_qk_norm_rope_vt(hipStream_t stream, uint16_t* qkv, int ldqkv, int S, int heads, int split,
                            const uint16_t* qscale0, const uint16_t* kscale0, const uint16_t* qscale1,
                            const uint16_t* kscale1, const float* cos_tab, const float* sin_tab,
-                           uint16_t* vt, int s_pad, float q_mul) {
+                           uint16_t* vt, int s_pad, float q_mul, uint8_t* qk8, int q8_exp, int k8_exp) {
     if (S <= 0 || heads <= 0 || (ldqkv & 7) || s_pad < attn_s_pad(S)) return 1;
     const long total = (long)S * 2 * heads;
     hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, qkv, ldqkv, S,
-                       heads, split, qscale0, kscale0, qscale1, kscale1, cos_tab, sin_tab, q_mul);
+                       heads, split, qscale0, kscale0, qscale1, kscale1, cos_tab, sin_tab, q_mul, qk8, ldexpf(1.0f, q8_exp), ldexpf(1.0f, k8_exp));
     hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, heads), dim3(256), 0, stream, qkv, ldqkv, S,
                        2 * heads * 128, vt, s_pad);
     return hipGetLastError() == hipSuccess ? 0 : 2;

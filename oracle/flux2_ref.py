@@ -322,6 +322,25 @@ def fake_quant_e4m3_rows(x: Tensor) -> Tensor:
     return q * scale
 
 
+def fp8_qk(q: Tensor, k: Tensor, wq_max: float, wk_max: float) -> Tuple[Tensor, Tensor]:
+    """fp8 mode, plain forwards only (the MI355X path's e4m3 Q K^T, attention64b.hip QK8 / dit.cpp finalize — NOT a restatement of the
+    reference): q carries the score scale log2(e)/sqrt(128); q 2^qe and k 2^ke are rounded to e4m3 with the largest powers of two that
+    keep the RMSNorm-bounded elements (|x_d| <= sqrt(128) max|w|) inside 448; returns the de-quantised q (score scale removed again), k."""
+    if not _FP8_BLOCK_GEMMS:
+        return q, k
+    c = math.log2(math.e) / math.sqrt(128.0)
+    r128 = math.sqrt(128.0)
+
+    def e8(bound):
+        return max(0, min(30, int(math.floor(math.log2(448.0 / bound))))) if bound > 0 else 0
+    qe, ke = e8(r128 * wq_max * c), e8(r128 * wk_max)
+
+    def rq(x, e):
+        m = float(2.0 ** e)
+        return (x.float() * m).clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).float() / m
+    return rq(q * c, qe) / c, rq(k, ke)
+
+
 def block_linear(x: Tensor, w: Tensor) -> Tensor:
     """A block GEMM.  In fp8 mode the activation is first rounded to bf16 (what the producing
     kernel stores) and both operands are fake-quantised row-wise."""
@@ -424,6 +443,8 @@ def double_block(P: Dict[str, Tensor], i: int, img: Tensor, txt: Tensor, H: int,
     q = torch.cat([q_t, q_i], dim=2)               # [txt ; img]  (Flux2Attention.swift:161-163)
     k = torch.cat([k_t, k_i], dim=2)
     v = torch.cat([v_t, v_i], dim=2)
+    wmax = lambda s_: max(float(P[pre + "img_attn.norm." + s_].float().abs().max()), float(P[pre + "txt_attn.norm." + s_].float().abs().max()))
+    q, k = fp8_qk(q, k, wmax("query_norm.scale"), wmax("key_norm.scale"))
     o = _unheads(sdpa(q, k, v))
     txt_attn = block_linear(o[:, :S_txt], P[pre + "txt_attn.proj.weight"])
     img_attn = block_linear(o[:, S_txt:], P[pre + "img_attn.proj.weight"])
@@ -449,6 +470,7 @@ def single_block(P: Dict[str, Tensor], i: int, hs: Tensor, H: int, cos: Tensor, 
     q, k, v = _heads(q, H), _heads(k, H), _heads(v, H)
     q = apply_rope(rms_norm(q, P[pre + "norm.query_norm.scale"]), cos, sin)
     k = apply_rope(rms_norm(k, P[pre + "norm.key_norm.scale"]), cos, sin)
+    q, k = fp8_qk(q, k, float(P[pre + "norm.query_norm.scale"].float().abs().max()), float(P[pre + "norm.key_norm.scale"].float().abs().max()))
     attn = _unheads(sdpa(q, k, v))
     out = block_linear(torch.cat([attn, F.silu(gate) * up], dim=-1), P[pre + "linear2.weight"])
     return hs + out * mod[0][2].unsqueeze(1)

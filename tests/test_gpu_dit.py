@@ -225,6 +225,7 @@ def test_production_width_fused_paths_bf16_and_fp8(flux2mi, ctx):
     # noise, see test_tiny_forward_fp8) — the same value with the fused epilogue / V^T GEMM switched off
     q = rel_l2(ref8, ref32)
     e8 = rel_l2(outs["fp8"], ref8)
+    print(f"production width fp8: q {q:.3e}, HIP vs emulation {e8:.3e}, HIP vs f32 oracle {rel_l2(outs['fp8'], ref32):.3e}")
     assert e8 < 3e-2 and e8 < q
     assert 0.5 * q < rel_l2(outs["fp8"], ref32) < 1.5 * q
 

@@ -634,3 +634,34 @@ def test_gemm_random_shapes_exact(ctx):
         out16 = ctx.op_gemm_bf16_out_bf16(a, w)
         ctx.sync()
         assert torch.equal(out16, ref.to(torch.bfloat16)), (M, N, K)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("doff", [False, True])
+@pytest.mark.parametrize("S,heads", [(64, 1), (200, 2), (448, 3), (1153, 2), (4608, 2)])
+def test_attention_e4m3_qk(ctx, S, heads, doff):
+    """The fp8 models' attention (attention64b.hip, QK8; flux2mi_op_attention_qk8): Q K^T on e4m3 copies q8 = q 2^7, k8 = k 2^4 through ONE
+    block-scaled MFMA 16x16x128 per 16 x 16 score block, the powers of two undone by its scale operands; softmax, P and P V as in the bf16
+    form.  Against the oracle's softmax on the DE-QUANTISED q8 / k8 (the kernel sees exactly those values: rel-L2 <= 1e-2 like the bf16
+    kernel), 1 .. 72 KV tiles, ragged key counts (clamped e4m3 K rows + cleared P slots), both softmax-offset forms, bit-reproducible."""
+    import math
+    g = torch.Generator().manual_seed(S * 11 + heads)
+    d = heads * 128
+    x = torch.randn((S, 3 * d), generator=g)
+    q = x[:, :d].view(S, heads, 128)
+    k = x[:, d:2 * d].view(S, heads, 128)
+    q = q / q.pow(2).mean(-1, keepdim=True).sqrt() * (3.0 if doff else 1.0)
+    k = k / k.pow(2).mean(-1, keepdim=True).sqrt()
+    k[S // 2] *= 1.5
+    c = math.log2(math.e) / math.sqrt(128.0)
+    qe, ke = (5 if doff else 7), 4
+    q8 = ((q * c).reshape(S, d) * 2.0 ** qe).clamp(-448, 448).to(torch.float8_e4m3fn)
+    k8 = (k.reshape(S, d) * 2.0 ** ke).clamp(-448, 448).to(torch.float8_e4m3fn)
+    v = x[:, 2 * d:].to(torch.bfloat16)
+    bound = 0.0 if doff else 1.5 * 128.0 * c
+    out = ctx.op_attention_qk8(q8.cuda(), k8.cuda(), v.cuda(), heads, qe, ke, bound).float().cpu()
+    hv = lambda t: t.reshape(1, S, heads, 128).permute(0, 2, 1, 3)
+    ref = R.sdpa(hv(q8.float() / 2.0 ** qe / c), hv(k8.float() / 2.0 ** ke), hv(v.float())).permute(0, 2, 1, 3).reshape(S, d)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 1e-2, rel_l2(out, ref)
+    assert torch.equal(out, ctx.op_attention_qk8(q8.cuda(), k8.cuda(), v.cuda(), heads, qe, ke, bound).float().cpu())

@@ -10,7 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "flux-2-swift-mlx_amd", "csrc", "build")
-NAMES = ["gemm256s", "attention64b", "attention64b_doff"]
+NAMES = ["gemm256s", "attention64b", "attention64b_doff", "attention64b_qk8", "attention64b_qk8_doff"]
 
 
 def test_isa_invariants_of_the_linked_objects(flux2mi):

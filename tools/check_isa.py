@@ -125,17 +125,18 @@ def main():
                 found = True
         if not found:
             errors.append((kname, "steady-state loop not found"))
-    # ---- attention: the three-tile loop of both instantiations (DOFF = false: fixed zero offset, true: per-query data offset)
-    texts = compile_many(["attention64b", "attention64b_doff"])
-    for n, t in zip(["attention64b", "attention64b_doff"], texts):
+    # ---- attention: the three-tile loop of the four instantiations (softmax offset: fixed zero / per-query data offset; Q, K: bf16 / e4m3)
+    names = ["attention64b", "attention64b_doff", "attention64b_qk8", "attention64b_qk8_doff"]
+    texts = compile_many(names)
+    for n, t in zip(names, texts):
         check_m0(n, t, errors)
     for text, (kname, body) in [(t, kb) for t in texts for kb in kernels(t)]:
-        m = re.search(r"attn64b_kernelILb(\d)E", kname)
+        m = re.search(r"attn64b_kernelILb(\d)E(?:Lb(\d)E)?", kname)
         if not m:
             continue
-        doff = int(m.group(1))
+        doff, qk8 = int(m.group(1)), int(m.group(2) or 0)
         scratch = meta(text, kname, "private_segment_fixed_size")
-        print(f"attn64b_kernel<{'data offset' if doff else 'fixed offset'}>: scratch {scratch} B, spills {meta(text, kname, 'vgpr_spill_count')}")
+        print(f"attn64b_kernel<{'data offset' if doff else 'fixed offset'}{', e4m3 Q K' if qk8 else ''}>: scratch {scratch} B, spills {meta(text, kname, 'vgpr_spill_count')}")
         # the data-offset form keeps 16 more VGPRs (the offsets): a few set-up values of the prologue / epilogue go to scratch,
         # never inside a block that issues MFMAs
         if scratch > (64 if doff else 0):
@@ -143,14 +144,16 @@ def main():
         for label, ins in blocks(body):
             if any(i.startswith("v_mfma") for i in ins) and any(i.startswith("scratch_") for i in ins):
                 errors.append((kname, label, "scratch access in a block that issues MFMAs"))
+        # per tile: bf16 64 QK^T + 72 PV / row-sum MFMAs, 32 fragment reads, 8 DMA pieces; e4m3 Q K: 16 block-scaled QK^T MFMAs, 24 reads, 6 pieces
+        n_mfma, n_dsr, n_dma = (3 * 88, 3 * 24, 3 * 6) if qk8 else (3 * 136, 3 * 32, 3 * 8)
         found = False
         for label, ins in blocks(body):
             c = collections.Counter(i.split()[0] for i in ins)
-            if sum(v for k, v in c.items() if k.startswith("v_mfma")) == 3 * 136:
-                check_loop(kname, label, ins, 3 * 136, 3 * 32, 3 * 8, "buffer_load_dwordx4", errors)
+            if sum(v for k, v in c.items() if k.startswith("v_mfma")) == n_mfma:
+                check_loop(kname, label, ins, n_mfma, n_dsr, n_dma, "buffer_load_dwordx4", errors)
                 cc = collections.Counter(i.split()[0] for i in ins)
-                if cc.get("v_exp_f32", 0) != 3 * 64 or cc.get("v_cvt_pk_bf16_f32", 0) != 3 * 32:
-                    errors.append((kname, "softmax instruction counts", cc.get("v_exp_f32"), cc.get("v_cvt_pk_bf16_f32")))
+                if cc.get("v_exp_f32", 0) != 3 * 64 or cc.get("v_cvt_pk_bf16_f32", 0) != 3 * 32 or (qk8 and cc.get("v_mfma_scale_f32_16x16x128_f8f6f4", 0) != 3 * 16):
+                    errors.append((kname, "softmax / MFMA instruction counts", cc.get("v_exp_f32"), cc.get("v_cvt_pk_bf16_f32")))
                 found = True
         if not found:
             errors.append((kname, "three-tile loop not found"))
