@@ -24,6 +24,7 @@ argv = [a for a in sys.argv[1:]]
 oracle_only = argv[argv.index("--oracle-only") + 1] if "--oracle-only" in argv else None
 against = argv[argv.index("--against") + 1] if "--against" in argv else None
 threads = int(argv[argv.index("--threads") + 1]) if "--threads" in argv else None
+fp8 = "--fp8" in argv   # weight_format 1 against the oracle running the same e4m3 emulation (block GEMMs + Q K^T), one process only
 pos = [a for i, a in enumerate(argv) if not a.startswith("--") and (i == 0 or argv[i - 1] not in ("--oracle-only", "--against", "--threads"))]
 steps = int(pos[0]) if len(pos) > 0 else 28
 H = W = int(pos[1]) if len(pos) > 1 else 256
@@ -60,7 +61,7 @@ if oracle_only:
 import flux2mi  # noqa: E402,F401
 from flux2mi.pipeline import Flux2Pipeline  # noqa: E402
 
-pipe = Flux2Pipeline(model="klein-4b", vae_variant="standard").load_models(P, VP)
+pipe = Flux2Pipeline(model="klein-4b", vae_variant="standard", quantization="fp8" if fp8 else "bf16").load_models(P, VP)
 traj = []
 res = pipe.generate_text_to_image(height=H, width=W, steps=steps, precomputed_embeddings=inp["txt"], noise=inp["noise"],
                                   on_step=lambda c, x: traj.append(x.detach().clone().cpu()) or x)
@@ -70,9 +71,18 @@ if against:
     osec, othr = ref["oracle_seconds"], ref["oracle_threads"]
 else:
     from oracle import flux2_ref as R
+    import contextlib
     t0 = time.time()
-    with torch.no_grad():
-        ref = R.generate(P, cfg, VP, vcfg, inp["txt"].float(), inp["noise"], H, W, steps)
+
+    def tick(c, x):
+        print(f"oracle step at {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+        return x
+    with torch.no_grad(), (R.fp8_block_gemms() if fp8 else contextlib.nullcontext()):
+        ref = R.generate(P, cfg, VP, vcfg, inp["txt"].float(), inp["noise"], H, W, steps, on_step=tick)
+    ref32 = None
+    if fp8:   # the unquantised oracle as well: how large the quantisation effect itself is on this trajectory
+        with torch.no_grad():
+            ref32 = R.generate(P, cfg, VP, vcfg, inp["txt"].float(), inp["noise"], H, W, steps, on_step=tick)
     osec, othr = round(time.time() - t0, 1), torch.get_num_threads()
 rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
 errs = [rel(traj[k], ref["latents"][k]) for k in range(steps)]
@@ -82,4 +92,11 @@ out = {"workload": f"Klein-4B full depth, {H}x{W}, {steps} steps, standard VAE d
        "u8_abs_diff": {"mean": round(float(d.mean()), 4), "max": int(d.max()), "frac_gt_1": round(float((d > 1).float().mean()), 5),
                        "frac_gt_2": round(float((d > 2).float().mean()), 5), "frac_gt_8": round(float((d > 8).float().mean()), 6)},
        "oracle_seconds": osec, "oracle_threads": othr, "oracle_side": "separate CPU run (--oracle-only)" if against else "same process"}
+if fp8:
+    q = [rel(ref["latents"][k], ref32["latents"][k]) for k in range(steps)]
+    d32 = (torch.from_numpy(res.image).int() - ref32["image"].int()).abs().float()
+    dq = (ref["image"].int() - ref32["image"].int()).abs().float()
+    out["workload"] = out["workload"].replace("HIP path vs fp32 CPU oracle", "HIP fp8 path (e4m3 block GEMMs + e4m3 Q K^T) vs the CPU oracle running the same e4m3 emulation")
+    out["quantisation_effect_emulating_vs_f32_oracle"] = {"latent_rel_l2_final": round(q[-1], 6), "latent_rel_l2_max": round(max(q), 6), "u8_mean": round(float(dq.mean()), 4), "u8_max": int(dq.max())}
+    out["hip_fp8_vs_f32_oracle"] = {"latent_rel_l2_final": round(rel(traj[-1], ref32["latents"][-1]), 6), "u8_mean": round(float(d32.mean()), 4), "u8_max": int(d32.max())}
 print(json.dumps(out))
