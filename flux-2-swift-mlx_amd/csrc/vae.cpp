@@ -239,6 +239,7 @@ extern "C" int flux2mi_vae_destroy(flux2mi_vae* v) {
     DevBuf* bufs[] = {&v->stage_raw, &v->stage_bf16, &v->act[0], &v->act[1], &v->act[2], &v->act[3], &v->aq, &v->ak,
                       &v->av, &v->avt, &v->scores, &v->probs, &v->gn_partial, &v->gn_ab, &v->zin, &v->img_in, &v->gn_chan};
     for (DevBuf* b : bufs) b->release();
+    for (DevBuf& b : v->up_phase) b.release();
     delete v;
     return FLUX2MI_OK;
 }
