@@ -968,7 +968,11 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
         const GemmProblem& q = probs[i];   // fused QK norm + RoPE: whole heads per tile, 16-byte row stores
         if (q.qk_qw && (!q.qk_kw || !q.qk_pos || q.qk_cols % 512 != 0 || q.qk_cols > q.N || (q.N & 255) || (q.ldc & 7) ||
                         (reinterpret_cast<uintptr_t>(q.C) & 15) || (q.epi != EPI_BF16 && q.epi != EPI_QKV_MLP) ||
-                        (q.epi == EPI_QKV_MLP && q.qk_cols > q.n_split)))
+                        (q.epi == EPI_QKV_MLP && q.qk_cols > q.n_split) ||
+                        // the fused epilogue's row offsets are 32-bit; its e4m3 form stores 8-byte runs
+                        (unsigned long long)q.M * (unsigned long long)q.ldc * 2ull >= (1ull << 32) ||
+                        (q.qk8 && ((q.qk8_ld & 7) || (reinterpret_cast<uintptr_t>(q.qk8) & 7) ||
+                                   (unsigned long long)q.M * (unsigned long long)q.qk8_ld >= (1ull << 32)))))
             return 1;
         tiles[i] = wide ? ((q.M + 511) / 512) * ((q.N + 127) / 128) : ((q.M + 32 * ni - 1) / (32 * ni)) * ((q.N + TN - 1) / TN);
     }
