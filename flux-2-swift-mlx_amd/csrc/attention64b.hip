@@ -121,8 +121,8 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
             asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(qf8[qb].hi) : "v"(qp) : "memory");
         }
     }
-    // QK8: the e8m0 scale operands that undo q8 = q 2^qe, k8 = k 2^ke (qk8_exps = qe | ke << 8), in every byte
-    uint32_t sc_q = 0x01010101u * (uint32_t)(127 - (qk8_exps & 0xff)), sc_k = 0x01010101u * (uint32_t)(127 - ((qk8_exps >> 8) & 0xff));
+    // QK8: the e8m0 scale operands that undo q8 = q 2^qe, k8 = k 2^ke (qk8_exps = the two e8m0 bytes 127 - qe | (127 - ke) << 8), in every byte
+    uint32_t sc_q = 0x01010101u * (uint32_t)(qk8_exps & 0xff), sc_k = 0x01010101u * (uint32_t)((qk8_exps >> 8) & 0xff);
     asm volatile("" : "+v"(sc_q), "+v"(sc_k));
 
     // ---- LDS-DMA sources.  K piece j of wave w: rows 16 j + 4 w + (lane >> 4), LDS chunk lane & 15 <- global chunk (lane & 15) ^ f(row),
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
 #define A64B_CAT2(a, b, c) a##b##c
 #define A64B_CAT(a, b, c) A64B_CAT2(a, b, c)
 #define A64B_VARIANT A64B_CAT(launch_attention64b_v, ATTN64B_DOFF, ATTN64B_QK8)
-// q, k: bf16 rows of ldqk elements, or (QK8) e4m3 rows of ldqk bytes with qk8_exps = qe | ke << 8 (q8 = q 2^qe, k8 = k 2^ke)
+// q, k: bf16 rows of ldqk elements, or (QK8) e4m3 rows of ldqk bytes with qk8_exps = (127 - qe) | (127 - ke) << 8 (q8 = q 2^qe, k8 = k 2^ke)
 int launch_attention64b_v00(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int);
 int launch_attention64b_v10(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int);
 int launch_attention64b_v01(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int);
@@ -585,8 +585,8 @@ int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k
 }
 int launch_attention64b_qk8(hipStream_t stream, const uint8_t* q8, const uint8_t* k8, int ld8, int q_exp, int k_exp, const uint16_t* vt, int s_pad,
                             uint16_t* out, int ldo, int Sq, int S, int heads, bool data_offset) {
-    if (q_exp < 0 || q_exp > 60 || k_exp < 0 || k_exp > 60) return 1;
-    const int exps = q_exp | (k_exp << 8);
+    if (q_exp < -60 || q_exp > 60 || k_exp < -60 || k_exp > 60) return 1;   // negative: operands larger than e4m3's 448 were scaled DOWN
+    const int exps = (127 - q_exp) | ((127 - k_exp) << 8);
     return data_offset ? launch_attention64b_v11(stream, q8, k8, ld8, vt, s_pad, out, ldo, Sq, S, heads, exps)
                        : launch_attention64b_v01(stream, q8, k8, ld8, vt, s_pad, out, ldo, Sq, S, heads, exps);
 }

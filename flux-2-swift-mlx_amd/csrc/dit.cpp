@@ -520,7 +520,7 @@ extern "C" int flux2mi_dit_finalize(flux2mi_dit* m) {
         };
         const float c = 128.0f / sqrtf(128.0f) * 1.4426950408889634f * 1.03f;
         // e4m3 exponents: |q_d| <= sqrt(128) max|w_q| q_mul (q carries the score scale log2(e) / sqrt(128)), |k_d| <= sqrt(128) max|w_k|
-        auto e8 = [](float bound) { return bound > 0.f ? std::max(0, std::min(30, (int)floorf(log2f(448.0f / bound)))) : 0; };
+        auto e8 = [](float bound) { return bound > 0.f ? std::max(-30, std::min(30, (int)floorf(log2f(448.0f / bound)))) : 0; };
         const float qm = 1.4426950408889634f / sqrtf(128.0f), r128 = sqrtf(128.0f);
         for (auto& b : m->dbl) {
             float q0, q1, k0, k1;

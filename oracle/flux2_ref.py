@@ -332,7 +332,7 @@ def fp8_qk(q: Tensor, k: Tensor, wq_max: float, wk_max: float) -> Tuple[Tensor, 
     r128 = math.sqrt(128.0)
 
     def e8(bound):
-        return max(0, min(30, int(math.floor(math.log2(448.0 / bound))))) if bound > 0 else 0
+        return max(-30, min(30, int(math.floor(math.log2(448.0 / bound))))) if bound > 0 else 0
     qe, ke = e8(r128 * wq_max * c), e8(r128 * wk_max)
 
     def rq(x, e):

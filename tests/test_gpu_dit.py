@@ -155,10 +155,12 @@ def test_production_width_blocks_ragged(flux2mi, ctx):
 
 
 # ---- weight_format 1: e4m3 block GEMMs ----------------------------------------------------------
-def _fp8_case(ctx, cfg, s_txt, h, w, std=0.05):
+def _fp8_case(ctx, cfg, s_txt, h, w, std=0.05, tweak=None):
     from flux2mi import synthetic as syn
     from flux2mi.api import DiT
     P = syn.make_dit_weights(cfg, seed=77, std=std)
+    if tweak:
+        tweak(P)
     inp = syn.make_inputs(cfg, h, w, s_txt=s_txt)
     lat = R.pack_patchified_to_sequence(inp["noise"])
     img_ids, txt_ids = R.image_position_ids(h, w), R.text_position_ids(s_txt)
@@ -199,6 +201,28 @@ def test_tiny_forward_fp8(flux2mi, ctx, s_txt, h, w):
     d_ref = (ref8 - ref32).flatten()
     assert torch.dot(d_hip, d_ref) / (d_hip.norm() * d_ref.norm()) > 0.7
     assert outs["fp8_bytes"] < 0.7 * outs["bf16_bytes"]  # block weights are stored in one byte
+
+
+def test_tiny_forward_fp8_large_key_norm_weights(flux2mi, ctx):
+    """Key-norm weights x 64, query-norm weights / 64 (the same scores): the keys' bound sqrt(128) max|w_k| ~ 900 is beyond e4m3's 448, so
+    the e4m3 keys of the attention are scaled DOWN (negative power of two, dit.cpp finalize / oracle fp8_qk) instead of saturating; the
+    tolerances of test_tiny_forward_fp8 hold unchanged."""
+    from flux2mi import synthetic as syn
+
+    def tweak(P):
+        for k in P:
+            if k.endswith("key_norm.scale"):
+                P[k] = (P[k].float() * 64.0).to(P[k].dtype)
+            elif k.endswith("query_norm.scale"):
+                P[k] = (P[k].float() / 64.0).to(P[k].dtype)
+    outs, ref32, ref8 = _fp8_case(ctx, syn.DIT_PRESETS["tiny"], 16, 128, 128, tweak=tweak)
+    assert torch.isfinite(outs["fp8"]).all()
+    assert rel_l2(outs["bf16"], ref32) < 2e-2
+    q = rel_l2(ref8, ref32)
+    e8 = rel_l2(outs["fp8"], ref8)
+    print(f"large key-norm weights: q {q:.3e}, HIP fp8 vs emulation {e8:.3e}")
+    assert e8 < 1e-2 and e8 < q
+    assert 0.5 * q < rel_l2(outs["fp8"], ref32) < 1.5 * q
 
 
 def test_klein9b_width_blocks(flux2mi, ctx):

@@ -665,3 +665,29 @@ def test_attention_e4m3_qk(ctx, S, heads, doff):
     assert torch.isfinite(out).all()
     assert rel_l2(out, ref) < 1e-2, rel_l2(out, ref)
     assert torch.equal(out, ctx.op_attention_qk8(q8.cuda(), k8.cuda(), v.cuda(), heads, qe, ke, bound).float().cpu())
+
+
+@pytest.mark.gpu
+def test_attention_e4m3_qk_negative_exponent(ctx):
+    """Operands larger than e4m3's 448 are scaled DOWN (k8 = k 2^-3 for keys of magnitude ~600, e.g. a checkpoint whose key-norm weights
+    are large): the scale operand carries 2^+3, the scores are the same as with any other split of the powers of two."""
+    import math
+    S, heads = 448, 2
+    g = torch.Generator().manual_seed(77)
+    d = heads * 128
+    x = torch.randn((S, 3 * d), generator=g)
+    q = x[:, :d].view(S, heads, 128)
+    k = x[:, d:2 * d].view(S, heads, 128)
+    q = q / q.pow(2).mean(-1, keepdim=True).sqrt() / 200.0
+    k = k / k.pow(2).mean(-1, keepdim=True).sqrt() * 200.0          # |k_d| up to ~800
+    c = math.log2(math.e) / math.sqrt(128.0)
+    qe, ke = 14, -3
+    q8 = ((q * c).reshape(S, d) * 2.0 ** qe).clamp(-448, 448).to(torch.float8_e4m3fn)
+    k8 = (k.reshape(S, d) * 2.0 ** ke).clamp(-448, 448).to(torch.float8_e4m3fn)
+    assert float((k.abs() * 2.0 ** ke).max()) < 448.0 and float(k.abs().max()) > 448.0
+    v = x[:, 2 * d:].to(torch.bfloat16)
+    out = ctx.op_attention_qk8(q8.cuda(), k8.cuda(), v.cuda(), heads, qe, ke, 0.0).float().cpu()
+    hv = lambda t: t.reshape(1, S, heads, 128).permute(0, 2, 1, 3)
+    ref = R.sdpa(hv(q8.float() / 2.0 ** qe / c), hv(k8.float() / 2.0 ** ke), hv(v.float())).permute(0, 2, 1, 3).reshape(S, d)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 1e-2, rel_l2(out, ref)
