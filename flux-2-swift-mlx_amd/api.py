@@ -351,6 +351,17 @@ class Context:
         self._exit()
         return out
 
+    def op_gemm_fp8_blocks(self, a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        """A quantised in 16-row x 128-column e4m3 blocks with power-of-two scales (the form the fp8 models' epilogues emit), W per row."""
+        a, w = _req(a, torch.bfloat16, "A"), _req(w, torch.bfloat16, "W")
+        m, k = a.shape
+        n = w.shape[0]
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+        self._enter()
+        check(lib().flux2mi_op_gemm_fp8_blocks(self.handle, _ptr(a), _ptr(w), _ptr(out), m, n, k))
+        self._exit()
+        return out
+
     def op_layernorm_modulate(self, x, split, shift0, scale0, shift1, scale1) -> torch.Tensor:
         x = _req(x, torch.float32, "x")
         vs = [_req(v, torch.float32, "modulation vector") for v in (shift0, scale0, shift1, scale1)]

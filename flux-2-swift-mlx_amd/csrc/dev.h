@@ -21,6 +21,17 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float lo_bf16(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float hi_bf16(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
+// Block-scaled e4m3 activations (GemmProblem::a_bscale): the exponent e of a block with absolute maximum amax is the largest integer
+// with amax 2^e <= 448, clamped to [-60, 60] (amax = 0: 60); the block stores x 2^e as e4m3 and the e8m0 byte 127 - e.  Exact integer
+// arithmetic on the float's fields (448 = 0.875 x 2^9), so that every producer and the oracle agree on every block.
+__device__ __forceinline__ int fp8_block_exp(float amax) {
+    if (!(amax > 0.f)) return 60;
+    int x;
+    const float m = frexpf(amax, &x);          // amax = m 2^x, m in [0.5, 1)
+    const int e = (m <= 0.875f ? 9 : 8) - x;
+    return e < -60 ? -60 : (e > 60 ? 60 : e);
+}
+
 // OCP e4m3 pack of 4 floats (already divided by the scale); clamped to +-448 (the cast has no saturation)
 __device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
     a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);

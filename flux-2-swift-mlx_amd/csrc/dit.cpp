@@ -1289,6 +1289,29 @@ extern "C" int flux2mi_op_gemm_fp8(flux2mi_ctx* ctx, const void* A, const void* 
     return FLUX2MI_OK;
 }
 
+// The same product with A quantised in 16-row x 128-column blocks with power-of-two scales (GemmProblem::a_bscale: what the SwiGLU and
+// attention epilogues of the fp8 models emit): the block scales ride in the MFMA's scale operand.
+extern "C" int flux2mi_op_gemm_fp8_blocks(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K) {
+    F2_REQUIRE(ctx && A && W && C && M > 0 && N > 0 && K > 0 && K % 128 == 0, FLUX2MI_ERR_INVALID_ARG, "op_gemm_fp8_blocks: bad argument");
+    const int lds = (((M + 15) / 16 + 12) + 15) & ~15;
+    const size_t need = (size_t)M * K + (size_t)N * K + (size_t)N * 4 + (size_t)(K / 128) * lds + 2048;
+    F2_TRY(ctx->scratch.reserve(need));
+    uint8_t* aq = ctx->scratch.as<uint8_t>();
+    uint8_t* wq = aq + (((size_t)M * K + 255) & ~(size_t)255);
+    float* ws = reinterpret_cast<float*>(wq + (((size_t)N * K + 255) & ~(size_t)255));
+    uint8_t* bs = reinterpret_cast<uint8_t*>(ws) + (((size_t)N * 4 + 255) & ~(size_t)255);
+    F2_CHECK_HIP(hipMemsetAsync(bs, 0x7F, (size_t)(K / 128) * lds, ctx->stream));
+    F2_LAUNCH(launch_quantize_blocks_fp8(ctx->stream, reinterpret_cast<const uint16_t*>(A), K, aq, K, bs, lds, M, K), "quantize A (blocks)");
+    F2_LAUNCH(launch_quantize_rows_fp8(ctx->stream, reinterpret_cast<const uint16_t*>(W), K, wq, K, ws, N, K), "quantize W");
+    GemmProblem p = mk(reinterpret_cast<const uint16_t*>(aq), K, reinterpret_cast<const uint16_t*>(wq), K, C, N, M, N, K, EPI_F32);
+    p.fp8 = 1; p.a_scale = nullptr; p.w_scale = ws; p.a_bscale = bs; p.a_bscale_ld = lds;
+    prof_before(ctx, PROF_DIT_GEMM);
+    const int r = launch_gemm(ctx->stream, &p, 1);
+    prof_after(ctx, PROF_DIT_GEMM, 2.0 * M * (double)N * K);
+    F2_LAUNCH(r, "op_gemm_fp8_blocks");
+    return FLUX2MI_OK;
+}
+
 extern "C" int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv_in, void* out, int S, int heads) {
     F2_REQUIRE(ctx && qkv_in && out && S > 0 && heads > 0, FLUX2MI_ERR_INVALID_ARG, "op_attention: bad argument");
     const int d = heads * 128, s_pad = attn_s_pad(S);

@@ -350,7 +350,9 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
         if (n_fp8 != nprob) return 1;
         for (int i = 0; i < nprob; ++i) {
             const GemmProblem& p = probs[i];
-            if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.K % 128 != 0 || (p.lda & 15) || (p.ldw & 15) || !p.a_scale || !p.w_scale) return 1;
+            if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.K % 128 != 0 || (p.lda & 15) || (p.ldw & 15) || (!p.a_scale && !p.a_bscale) || !p.w_scale) return 1;
+            // block-scaled A (kernels.h): the table is read by 4-byte aligned scalar loads, up to 12 bytes behind a tile's first row block
+            if (p.a_bscale && ((reinterpret_cast<uintptr_t>(p.a_bscale) & 3) || (p.a_bscale_ld & 3) || p.a_bscale_ld < (p.M + 15) / 16 + 12)) return 1;
             if ((p.epi == EPI_SWIGLU || p.epi == EPI_QKV_MLP) && (p.N % 64 != 0 || p.n_split % 256 != 0)) return 1;
         }
         // the one-wave-per-SIMD kernel (gemm256s.hip)

@@ -167,6 +167,9 @@ struct SchedF {
     static_assert(B1 < Q0 && B1 < B2 && RA1 <= 8 && spaced(), "fp8 schedule");
 };
 
+// e8m0 1.0 in every byte: the A block-scale "table" of a problem that has none (GemmProblem::a_bscale), read with a row stride of 0
+__device__ const uint32_t gs_unit_scales[4] = {0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu};
+
 template <int I> using ic = std::integral_constant<int, I>;
 template <bool B> using bc = std::integral_constant<bool, B>;
 // f(ic<0>{}), f(ic<1>{}), ... in order
@@ -345,6 +348,22 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                                                     // ds_read_b128 into the SAME register tuple
     int unit_scale = 0x7F7F7F7F;                    // e8m0 127 = 1.0 in every byte; the real scales are per row / column, in the epilogue
     asm volatile("" : "+v"(unit_scale));
+    // A block scales (GemmProblem::a_bscale): one e8m0 byte per 16-row block and K-tile = per MFMA row block i, uniform over the wave.
+    // Per K-tile the wave's NI bytes [rb0, rb0 + NI) of table row kt arrive as two overlapping scalar loads (dwords 0-1 and 1-2 from
+    // the 4-byte aligned address below rb0), are shifted down by rb0 % 4 bytes once the K-tile's lgkmcnt(0) has passed, and are moved
+    // into the two VGPRs the MFMAs take their activation scale from (byte i % 4 of asc[i / 4], selected by op_sel): asc0 (rows 0-3)
+    // behind MFMA 31 for the next tile, asc1 (rows 4..) at gap 0 for this one — replaced in place like the operands.
+    const int bs_rb0 = __builtin_amdgcn_readfirstlane((m0 + wm * WROWS) >> 4);
+    const uint32_t bs_sh = (uint32_t)(bs_rb0 & 3) * 8u;
+    const bool bs_on = p.a_bscale != nullptr;
+    const uint8_t* bs_ptr = bs_on ? p.a_bscale + (bs_rb0 & ~3) : reinterpret_cast<const uint8_t*>(gs_unit_scales);
+    const int bs_ld = bs_on ? p.a_bscale_ld : 0;
+    unsigned long long bs_l0, bs_l1, bs_t0, bs_t1;   // loaded dword pairs, shifted pairs (the low halves are the scales)
+    uint32_t asc0, asc1;
+    asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(bs_l0), "=&s"(bs_l1) : "s"(bs_ptr) : "memory");
+    asm volatile("s_lshr_b64 %0, %2, %4\n\ts_lshr_b64 %1, %3, %4" : "=&s"(bs_t0), "=&s"(bs_t1) : "s"(bs_l0), "s"(bs_l1), "s"(bs_sh) : "scc");
+    asm volatile("v_mov_b32 %0, %1" : "=v"(asc0) : "s"((uint32_t)bs_t0));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(asc1) : "s"((uint32_t)bs_t1));
     {
         auto fill_all = [&](uint32_t mm, const uint8_t* sa, const uint8_t* sw_) GS_INLINE {
             for_seq([&](auto nc) GS_INLINE {
@@ -385,20 +404,37 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
         const uint32_t mm = m0_wave + st_cur;
         const uint8_t* sa = gA + (size_t)(u + 2) * 128;
         const uint8_t* sw_ = gW + (size_t)(u + 2) * 128;
+        const uint8_t* bsp = bs_ptr + (size_t)(u + 1) * (size_t)bs_ld;   // the next tile's block scales
         auto gap = [&](auto gc) GS_INLINE {
             constexpr int I = decltype(gc)::value;
             (void)acc; (void)wop; (void)aop; (void)unit_scale; (void)hal; (void)hah; (void)hal2; (void)hah2; (void)hbl2; (void)hbh2;
-            (void)mm; (void)sa; (void)sw_;
+            (void)mm; (void)sa; (void)sw_; (void)bsp; (void)bs_l0; (void)bs_l1; (void)bs_t0; (void)bs_t1; (void)asc0; (void)asc1; (void)bs_sh;
             // both halves column-major: W operand j is first needed at gap 4 j, i.e. the later it was re-read the later it is used
             constexpr int i = I < 32 ? I % 4 : 4 + (I - 32) % S::H1N, j = I < 32 ? I / 4 : (I - 32) / S::H1N;
             // W operand first: acc[i][j] rows = output columns j*16 + fq*4 + r, lanes = output rows i*16 + frow
-            asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(acc[i][j]) : "v"(wop[j]), "v"(aop[i]), "v"(unit_scale));
+            // scale operands: the W operand's (unit), then the activation's: byte i % 4 of asc[i / 4] (op_sel / op_sel_hi = the two bits of the byte index)
+            if constexpr (I == 0) asm volatile("v_mov_b32 %0, %1" : "+v"(asc1) : "s"((uint32_t)bs_t1));   // this tile's rows 4..: free since the previous tile's last MFMA
+            if constexpr (i < 4) {
+                if constexpr (i == 0) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+a"(acc[i][j]) : "v"(wop[j]), "v"(aop[i]), "v"(unit_scale), "v"(asc0));
+                if constexpr (i == 1) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[0,1,0] op_sel_hi:[0,0,0]" : "+a"(acc[i][j]) : "v"(wop[j]), "v"(aop[i]), "v"(unit_scale), "v"(asc0));
+                if constexpr (i == 2) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+a"(acc[i][j]) : "v"(wop[j]), "v"(aop[i]), "v"(unit_scale), "v"(asc0));
+                if constexpr (i == 3) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+a"(acc[i][j]) : "v"(wop[j]), "v"(aop[i]), "v"(unit_scale), "v"(asc0));
+            } else {
+                if constexpr (i == 4) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+a"(acc[i][j]) : "v"(wop[j]), "v"(aop[i]), "v"(unit_scale), "v"(asc1));
+                if constexpr (i == 5) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[0,1,0] op_sel_hi:[0,0,0]" : "+a"(acc[i][j]) : "v"(wop[j]), "v"(aop[i]), "v"(unit_scale), "v"(asc1));
+                if constexpr (i == 6) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+a"(acc[i][j]) : "v"(wop[j]), "v"(aop[i]), "v"(unit_scale), "v"(asc1));
+                if constexpr (i == 7) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+a"(acc[i][j]) : "v"(wop[j]), "v"(aop[i]), "v"(unit_scale), "v"(asc1));
+            }
+            if constexpr (RD && I == 1) asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x4" : "=&s"(bs_l0), "=&s"(bs_l1) : "s"(bsp) : "memory");
             if constexpr (I < S::RA1) {                      // A rows 4.. of this tile: operand 4 + I / 2, half I % 2
                 constexpr int ai = 4 + I / 2;
                 if constexpr (I % 2 == 0) GS_DSR(aop[ai].lo, hal, ai * 2048);
                 else GS_DSR(aop[ai].hi, hah, ai * 2048);
             }
             if constexpr (I == S::B1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // (the scalar loads of gap 1 are behind that wait) the next tile's bytes, shifted to bit 0
+            if constexpr (RD && I == S::B1 + 1) asm volatile("s_lshr_b64 %0, %2, %4\n\ts_lshr_b64 %1, %3, %4" : "=&s"(bs_t0), "=&s"(bs_t1) : "s"(bs_l0), "s"(bs_l1), "s"(bs_sh) : "scc");
+            if constexpr (RD && I == 33) asm volatile("v_mov_b32 %0, %1" : "+v"(asc0) : "s"((uint32_t)bs_t0));   // rows 0-3 of the next tile: free behind MFMA 31
             if constexpr (I == S::B2) {
                 if constexpr (IS) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(S::before_b2()) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -463,7 +499,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     f32x4 fs_col[8];
     if constexpr (FP8) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) fs_row[i] = p.a_scale[(unsigned)min(row_base + i * 16, p.M - 1)];
+        for (int i = 0; i < NI; ++i) fs_row[i] = p.a_bscale ? 1.0f : p.a_scale[(unsigned)min(row_base + i * 16, p.M - 1)];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll

@@ -42,6 +42,12 @@ struct GemmProblem {
     const float* a_scale;
     const float* w_scale;
     int fp8;
+    // fp8, gemm256s: A quantised in 2-D blocks instead of per row — one e8m0 byte (value = 2^(byte - 127)) per 16 consecutive rows x
+    // 128 consecutive k (= one K-tile): a_bscale[kt * a_bscale_ld + (row >> 4)], row = the problem's A row.  The bytes ride in the
+    // block-scaled MFMA's scale operand (no epilogue factor; a_scale is not read).  Written by the producing epilogues (SwiGLU hidden,
+    // attention output) or by launch_quantize_blocks_fp8.  a_bscale 4-byte aligned, a_bscale_ld % 4 == 0 and >= ceil(M / 16) + 12.
+    const uint8_t* a_bscale;
+    int a_bscale_ld;
     // 256x256 kernel, EPI_BF16 columns [0, qk_cols) (= q | k of a fused qkv projection, qk_cols = 2*dim, dim % 256 == 0):
     // per-head RMSNorm (eps 1e-6, weights qk_qw / qk_kw bf16 [128]) + RoPE applied to the f32 accumulators before
     // the store — what launch_qk_norm_rope_vt does in a separate pass over the stored bf16 values; q additionally
@@ -143,6 +149,9 @@ int launch_layernorm_modulate_fp8(hipStream_t stream, const float* x, uint8_t* y
 // Register-only MFMA stream (mfma_stream.hip): the matrix-pipe rate this card sustains at its power cap; diagnostic.
 int launch_mfma_stream(hipStream_t stream, float* out, int workgroups, bool fp8, double seconds, double* tflops);
 // Row-wise dynamic quantisation bf16 [rows, cols] (row stride ld) -> e4m3 [rows, cols] (stride ldq) + scale[rows].
+// x bf16 [rows, cols] -> e4m3 in 16 x 128 blocks with power-of-two scales: q [rows, cols] bytes + bscale[(col / 128) * lds + row / 16]
+// (GemmProblem::a_bscale; dev.h fp8_block_exp).  cols % 128 == 0, lds >= ceil(rows / 16)
+int launch_quantize_blocks_fp8(hipStream_t stream, const uint16_t* x, int ld, uint8_t* q, int ldq, uint8_t* bscale, int lds, int rows, int cols);
 int launch_quantize_rows_fp8(hipStream_t stream, const uint16_t* x, int ld, uint8_t* q, int ldq, float* scale,
                              int rows, int cols);
 // In place on qkv bf16 [S, 3*dim] (q | k | v): per-head RMSNorm (eps 1e-6, learned scale)

@@ -177,6 +177,31 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const uint16_t* 
     }
 }
 
+// Block quantisation of a bf16 matrix (GemmProblem::a_bscale): one workgroup per 16 rows x 128 columns, thread = (row, 8-column chunk).
+// The stand-alone form of what the SwiGLU and attention epilogues do in place; rows beyond `rows` count as zeros.
+__global__ __launch_bounds__(256) void quantize_blocks_fp8_kernel(const uint16_t* __restrict__ x, int ld, uint8_t* __restrict__ q, int ldq,
+                                                                  uint8_t* __restrict__ bscale, int lds, int rows) {
+    __shared__ float red[4];
+    const int kb = blockIdx.x, rb = blockIdx.y;
+    const int row = rb * 16 + (threadIdx.x >> 4), c0 = kb * 128 + (threadIdx.x & 15) * 8;
+    uint4 u = make_uint4(0u, 0u, 0u, 0u);
+    if (row < rows) u = *reinterpret_cast<const uint4*>(x + (size_t)row * ld + c0);
+    const float f[8] = {lo_bf16(u.x), hi_bf16(u.x), lo_bf16(u.y), hi_bf16(u.y), lo_bf16(u.z), hi_bf16(u.z), lo_bf16(u.w), hi_bf16(u.w)};
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+    amax = block_max_256(amax, red);
+    const int e = fp8_block_exp(amax);
+    const float m = ldexpf(1.0f, e);
+    if (threadIdx.x == 0) bscale[(size_t)kb * lds + rb] = (uint8_t)(127 - e);
+    if (row < rows) {
+        uint2 o;
+        o.x = pack_fp8x4(f[0] * m, f[1] * m, f[2] * m, f[3] * m);
+        o.y = pack_fp8x4(f[4] * m, f[5] * m, f[6] * m, f[7] * m);
+        *reinterpret_cast<uint2*>(q + (size_t)row * ldq + c0) = o;
+    }
+}
+
 // ------------------------------------------------------------------ QK RMSNorm + RoPE (in place)
 // 16 lanes per (row, head, q|k) vector of 128: a lane owns 8 consecutive elements = 4 RoPE
 // pairs (16-B accesses); a wave handles 4 vectors, a workgroup 16.  Sum of squares by a
@@ -406,6 +431,12 @@ int launch_quantize_rows_fp8(hipStream_t stream, const uint16_t* x, int ld, uint
                              int rows, int cols) {
     if (rows <= 0 || cols <= 0 || (cols & 7) || (ld & 7) || (ldq & 7)) return 1;
     hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(rows), dim3(256), 0, stream, x, ld, q, ldq, scale, cols);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_quantize_blocks_fp8(hipStream_t stream, const uint16_t* x, int ld, uint8_t* q, int ldq, uint8_t* bscale, int lds, int rows, int cols) {
+    if (rows <= 0 || cols <= 0 || (cols & 127) || (ld & 7) || (ldq & 7) || lds < (rows + 15) / 16) return 1;
+    hipLaunchKernelGGL(quantize_blocks_fp8_kernel, dim3(cols / 128, (rows + 15) / 16), dim3(256), 0, stream, x, ld, q, ldq, bscale, lds, rows);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -479,6 +479,9 @@ int flux2mi_op_gemm_gate_resid(flux2mi_ctx* ctx, const void* A, const void* W, c
  * per-row scales (what the fp8 model does to activations / weights), then
  * v_mfma_f32_16x16x32_fp8_fp8; K % 128 == 0. */
 int flux2mi_op_gemm_fp8(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K);
+/* the same with A quantised in 16-row x 128-column blocks with power-of-two (e8m0) scales — the form the fp8 models' SwiGLU and
+   attention epilogues emit for proj / mlp_out / linear2 (no reference counterpart: weight_format 1 is this library's own quantiser) */
+int flux2mi_op_gemm_fp8_blocks(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K);
 /* Per-op entry points of the HBM-bound kernels (their own tolerance, SURVEY §8c: <= 4e-3 vs the fp32 oracle).
  * y bf16 [rows,dim] = LayerNorm(x f32, eps 1e-6, no affine) * (1 + scale) + shift; rows < split: set 0, else set 1
  * (Flux2TransformerBlock.swift:56-61, Flux2Modulation.swift:96-112). */

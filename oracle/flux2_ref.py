@@ -322,6 +322,28 @@ def fake_quant_e4m3_rows(x: Tensor) -> Tensor:
     return q * scale
 
 
+def fp8_block_exponents(amax: Tensor) -> Tensor:
+    """dev.h fp8_block_exp: the largest integer e with amax 2^e <= 448 (= 0.875 x 2^9), clamped to [-60, 60] (amax = 0: 60), from the
+    float's mantissa / exponent fields — exact, so that the device and this restatement agree on every block."""
+    m, x = torch.frexp(amax.float())
+    e = torch.where(m <= 0.875, 9 - x, 8 - x).clamp(-60, 60)
+    return torch.where(amax > 0, e, torch.full_like(e, 60))
+
+
+def fake_quant_e4m3_blocks(x: Tensor) -> Tensor:
+    """Block quantisation of an activation [..., S, K] to OCP e4m3 (the MI355X path's GemmProblem::a_bscale — NOT a restatement of the
+    reference): blocks of 16 consecutive rows x 128 consecutive columns share one power-of-two scale 2^-e (fp8_block_exponents of the
+    block's absolute maximum); rows beyond S count as zeros.  Returns the de-quantised f32 values."""
+    xf = x.float()
+    S, K = xf.shape[-2], xf.shape[-1]
+    Sp = (S + 15) // 16 * 16
+    xp = F.pad(xf, (0, 0, 0, Sp - S)).reshape(*xf.shape[:-2], Sp // 16, 16, K // 128, 128)
+    amax = xp.abs().amax(dim=(-3, -1), keepdim=True)
+    mult = torch.exp2(fp8_block_exponents(amax).float())
+    q = (xp * mult).clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).float() / mult
+    return q.reshape(*xf.shape[:-2], Sp, K)[..., :S, :]
+
+
 def fp8_qk(q: Tensor, k: Tensor, wq_max: float, wk_max: float) -> Tuple[Tensor, Tensor]:
     """fp8 mode, plain forwards only (the MI355X path's e4m3 Q K^T, attention64b.hip QK8 / dit.cpp finalize — NOT a restatement of the
     reference): q carries the score scale log2(e)/sqrt(128); q 2^qe and k 2^ke are rounded to e4m3 with the largest powers of two that

@@ -169,6 +169,37 @@ def test_gemm_fp8_vs_emulation(ctx, M, N, K):
     assert rel_l2(out, exact) < 6e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 512), (300, 200, 384), (1000, 1544, 1024), (4608, 512, 3072), (1360, 512, 1024),
+                                   (2240, 256, 256)])
+def test_gemm_fp8_block_scaled_activations(ctx, M, N, K):
+    """op_gemm_fp8_blocks: A in 16-row x 128-column e4m3 blocks with power-of-two scales that ride in the block-scaled MFMA's scale
+    operand (GemmProblem::a_bscale; byte i % 4 of two VGPRs refreshed per K-tile from scalar loads), W per row — against the oracle's
+    fake_quant_e4m3_blocks.  Row blocks of very different magnitude (every MFMA row block and K-tile takes ITS byte: a wrong byte
+    select, K-tile or row block shows as a power-of-two error), tile heights 5-8 x 32 rows, unaligned first row blocks (M = 1360:
+    tiles of 160 rows start at row block 10, 20, ...), a partial last block, an all-zero block."""
+    from oracle import flux2_ref as R
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn((M, K), generator=g)
+    nrb, nkb = (M + 15) // 16, K // 128
+    mag = torch.exp2(torch.randint(-12, 10, (nrb, nkb), generator=g).float())          # per-block magnitudes 2^-12 .. 2^9
+    a = a * mag.repeat_interleave(16, 0)[:M].repeat_interleave(128, 1)
+    if M > 48:
+        a[32:48, :128] = 0                                                              # an all-zero block
+    a = a.to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g) * 0.05).to(torch.bfloat16)
+    out = ctx.op_gemm_fp8_blocks(a.cuda(), w.cuda()).cpu()
+    emu = R.fake_quant_e4m3_blocks(a.float()) @ R.fake_quant_e4m3_rows(w.float()).t()
+    exact = a.float() @ w.float().t()
+    assert torch.isfinite(out).all()
+    # per 16-row block: the magnitudes differ by up to 2^21 between blocks
+    for rb in range(0, M, 16 * max(1, nrb // 24)):
+        sl = slice(rb, min(rb + 16, M))
+        assert rel_l2(out[sl], emu[sl]) < 1e-3, (rb, rel_l2(out[sl], emu[sl]))
+    assert rel_l2(out, emu) < 1e-3
+    assert rel_l2(out, exact) < 6e-2
+    assert torch.equal(out, ctx.op_gemm_fp8_blocks(a.cuda(), w.cuda()).cpu())
+
+
 def test_gemm_fp8_rejects_bad_k(ctx):
     from flux2mi import Flux2Error
     a = torch.zeros((256, 192), dtype=torch.bfloat16, device="cuda")
