@@ -92,7 +92,7 @@ struct flux2mi_dit {
     // staging for ingestion
     DevBuf stage_raw, stage_bf16, stage_w, stage_d, stage_q8;
     // forward workspace
-    DevBuf hs, xn, qkv, vt, comb, mods, rope, lat_bf16, xq, xs, qk8;
+    DevBuf hs, xn, qkv, vt, comb, mods, rope, lat_bf16, xq, xs, qk8, xbs, xq2;
     DevBuf splitk_ws;   // proj_out ([s_out, d] x [128, d]^T: 32 tiles of 128x128 at 1024^2, 48 K-tiles): split-K workspace (kernels.h)
     int ws_S = 0;
 };
@@ -325,7 +325,7 @@ extern "C" int flux2mi_dit_destroy(flux2mi_dit* m) {
         if (b.scale) (void)hipFree(b.scale);
     }
     DevBuf* ws[] = {&m->stage_raw, &m->stage_bf16, &m->stage_w, &m->stage_d, &m->stage_q8, &m->hs, &m->xn, &m->qkv, &m->vt, &m->comb, &m->mods,
-                    &m->rope, &m->lat_bf16, &m->xq, &m->xs, &m->splitk_ws};
+                    &m->rope, &m->lat_bf16, &m->xq, &m->xs, &m->splitk_ws, &m->qk8, &m->xbs, &m->xq2};
     for (DevBuf* w : ws) w->release();
     delete m;
     return FLUX2MI_OK;
@@ -697,6 +697,9 @@ extern "C" int flux2mi_dit_load_prequantized(flux2mi_dit* m, const char* path, c
 // ------------------------------------------------------------------ forward
 namespace {
 
+// row pitch of the block-scale table: row blocks of 16 + the 12 bytes a scalar load may read behind the last one, 16-byte multiples
+int bscale_ld(int S) { return (((S + 15) / 16 + 12) + 15) & ~15; }
+
 int ensure_workspace(flux2mi_dit* m, int S, int s_img) {
     const int d = m->cfg.dim, H = m->cfg.heads;
     const size_t Sz = (size_t)S;
@@ -721,6 +724,15 @@ int ensure_workspace(flux2mi_dit* m, int S, int s_img) {
         F2_TRY(m->xq.reserve(Sz * 4 * d));
         F2_TRY(m->xs.reserve(Sz * 4));
         F2_TRY(m->qk8.reserve(Sz * 2 * d));   // e4m3 [S][q | k] of the current block (attention64b.hip, QK8)
+        // block scales of the block-quantised activations (GemmProblem::a_bscale): [4d / 128 K-tiles][row blocks of 16, padded]; the pad
+        // bytes are read (never used) by the scalar loads of a tile's last wave: unit scales
+        // (their bytes: a buffer of their own — the producing GEMM still reads its LayerNorm operand from xq while its epilogue writes them)
+        F2_TRY(m->xq2.reserve(Sz * 4 * d));
+        const size_t bs_bytes = (size_t)(4 * d / 128) * (size_t)bscale_ld(S);
+        if (m->xbs.bytes < bs_bytes || m->ws_S != S) {
+            F2_TRY(m->xbs.reserve(bs_bytes));
+            F2_CHECK_HIP(hipMemsetAsync(m->xbs.ptr, 0x7F, m->xbs.bytes, m->ctx->stream));
+        }
     }
     m->ws_S = S;
     return FLUX2MI_OK;
@@ -903,6 +915,35 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     auto quant = [&](const uint16_t* a, int ld, int cols) {
         return f8 ? launch_quantize_rows_fp8(st, a, ld, xq, ld, xs, S, cols) : 0;
     };
+    // fp8 models, plain forwards: the activations of proj / mlp_out / linear2 in 16-row x 128-column e4m3 blocks with power-of-two
+    // scales (kernels.h, GemmProblem::a_bscale), written by the producing epilogues instead of a row-quantise pass over bf16 copies.
+    // Row ranges start at multiples of 64 (the scale table is read by aligned scalar loads).  FLUX2MI_FP8_BLOCKS=0 (dev library): rows
+    static const int bsa_mode = [] {   // 2 (dev library): block-quantise passes in place of the fused epilogues (bisection aid)
+        const char* e = F2_DEV_ENV("FLUX2MI_FP8_BLOCKS");
+        return e ? atoi(e) : 1;
+    }();
+    const bool bsa_on = bsa_mode != 0, bsa_fused = bsa_mode == 1;
+    const bool bsa = f8 && bsa_on && mode == FWD_PLAIN && (s_txt & 63) == 0 && (img0 & 63) == 0 && d % 128 == 0;
+    const int bs_ld = bscale_ld(S);
+    uint8_t* xbs = bsa ? m->xbs.as<uint8_t>() : nullptr;
+    uint8_t* xq2 = bsa ? m->xq2.as<uint8_t>() : nullptr;
+    // the A operand of a consuming GEMM: rows from r0 of the block-quantised buffer (row pitch = the problem's lda)
+    auto with_blocks = [&](GemmProblem& q, int r0) {
+        q.A = reinterpret_cast<const uint16_t*>(xq2 + (size_t)r0 * q.lda);
+        q.a_scale = nullptr;
+        q.a_bscale = xbs + r0 / 16;
+        q.a_bscale_ld = bs_ld;
+    };
+    // the SwiGLU hidden of a producing GEMM: rows from r0 of xq (row pitch ld), hidden column 0 at byte column c0 = K-tile c0 / 128
+    auto hidden_blocks = [&](GemmProblem& q, int r0, int ld, int c0) {
+        if (!bsa_fused) return;
+        q.c2_q8 = xq2 + (size_t)r0 * ld + c0;
+        q.c2_q8_ld = ld;
+        q.c2_bs = xbs + (size_t)(c0 / 128) * bs_ld + r0 / 16;
+        q.c2_bs_ld = bs_ld;
+    };
+    // interim: the attention output (bf16 comb columns [0, d), row pitch ld) into blocks by its own pass
+    auto quant_attn_blocks = [&](int ld) { return launch_quantize_blocks_fp8(st, comb, ld, xq2, ld, xbs, bs_ld, S, d); };
     // joint attention per query range; keys = all S rows except for the reference queries of the
     // extraction pass, which see [txt | ref] only.  Also moves the reference K / V^T to / from the cache.
     // the score scale log2(e)/sqrt(128) rides on Q from the norm+RoPE kernel (one rounding, as before), so the
@@ -1008,13 +1049,15 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, s_txt, w.qn[0], w.kn[0], w.qn[1], w.kn[1], cos_tab, sin_tab,
                                          vt, s_pad, q_mul, qk8_buf, w.q8_exp, w.k8_exp), "qk_norm_rope");
         F2_TRY(attend(i, comb, d, w.score_bound, w.q8_exp, w.k8_exp));
-        F2_LAUNCH(quant(comb, d, d), "quantize(attn out)");
+        if (bsa) F2_LAUNCH(quant_attn_blocks(d), "quantize(attn out, blocks)");
+        else F2_LAUNCH(quant(comb, d, d), "quantize(attn out)");
         {
             GemmProblem p[2];
             p[0] = blk(comb, d, 0, w.proj[0], hs, d, s_txt, d, d, EPI_GATE_RESID);
             p[0].vec = mod_txt + 2 * d;
             p[1] = blk(comb, d, img0, w.proj[1], hs + (size_t)img0 * d, d, n_img, d, d, EPI_GATE_RESID);
             p[1].vec = mod_img + 2 * d;
+            if (bsa) { with_blocks(p[0], 0); with_blocks(p[1], img0); }
             F2_TRY(run_gemm(m, p, 2, 0, "dbl.proj"));
         }
         // feed-forward half: LN -> modulate(set 1) -> Linear(d->6d) SwiGLU -> Linear(3d->d)
@@ -1025,15 +1068,18 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
             p[0].C2 = comb; p[0].ldc2 = 3 * d;
             p[1] = blk(xn, d, img0, w.mlp_in[1], nullptr, 0, n_img, 6 * d, d, EPI_SWIGLU);
             p[1].C2 = comb + (size_t)img0 * 3 * d; p[1].ldc2 = 3 * d;
+            if (bsa) { hidden_blocks(p[0], 0, 3 * d, 0); hidden_blocks(p[1], img0, 3 * d, 0); }   // straight into mlp_out's operand
             F2_TRY(run_gemm(m, p, 2, 0, "dbl.mlp_in"));
         }
-        F2_LAUNCH(quant(comb, 3 * d, 3 * d), "quantize(ff hidden)");
+        if (!bsa) F2_LAUNCH(quant(comb, 3 * d, 3 * d), "quantize(ff hidden)");
+        else if (!bsa_fused) F2_LAUNCH(launch_quantize_blocks_fp8(st, comb, 3 * d, xq2, 3 * d, xbs, bs_ld, S, 3 * d), "quantize(ff hidden, blocks)");
         {
             GemmProblem p[2];
             p[0] = blk(comb, 3 * d, 0, w.mlp_out[0], hs, d, s_txt, d, 3 * d, EPI_GATE_RESID);
             p[0].vec = mod_txt + 5 * d;
             p[1] = blk(comb, 3 * d, img0, w.mlp_out[1], hs + (size_t)img0 * d, d, n_img, d, 3 * d, EPI_GATE_RESID);
             p[1].vec = mod_img + 5 * d;
+            if (bsa) { with_blocks(p[0], 0); with_blocks(p[1], img0); }
             F2_TRY(run_gemm(m, p, 2, 0, "dbl.mlp_out"));
         }
     }
@@ -1058,6 +1104,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
             p[1] = blk(xn, d, 0, wrows(w.lin1, 3 * d, d), nullptr, 0, S, 6 * d, d, EPI_SWIGLU);
             p[1].C2 = comb + d;
             p[1].ldc2 = 4 * d;
+            if (bsa) hidden_blocks(p[1], 0, 4 * d, d);   // columns d..4d of linear2's operand
             F2_TRY(run_gemm(m, p, 2, PROF_LINEAR1, "single.linear1(qk|mlp)"));
             GemmProblem pv = vt_problem(wrows(w.lin1, 2 * d, d), 0, S);
             F2_TRY(run_gemm(m, &pv, 1, PROF_LINEAR1, "single.linear1(vt)"));
@@ -1069,6 +1116,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
                 p[r].n_split = 3 * d;
                 p[r].C2 = comb + (size_t)rng0[r] * 4 * d + d;  // SwiGLU hidden goes to columns d..4d of comb
                 p[r].ldc2 = 4 * d;
+                if (bsa) hidden_blocks(p[r], rng0[r], 4 * d, d);
                 if (qk_fuse) {   // per-head RMSNorm + RoPE of q | k in the GEMM epilogue (no separate pass over qkv)
                     p[r].qk_qw = w.qn; p[r].qk_kw = w.kn; p[r].qk_pos = pos_tab;
                     p[r].qk_cols = 2 * d; p[r].qk_row0 = rng0[r]; p[r].qk_qmul = q_mul;
@@ -1085,12 +1133,15 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, 0, w.qn, w.kn, w.qn, w.kn, cos_tab, sin_tab, vt, s_pad, q_mul, qk8_buf, w.q8_exp,
                                          w.k8_exp), "qk_norm_rope");
         F2_TRY(attend(m->cfg.n_double + i, comb, 4 * d, w.score_bound, w.q8_exp, w.k8_exp));
-        F2_LAUNCH(quant(comb, 4 * d, 4 * d), "quantize(attn | ff hidden)");
+        if (bsa && !bsa_fused) F2_LAUNCH(launch_quantize_blocks_fp8(st, comb, 4 * d, xq2, 4 * d, xbs, bs_ld, S, 4 * d), "quantize(attn | ff hidden, blocks)");
+        else if (bsa) F2_LAUNCH(quant_attn_blocks(4 * d), "quantize(attn out, blocks)");   // the hidden columns are in place already
+        else F2_LAUNCH(quant(comb, 4 * d, 4 * d), "quantize(attn | ff hidden)");
         {
             GemmProblem p[2];
             for (int r = 0; r < n_rng; ++r) {
                 p[r] = blk(comb, 4 * d, rng0[r], w.lin2, hs + (size_t)rng0[r] * d, d, rngn[r], d, 4 * d, EPI_GATE_RESID);
                 p[r].vec = mod_sgl + 2 * d;
+                if (bsa) with_blocks(p[r], rng0[r]);
             }
             F2_TRY(run_gemm(m, p, n_rng, 0, "single.linear2"));
         }

@@ -354,6 +354,10 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
             // block-scaled A (kernels.h): the table is read by 4-byte aligned scalar loads, up to 12 bytes behind a tile's first row block
             if (p.a_bscale && ((reinterpret_cast<uintptr_t>(p.a_bscale) & 3) || (p.a_bscale_ld & 3) || p.a_bscale_ld < (p.M + 15) / 16 + 12)) return 1;
             if ((p.epi == EPI_SWIGLU || p.epi == EPI_QKV_MLP) && (p.N % 64 != 0 || p.n_split % 256 != 0)) return 1;
+            // SwiGLU hidden as block-scaled e4m3: whole 256-column tiles (= 128 hidden columns, one scale block), 8-byte runs
+            if (p.c2_q8 && ((p.epi != EPI_SWIGLU && p.epi != EPI_QKV_MLP) || !p.c2_bs || (p.N - (p.epi == EPI_QKV_MLP ? p.n_split : 0)) % 256 != 0 ||
+                            (p.c2_q8_ld & 7) || (reinterpret_cast<uintptr_t>(p.c2_q8) & 7)))
+                return 1;
         }
         // the one-wave-per-SIMD kernel (gemm256s.hip)
         return gemm256s_eligible(probs, nprob) ? launch_gemm256s(stream, probs, nprob) : 1;

@@ -754,9 +754,41 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
         }
         return;
     }
+    // ---- SwiGLU hidden as block-scaled e4m3 (GemmProblem::c2_q8): a tile's 128 hidden columns x the 16 rows of an MFMA row block are
+    // one block.  First pass: the block maxima (the lane's 16 values per row block, the wave by lane exchange, the two waves of a row
+    // through LDS), exponents, scale bytes; the stores below then recompute the values and write bytes.
+    float bs_mult[NI];
+    const bool q8_out = FP8 && !CONV && epi == EPI_SWIGLU && p.c2_q8 != nullptr;
+    if constexpr (FP8 && !CONV) {
+        __shared__ float bsred[2][2][8];
+        if (q8_out) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                float mx = 0.f;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(silu_f(accv(i, 4 * hh + jj)[r]) * accv(i, 4 * hh + jj + 2)[r]));
+#pragma unroll
+                for (int sft = 1; sft < 64; sft <<= 1) mx = fmaxf(mx, __shfl_xor(mx, sft));
+                if (lane == 0) bsred[wm][wn][i] = mx;
+            }
+            __syncthreads();
+            const int start = (p.epi == EPI_QKV_MLP) ? p.n_split : 0;
+            uint8_t* bsp = p.c2_bs + (size_t)(((n0 - start) >> 1) >> 7) * p.c2_bs_ld + ((m0 + wm * WROWS) >> 4);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int e = fp8_block_exp(fmaxf(bsred[wm][0][i], bsred[wm][1][i]));
+                bs_mult[i] = ldexpf(1.0f, e);
+                if (wn == 0 && lane == 0 && m0 + wm * WROWS + i * 16 < p.M) bsp[i] = (uint8_t)(127 - e);
+            }
+        }
+    }
     for_seq([&](auto hc) GS_INLINE {
         constexpr int h = decltype(hc)::value;
-        (void)acc;
+        (void)acc; (void)bs_mult;
         const int wnv = wn * 2 + h;               // the 64-column group of this half
         const int col_base = n0 + wnv * 64 + fq * 4;
         if (epi == EPI_F32) {
@@ -869,6 +901,22 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
             const int hbase = ((n0 + wnv * 64 - start) >> 1) + fq * 4;
             const int hidden = (p.N - start) >> 1;
             const bool vec_ok = (p.ldc2 & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 7) == 0;
+            if (q8_out) {   // 8 consecutive hidden bytes per lane after the same lane exchange (the launcher guarantees full tiles)
+                const int wh = ((n0 + wnv * 64 - start) >> 1) + (fq & 1) * 16 + (fq >> 1) * 8;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int row = row_base + i * 16;
+                    float ox[4], oy[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ox[r] = silu_f(accv(i, 4 * h + 0)[r]) * accv(i, 4 * h + 2)[r] * bs_mult[i];
+                        oy[r] = silu_f(accv(i, 4 * h + 1)[r]) * accv(i, 4 * h + 3)[r] * bs_mult[i];
+                    }
+                    uint32_t e0 = pack_fp8x4(ox[0], ox[1], ox[2], ox[3]), e1 = pack_fp8x4(oy[0], oy[1], oy[2], oy[3]);
+                    s_swap16(e0, e1);
+                    if (row < p.M) *reinterpret_cast<uint2*>(p.c2_q8 + (size_t)row * p.c2_q8_ld + wh) = make_uint2(e0, e1);
+                }
+            } else
             if ((batch.flags & 1) && (p.ldc2 & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && n0 + TN <= p.N) {
                 const int wh = ((n0 + wnv * 64 - start) >> 1) + (fq & 1) * 16 + (fq >> 1) * 8;
 #pragma unroll

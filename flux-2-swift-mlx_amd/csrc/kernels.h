@@ -48,6 +48,14 @@ struct GemmProblem {
     // attention output) or by launch_quantize_blocks_fp8.  a_bscale 4-byte aligned, a_bscale_ld % 4 == 0 and >= ceil(M / 16) + 12.
     const uint8_t* a_bscale;
     int a_bscale_ld;
+    // fp8, gemm256s, EPI_SWIGLU / EPI_QKV_MLP: the SwiGLU hidden leaves in that block-scaled form (the A operand of mlp_out / linear2)
+    // instead of bf16 C2: bytes c2_q8[row * c2_q8_ld + h], scale bytes c2_bs[(h / 128) * c2_bs_ld + row / 16] (row, h: this problem's
+    // row and hidden column; a tile's 128 hidden columns x 16 rows are one block).  N - n_split % 256 == 0, c2_q8 8-byte aligned,
+    // c2_q8_ld % 8 == 0.  nullptr = bf16 C2.
+    uint8_t* c2_q8;
+    int c2_q8_ld;
+    uint8_t* c2_bs;
+    int c2_bs_ld;
     // 256x256 kernel, EPI_BF16 columns [0, qk_cols) (= q | k of a fused qkv projection, qk_cols = 2*dim, dim % 256 == 0):
     // per-head RMSNorm (eps 1e-6, weights qk_qw / qk_kw bf16 [128]) + RoPE applied to the f32 accumulators before
     // the store — what launch_qk_norm_rope_vt does in a separate pass over the stored bf16 values; q additionally

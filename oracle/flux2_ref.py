@@ -297,6 +297,9 @@ def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
 # MI355X path uses OCP e4m3 for weights (scale per output channel) AND activations (scale per
 # token) of the block GEMMs; this emulates exactly that so the fp8 parity test has a checker.
 _FP8_BLOCK_GEMMS = False
+# plain forwards of an fp8 model whose text length is a multiple of 64 (dit.cpp, `bsa`): the activations of proj / mlp_out / linear2 are
+# quantised in 16-row x 128-column blocks with power-of-two scales, straight from the producing epilogue's f32 values (set by dit_forward)
+_FP8_ACT_BLOCKS = False
 E4M3_MAX = 448.0
 
 
@@ -363,11 +366,14 @@ def fp8_qk(q: Tensor, k: Tensor, wq_max: float, wk_max: float) -> Tuple[Tensor, 
     return rq(q * c, qe) / c, rq(k, ke)
 
 
-def block_linear(x: Tensor, w: Tensor) -> Tensor:
+def block_linear(x: Tensor, w: Tensor, blocks: bool = False) -> Tensor:
     """A block GEMM.  In fp8 mode the activation is first rounded to bf16 (what the producing
-    kernel stores) and both operands are fake-quantised row-wise."""
+    kernel stores) and both operands are fake-quantised row-wise; `blocks` (proj / mlp_out / linear2 of a plain forward, see
+    _FP8_ACT_BLOCKS): the activation in 16 x 128 blocks instead, from the f32 values."""
     if not _FP8_BLOCK_GEMMS:
         return linear(x, w)
+    if blocks and _FP8_ACT_BLOCKS:
+        return F.linear(fake_quant_e4m3_blocks(x), fake_quant_e4m3_rows(w.float()))
     xq = fake_quant_e4m3_rows(x.to(torch.bfloat16).float())
     wq = fake_quant_e4m3_rows(w.float())
     return F.linear(xq, wq)
@@ -439,7 +445,7 @@ def swiglu_ff(x: Tensor, w_in: Tensor, w_out: Tensor) -> Tensor:
     """a15 — Flux2FeedForward.swift:42-109: gate = first half, value = second half."""
     p = block_linear(x, w_in)
     gate, value = p.chunk(2, dim=-1)
-    return block_linear(F.silu(gate) * value, w_out)
+    return block_linear(F.silu(gate) * value, w_out, blocks=True)
 
 
 def double_block(P: Dict[str, Tensor], i: int, img: Tensor, txt: Tensor, H: int,
@@ -468,8 +474,8 @@ def double_block(P: Dict[str, Tensor], i: int, img: Tensor, txt: Tensor, H: int,
     wmax = lambda s_: max(float(P[pre + "img_attn.norm." + s_].float().abs().max()), float(P[pre + "txt_attn.norm." + s_].float().abs().max()))
     q, k = fp8_qk(q, k, wmax("query_norm.scale"), wmax("key_norm.scale"))
     o = _unheads(sdpa(q, k, v))
-    txt_attn = block_linear(o[:, :S_txt], P[pre + "txt_attn.proj.weight"])
-    img_attn = block_linear(o[:, S_txt:], P[pre + "img_attn.proj.weight"])
+    txt_attn = block_linear(o[:, :S_txt], P[pre + "txt_attn.proj.weight"], blocks=True)
+    img_attn = block_linear(o[:, S_txt:], P[pre + "img_attn.proj.weight"], blocks=True)
     img = img + img_attn * img_mod[0][2].unsqueeze(1)
     txt = txt + txt_attn * txt_mod[0][2].unsqueeze(1)
 
@@ -494,7 +500,7 @@ def single_block(P: Dict[str, Tensor], i: int, hs: Tensor, H: int, cos: Tensor, 
     k = apply_rope(rms_norm(k, P[pre + "norm.key_norm.scale"]), cos, sin)
     q, k = fp8_qk(q, k, float(P[pre + "norm.query_norm.scale"].float().abs().max()), float(P[pre + "norm.key_norm.scale"].float().abs().max()))
     attn = _unheads(sdpa(q, k, v))
-    out = block_linear(torch.cat([attn, F.silu(gate) * up], dim=-1), P[pre + "linear2.weight"])
+    out = block_linear(torch.cat([attn, F.silu(gate) * up], dim=-1), P[pre + "linear2.weight"], blocks=True)
     return hs + out * mod[0][2].unsqueeze(1)
 
 
@@ -505,6 +511,8 @@ def dit_forward(P: Dict[str, Tensor], cfg: dict, lat: Tensor, txt_emb: Tensor, t
     lat [B,S_img,128], txt_emb [B,S_txt,J], t [B] in [0,1], g [B] or None.
     `taps`, if given, receives intermediate tensors (test aid)."""
     H = cfg["heads"]
+    global _FP8_ACT_BLOCKS
+    _FP8_ACT_BLOCKS = _FP8_BLOCK_GEMMS and txt_emb.shape[1] % 64 == 0 and cfg["dim"] % 128 == 0
     img = linear(lat.float(), P["img_in.weight"])
     txt = linear(txt_emb.float(), P["txt_in.weight"])
     temb = time_guidance_embed(P, t.float() * 1000.0, None if g is None else g.float() * 1000.0)
@@ -561,6 +569,8 @@ def dit_forward_kv(P: Dict[str, Tensor], cfg: dict, lat: Tensor, txt_emb: Tensor
     layers = double blocks then single blocks."""
     extract = ref_lat is not None
     assert extract != (cache is not None)
+    global _FP8_ACT_BLOCKS
+    _FP8_ACT_BLOCKS = False     # the KV passes keep the row-wise activations (dit.cpp: bsa needs a plain forward)
     H, d = cfg["heads"], cfg["dim"]
     S_txt, S_out = txt_emb.shape[1], lat.shape[1]
     img = linear(lat.float(), P["img_in.weight"])
