@@ -32,6 +32,14 @@ __device__ __forceinline__ int fp8_block_exp(float amax) {
     return e < -60 ? -60 : (e > 60 ? 60 : e);
 }
 
+// OCP e4m3 pack of 4 floats the caller knows to lie inside +-448 (block-scaled values: the block exponent guarantees it)
+__device__ __forceinline__ uint32_t pack_fp8x4_inrange(float a, float b, float c, float d) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+}
+
 // OCP e4m3 pack of 4 floats (already divided by the scale); clamped to +-448 (the cast has no saturation)
 __device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
     a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);

@@ -187,7 +187,11 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     constexpr int PARTA = WIDE ? 4 * PART / 2 : PART;          // bytes of the A rows of a stage (512 or 256 rows x 128 B)
     constexpr int STG = WIDE ? PARTA + PART / 2 : STAGE;       // A rows + W rows (128 or 256 rows)
     constexpr int TN = WIDE ? 128 : 256;
-    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STG];  // 128 KB (WIDE: 160 KB), the only LDS object
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STG];  // 128 KB (WIDE: 160 KB), the only LDS object of the K loop
+    __shared__ unsigned bsred[2][8];   // fp8 SwiGLU epilogue (GemmProblem::c2_q8): block maxima [wave row][MFMA row block], as float bits
+    if constexpr (FP8 && !CONV) {
+        if (threadIdx.x < 16) (&bsred[0][0])[threadIdx.x] = 0u;   // visible behind the prologue's barrier
+    }
     using S = std::conditional_t<FP8, SchedF<NI>, Sched<NI, WIDE>>;
     constexpr int ES = FP8 ? 1 : 2;   // bytes per operand element: the byte geometry of a tile is the same (128-byte rows)
     constexpr int BMT = WIDE ? 512 : 32 * NI, WROWS = WIDE ? 128 : 16 * NI;
@@ -755,12 +759,13 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
         return;
     }
     // ---- SwiGLU hidden as block-scaled e4m3 (GemmProblem::c2_q8): a tile's 128 hidden columns x the 16 rows of an MFMA row block are
-    // one block.  First pass: the block maxima (the lane's 16 values per row block, the wave by lane exchange, the two waves of a row
-    // through LDS), exponents, scale bytes; the stores below then recompute the values and write bytes.
+    // one block.  First pass: a bound of the block maxima — |silu(g) u| <= |g u|, no transcendental (evaluating SiLU twice cost 23 us
+    // per linear1 launch); the bound is tight where the maximum sits (large positive gates) and a power-of-two scale that is one step
+    // low changes no e4m3 value above the subnormals — (the lane's 16 products per row block, the wave by lane exchange, the two waves
+    // of a row through LDS), exponents, scale bytes; the stores below compute the values and write bytes.
     float bs_mult[NI];
     const bool q8_out = FP8 && !CONV && epi == EPI_SWIGLU && p.c2_q8 != nullptr;
     if constexpr (FP8 && !CONV) {
-        __shared__ float bsred[2][2][8];
         if (q8_out) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -770,17 +775,17 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(silu_f(accv(i, 4 * hh + jj)[r]) * accv(i, 4 * hh + jj + 2)[r]));
-#pragma unroll
-                for (int sft = 1; sft < 64; sft <<= 1) mx = fmaxf(mx, __shfl_xor(mx, sft));
-                if (lane == 0) bsred[wm][wn][i] = mx;
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(accv(i, 4 * hh + jj)[r] * accv(i, 4 * hh + jj + 2)[r]));
+                // both waves of the row, all lanes: one LDS maximum per row block (non-negative floats order like their bit patterns;
+                // a chain of six lane exchanges per row block cost 3 us per tile)
+                atomicMax(&bsred[wm][i], __float_as_uint(mx));
             }
             __syncthreads();
             const int start = (p.epi == EPI_QKV_MLP) ? p.n_split : 0;
             uint8_t* bsp = p.c2_bs + (size_t)(((n0 - start) >> 1) >> 7) * p.c2_bs_ld + ((m0 + wm * WROWS) >> 4);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int e = fp8_block_exp(fmaxf(bsred[wm][0][i], bsred[wm][1][i]));
+                const int e = fp8_block_exp(__uint_as_float(bsred[wm][i]));
                 bs_mult[i] = ldexpf(1.0f, e);
                 if (wn == 0 && lane == 0 && m0 + wm * WROWS + i * 16 < p.M) bsp[i] = (uint8_t)(127 - e);
             }
@@ -912,7 +917,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                         ox[r] = silu_f(accv(i, 4 * h + 0)[r]) * accv(i, 4 * h + 2)[r] * bs_mult[i];
                         oy[r] = silu_f(accv(i, 4 * h + 1)[r]) * accv(i, 4 * h + 3)[r] * bs_mult[i];
                     }
-                    uint32_t e0 = pack_fp8x4(ox[0], ox[1], ox[2], ox[3]), e1 = pack_fp8x4(oy[0], oy[1], oy[2], oy[3]);
+                    uint32_t e0 = pack_fp8x4_inrange(ox[0], ox[1], ox[2], ox[3]), e1 = pack_fp8x4_inrange(oy[0], oy[1], oy[2], oy[3]);
                     s_swap16(e0, e1);
                     if (row < p.M) *reinterpret_cast<uint2*>(p.c2_q8 + (size_t)row * p.c2_q8_ld + wh) = make_uint2(e0, e1);
                 }

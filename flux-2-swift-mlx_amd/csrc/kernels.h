@@ -50,8 +50,8 @@ struct GemmProblem {
     int a_bscale_ld;
     // fp8, gemm256s, EPI_SWIGLU / EPI_QKV_MLP: the SwiGLU hidden leaves in that block-scaled form (the A operand of mlp_out / linear2)
     // instead of bf16 C2: bytes c2_q8[row * c2_q8_ld + h], scale bytes c2_bs[(h / 128) * c2_bs_ld + row / 16] (row, h: this problem's
-    // row and hidden column; a tile's 128 hidden columns x 16 rows are one block).  N - n_split % 256 == 0, c2_q8 8-byte aligned,
-    // c2_q8_ld % 8 == 0.  nullptr = bf16 C2.
+    // row and hidden column; a tile's 128 hidden columns x 16 rows are one block, its exponent taken from max |gate x value| >= the
+    // block's maximum).  N - n_split % 256 == 0, c2_q8 8-byte aligned, c2_q8_ld % 8 == 0.  nullptr = bf16 C2.
     uint8_t* c2_q8;
     int c2_q8_ld;
     uint8_t* c2_bs;

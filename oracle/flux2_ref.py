@@ -333,15 +333,17 @@ def fp8_block_exponents(amax: Tensor) -> Tensor:
     return torch.where(amax > 0, e, torch.full_like(e, 60))
 
 
-def fake_quant_e4m3_blocks(x: Tensor) -> Tensor:
+def fake_quant_e4m3_blocks(x: Tensor, mag: Optional[Tensor] = None) -> Tensor:
     """Block quantisation of an activation [..., S, K] to OCP e4m3 (the MI355X path's GemmProblem::a_bscale — NOT a restatement of the
     reference): blocks of 16 consecutive rows x 128 consecutive columns share one power-of-two scale 2^-e (fp8_block_exponents of the
-    block's absolute maximum); rows beyond S count as zeros.  Returns the de-quantised f32 values."""
+    block's absolute maximum, or of the maximum of `mag` >= |x| where the producer bounds it instead: the SwiGLU epilogue takes
+    |gate x value|); rows beyond S count as zeros.  Returns the de-quantised f32 values."""
     xf = x.float()
     S, K = xf.shape[-2], xf.shape[-1]
     Sp = (S + 15) // 16 * 16
-    xp = F.pad(xf, (0, 0, 0, Sp - S)).reshape(*xf.shape[:-2], Sp // 16, 16, K // 128, 128)
-    amax = xp.abs().amax(dim=(-3, -1), keepdim=True)
+    blk = lambda t: F.pad(t, (0, 0, 0, Sp - S)).reshape(*xf.shape[:-2], Sp // 16, 16, K // 128, 128)
+    xp = blk(xf)
+    amax = (xp if mag is None else blk(mag.float())).abs().amax(dim=(-3, -1), keepdim=True)
     mult = torch.exp2(fp8_block_exponents(amax).float())
     q = (xp * mult).clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).float() / mult
     return q.reshape(*xf.shape[:-2], Sp, K)[..., :S, :]
@@ -366,14 +368,14 @@ def fp8_qk(q: Tensor, k: Tensor, wq_max: float, wk_max: float) -> Tuple[Tensor, 
     return rq(q * c, qe) / c, rq(k, ke)
 
 
-def block_linear(x: Tensor, w: Tensor, blocks: bool = False) -> Tensor:
+def block_linear(x: Tensor, w: Tensor, blocks: bool = False, mag: Optional[Tensor] = None) -> Tensor:
     """A block GEMM.  In fp8 mode the activation is first rounded to bf16 (what the producing
     kernel stores) and both operands are fake-quantised row-wise; `blocks` (proj / mlp_out / linear2 of a plain forward, see
     _FP8_ACT_BLOCKS): the activation in 16 x 128 blocks instead, from the f32 values."""
     if not _FP8_BLOCK_GEMMS:
         return linear(x, w)
     if blocks and _FP8_ACT_BLOCKS:
-        return F.linear(fake_quant_e4m3_blocks(x), fake_quant_e4m3_rows(w.float()))
+        return F.linear(fake_quant_e4m3_blocks(x, mag), fake_quant_e4m3_rows(w.float()))
     xq = fake_quant_e4m3_rows(x.to(torch.bfloat16).float())
     wq = fake_quant_e4m3_rows(w.float())
     return F.linear(xq, wq)
@@ -445,7 +447,7 @@ def swiglu_ff(x: Tensor, w_in: Tensor, w_out: Tensor) -> Tensor:
     """a15 — Flux2FeedForward.swift:42-109: gate = first half, value = second half."""
     p = block_linear(x, w_in)
     gate, value = p.chunk(2, dim=-1)
-    return block_linear(F.silu(gate) * value, w_out, blocks=True)
+    return block_linear(F.silu(gate) * value, w_out, blocks=True, mag=gate * value)
 
 
 def double_block(P: Dict[str, Tensor], i: int, img: Tensor, txt: Tensor, H: int,
@@ -500,7 +502,7 @@ def single_block(P: Dict[str, Tensor], i: int, hs: Tensor, H: int, cos: Tensor, 
     k = apply_rope(rms_norm(k, P[pre + "norm.key_norm.scale"]), cos, sin)
     q, k = fp8_qk(q, k, float(P[pre + "norm.query_norm.scale"].float().abs().max()), float(P[pre + "norm.key_norm.scale"].float().abs().max()))
     attn = _unheads(sdpa(q, k, v))
-    out = block_linear(torch.cat([attn, F.silu(gate) * up], dim=-1), P[pre + "linear2.weight"], blocks=True)
+    out = block_linear(torch.cat([attn, F.silu(gate) * up], dim=-1), P[pre + "linear2.weight"], blocks=True, mag=torch.cat([attn, gate * up], dim=-1))
     return hs + out * mod[0][2].unsqueeze(1)
 
 
