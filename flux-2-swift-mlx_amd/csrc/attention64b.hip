@@ -32,6 +32,9 @@
 namespace {
 
 constexpr int HD = 128, BKV = 64;
+// QK8: the output as block-scaled e4m3 instead of bf16 (the A operand of the fp8 models' proj / linear2): bytes q8[row * ld + head * 128 + d],
+// scale bytes bs[head * bs_ld + row / 16] (one per 16 queries x this head's 128 columns); q8 = nullptr: the bf16 output
+struct AttnBlocksOut { uint8_t* q8; int ld; uint8_t* bs; int bs_ld; };
 constexpr int KT = BKV * HD * 2;     // 16 KB
 constexpr int VT = HD * BKV * 2;     // 16 KB
 constexpr int VRING = 3 * KT;        // LDS: K ring (3 slots), then V ring (3 slots) = 96 KB
@@ -77,8 +80,9 @@ static_assert(x1_gap(31) == T + 24 && c1_gap(15) == T + 31 && vr_gap(15) == 135 
 template <bool DOFF, bool QK8 = false>
 __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, int ldqk,
                                                          const uint16_t* __restrict__ vt, int s_pad, uint16_t* __restrict__ out,
-                                                         int ldo, int Sq, int S, unsigned long long* trace, int qk8_exps) {
+                                                         int ldo, int Sq, int S, unsigned long long* trace, int qk8_exps, AttnBlocksOut bo) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[3 * KT + 3 * VT];
+    __shared__ unsigned bo_max[4][4];     // AttnBlocksOut: block maxima [wave][query block], as float bits
     __shared__ int s_again;               // DOFF: some wave of the workgroup asks for another pass
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int c16 = lane & 15, g4 = lane >> 4;
@@ -509,6 +513,39 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
     }
 
     // ---- normalise and store.  o[db][qb][r]: d = db*16 + 4 g4 + r, query = q0 + qb*16 + c16; lacc[qb][*] = the row sum of that query
+    if (QK8 && bo.q8 != nullptr) {
+        // fp8 models: O as block-scaled e4m3 (kernels.h, GemmProblem::a_bscale) — the 16 queries of a query block x this head's 128
+        // columns are one block: maximum over the wave (an LDS maximum per query block: own entries, the wave's LDS operations are
+        // ordered), exact power-of-two exponent, bytes + one scale byte; no bf16 copy, no quantisation pass in front of proj / linear2.
+        if (lane < 4) bo_max[wid][lane] = 0u;
+        float inv4[4];
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            inv4[qb] = 1.0f / lacc[qb][0];
+            float mx = 0.f;
+#pragma unroll
+            for (int db = 0; db < 8; ++db)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(o[db][qb][r] * inv4[qb]));
+            atomicMax(&bo_max[wid][qb], __float_as_uint(mx));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            const int e = fp8_block_exp(__uint_as_float(bo_max[wid][qb]));
+            const float mult = ldexpf(1.0f, e) * inv4[qb];
+            const int qrow = q0 + qb * 16 + c16;
+            if (lane == 0 && q0 + qb * 16 < Sq) bo.bs[(size_t)head * bo.bs_ld + ((q0 + qb * 16) >> 4)] = (uint8_t)(127 - e);
+            if (qrow < Sq) {
+                uint8_t* op = bo.q8 + (size_t)qrow * bo.ld + head * HD + g4 * 4;
+#pragma unroll
+                for (int db = 0; db < 8; ++db)
+                    *reinterpret_cast<uint32_t*>(op + db * 16) =
+                        pack_fp8x4_inrange(o[db][qb][0] * mult, o[db][qb][1] * mult, o[db][qb][2] * mult, o[db][qb][3] * mult);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) {
         const float inv = 1.0f / lacc[qb][0];
@@ -544,13 +581,15 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
 #define A64B_CAT(a, b, c) A64B_CAT2(a, b, c)
 #define A64B_VARIANT A64B_CAT(launch_attention64b_v, ATTN64B_DOFF, ATTN64B_QK8)
 // q, k: bf16 rows of ldqk elements, or (QK8) e4m3 rows of ldqk bytes with qk8_exps = (127 - qe) | (127 - ke) << 8 (q8 = q 2^qe, k8 = k 2^ke)
-int launch_attention64b_v00(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int);
-int launch_attention64b_v10(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int);
-int launch_attention64b_v01(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int);
-int launch_attention64b_v11(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int);
+int launch_attention64b_v00(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int, uint8_t*, int, uint8_t*, int);
+int launch_attention64b_v10(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int, uint8_t*, int, uint8_t*, int);
+int launch_attention64b_v01(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int, uint8_t*, int, uint8_t*, int);
+int launch_attention64b_v11(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int, uint8_t*, int, uint8_t*, int);
 
 int A64B_VARIANT(hipStream_t stream, const void* q, const void* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out, int ldo, int Sq, int S,
-                 int heads, int qk8_exps) {
+                 int heads, int qk8_exps, uint8_t* out8, int ld8o, uint8_t* bs, int bs_ld) {
+    if (out8 && (!ATTN64B_QK8 || !bs || (ld8o & 3) || (reinterpret_cast<uintptr_t>(out8) & 3) || bs_ld < (Sq + 15) / 16)) return 1;
+    const AttnBlocksOut bo{out8, ld8o, bs, bs_ld};
     if (S < 1 || Sq <= 0 || s_pad < ((S + BKV - 1) / BKV) * BKV) return 1;
     const unsigned long long esz = ATTN64B_QK8 ? 1 : 2;
     if ((unsigned long long)S * (unsigned long long)ldqk * esz >= (1ull << 31) || (unsigned long long)HD * (unsigned long long)s_pad * 2 >= (1ull << 31)) return 1;
@@ -562,7 +601,7 @@ int A64B_VARIANT(hipStream_t stream, const void* q, const void* k, int ldqk, con
     const size_t tn = (size_t)grid.x * grid.y * 4 * 2;
     if (trace_env && ++seen % 8 == 0 && hipMalloc((void**)&trace, tn * 8) != hipSuccess) trace = nullptr;
     hipLaunchKernelGGL((attn64b_kernel<(ATTN64B_DOFF != 0), (ATTN64B_QK8 != 0)>), grid, block, 0, stream, reinterpret_cast<const uint16_t*>(q),
-                       reinterpret_cast<const uint16_t*>(k), ldqk, vt, s_pad, out, ldo, Sq, S, trace, qk8_exps);
+                       reinterpret_cast<const uint16_t*>(k), ldqk, vt, s_pad, out, ldo, Sq, S, trace, qk8_exps, bo);
     if (trace) {
         std::vector<unsigned long long> h(tn);
         (void)hipStreamSynchronize(stream);
@@ -580,14 +619,14 @@ int A64B_VARIANT(hipStream_t stream, const void* q, const void* k, int ldqk, con
 #if !ATTN64B_DOFF && !ATTN64B_QK8
 int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
                         int ldo, int Sq, int S, int heads, bool data_offset) {
-    return data_offset ? launch_attention64b_v10(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads, 0)
-                       : launch_attention64b_v00(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads, 0);
+    return data_offset ? launch_attention64b_v10(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads, 0, nullptr, 0, nullptr, 0)
+                       : launch_attention64b_v00(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads, 0, nullptr, 0, nullptr, 0);
 }
 int launch_attention64b_qk8(hipStream_t stream, const uint8_t* q8, const uint8_t* k8, int ld8, int q_exp, int k_exp, const uint16_t* vt, int s_pad,
-                            uint16_t* out, int ldo, int Sq, int S, int heads, bool data_offset) {
+                            uint16_t* out, int ldo, int Sq, int S, int heads, bool data_offset, uint8_t* out8, int ld8o, uint8_t* bs, int bs_ld) {
     if (q_exp < -60 || q_exp > 60 || k_exp < -60 || k_exp > 60) return 1;   // negative: operands larger than e4m3's 448 were scaled DOWN
     const int exps = (127 - q_exp) | ((127 - k_exp) << 8);
-    return data_offset ? launch_attention64b_v11(stream, q8, k8, ld8, vt, s_pad, out, ldo, Sq, S, heads, exps)
-                       : launch_attention64b_v01(stream, q8, k8, ld8, vt, s_pad, out, ldo, Sq, S, heads, exps);
+    return data_offset ? launch_attention64b_v11(stream, q8, k8, ld8, vt, s_pad, out, ldo, Sq, S, heads, exps, out8, ld8o, bs, bs_ld)
+                       : launch_attention64b_v01(stream, q8, k8, ld8, vt, s_pad, out, ldo, Sq, S, heads, exps, out8, ld8o, bs, bs_ld);
 }
 #endif

@@ -960,13 +960,15 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         return e ? atoi(e) != 0 : true;
     }();
     const bool qk8 = f8 && qk8_on && q_pre && mode == FWD_PLAIN;
+    const bool attn_blocks = bsa && bsa_fused && qk8;   // the attention writes its output as block-scaled e4m3 itself
     uint8_t* qk8_buf = qk8 ? m->qk8.as<uint8_t>() : nullptr;
     auto attend = [&](int layer, uint16_t* o_buf, int ldo, float score_bound, int q8_exp, int k8_exp) -> int {
         if (m->attn_softmax_mode == 1) score_bound = 0.f;   // no bound given: launch_attention takes the data-offset form
         if (qk8) {
             prof_before(m->ctx, PROF_ATTENTION);
+            // (bsa: the output straight into proj's / linear2's block-scaled operand, row pitch ldo bytes, K-tiles 0 .. d / 128 - 1)
             const int ar = launch_attention64b_qk8(st, qk8_buf, qk8_buf + d, 2 * d, q8_exp, k8_exp, vt, s_pad, o_buf, ldo, S, S, H,
-                                                   !attention_uses_fixed_offset(score_bound, true));
+                                                   !attention_uses_fixed_offset(score_bound, true), attn_blocks ? xq2 : nullptr, ldo, xbs, bs_ld);
             prof_after(m->ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
             F2_LAUNCH(ar, "attention(e4m3 QK)");
             return FLUX2MI_OK;
@@ -1049,8 +1051,8 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, s_txt, w.qn[0], w.kn[0], w.qn[1], w.kn[1], cos_tab, sin_tab,
                                          vt, s_pad, q_mul, qk8_buf, w.q8_exp, w.k8_exp), "qk_norm_rope");
         F2_TRY(attend(i, comb, d, w.score_bound, w.q8_exp, w.k8_exp));
-        if (bsa) F2_LAUNCH(quant_attn_blocks(d), "quantize(attn out, blocks)");
-        else F2_LAUNCH(quant(comb, d, d), "quantize(attn out)");
+        if (bsa && !attn_blocks) F2_LAUNCH(quant_attn_blocks(d), "quantize(attn out, blocks)");
+        else if (!bsa) F2_LAUNCH(quant(comb, d, d), "quantize(attn out)");
         {
             GemmProblem p[2];
             p[0] = blk(comb, d, 0, w.proj[0], hs, d, s_txt, d, d, EPI_GATE_RESID);
@@ -1134,7 +1136,8 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
                                          w.k8_exp), "qk_norm_rope");
         F2_TRY(attend(m->cfg.n_double + i, comb, 4 * d, w.score_bound, w.q8_exp, w.k8_exp));
         if (bsa && !bsa_fused) F2_LAUNCH(launch_quantize_blocks_fp8(st, comb, 4 * d, xq2, 4 * d, xbs, bs_ld, S, 4 * d), "quantize(attn | ff hidden, blocks)");
-        else if (bsa) F2_LAUNCH(quant_attn_blocks(4 * d), "quantize(attn out, blocks)");   // the hidden columns are in place already
+        else if (bsa && !attn_blocks) F2_LAUNCH(quant_attn_blocks(4 * d), "quantize(attn out, blocks)");   // the hidden columns are in place already
+        else if (bsa) {}
         else F2_LAUNCH(quant(comb, 4 * d, 4 * d), "quantize(attn | ff hidden)");
         {
             GemmProblem p[2];

@@ -141,8 +141,11 @@ static inline int attn_s_pad(int S) { return ((S + 63) / 64) * 64; }
 // q8 = q 2^q_exp with q pre-scaled as above, k8 = k 2^k_exp (written by launch_qk_norm_rope_vt); S^T = K Q^T is one block-scaled
 // v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 block, the scales undone by its e8m0 operands; P, V, O stay bf16 / f32.
 // data_offset as launch_attention's softmax forms.  1 = not this kernel's case.
+// out8 != nullptr: O leaves as block-scaled e4m3 instead of bf16 (GemmProblem::a_bscale of the consuming proj / linear2): bytes
+// out8[row * ld8o + head * 128 + d], scale bytes bs[head * bs_ld + row / 16] (16 queries x one head's 128 columns per block); `out` unused.
 int launch_attention64b_qk8(hipStream_t stream, const uint8_t* q8, const uint8_t* k8, int ld8, int q_exp, int k_exp, const uint16_t* vt, int s_pad,
-                            uint16_t* out, int ldo, int Sq, int S, int heads, bool data_offset);
+                            uint16_t* out, int ldo, int Sq, int S, int heads, bool data_offset, uint8_t* out8 = nullptr, int ld8o = 0,
+                            uint8_t* bs = nullptr, int bs_ld = 0);
 
 // ---------------------------------------------------------------- norms / rope (norm.hip)
 // y bf16[row,:] = LN(x f32[row,:]) * (1 + scale) + shift ; rows < split use (shift0, scale0),
