@@ -527,7 +527,8 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
             for (int db = 0; db < 8; ++db)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(o[db][qb][r] * inv4[qb]));
-            atomicMax(&bo_max[wid][qb], __float_as_uint(mx));
+            mx = row16_max_nonneg(mx);
+            if ((lane & 15) == 15) atomicMax(&bo_max[wid][qb], __float_as_uint(mx));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll

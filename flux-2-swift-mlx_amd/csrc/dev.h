@@ -32,6 +32,15 @@ __device__ __forceinline__ int fp8_block_exp(float amax) {
     return e < -60 ? -60 : (e > 60 ? 60 : e);
 }
 
+// Maximum of a non-negative value over the 16 lanes of a DPP row; valid in lane 15 of the row (row_shr 1, 2, 4, 8 with zero fill)
+__device__ __forceinline__ float row16_max_nonneg(float v) {
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true)));
+    return v;
+}
+
 // OCP e4m3 pack of 4 floats the caller knows to lie inside +-448 (block-scaled values: the block exponent guarantees it)
 __device__ __forceinline__ uint32_t pack_fp8x4_inrange(float a, float b, float c, float d) {
     int w = 0;

@@ -778,7 +778,8 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(accv(i, 4 * hh + jj)[r] * accv(i, 4 * hh + jj + 2)[r]));
                 // both waves of the row, all lanes: one LDS maximum per row block (non-negative floats order like their bit patterns;
                 // a chain of six lane exchanges per row block cost 3 us per tile)
-                atomicMax(&bsred[wm][i], __float_as_uint(mx));
+                mx = row16_max_nonneg(mx);   // 4 lanes per wave go to the LDS instead of 64
+                if ((lane & 15) == 15) atomicMax(&bsred[wm][i], __float_as_uint(mx));
             }
             __syncthreads();
             const int start = (p.epi == EPI_QKV_MLP) ? p.n_split : 0;
