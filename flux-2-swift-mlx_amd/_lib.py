@@ -184,6 +184,7 @@ PROTOTYPES = {
     "flux2mi_op_gemm_bf16_out_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I]),
     "flux2mi_op_gemm_fp8": (_I, [_P, _P, _P, _P, _I, _I, _I]),
     "flux2mi_op_gemm_fp8_blocks": (_I, [_P, _P, _P, _P, _I, _I, _I]),
+    "flux2mi_op_attention_qk8_blocks": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float]),
     "flux2mi_op_gemm_gate_resid": (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
     "flux2mi_op_layernorm_modulate": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "flux2mi_op_qk_norm_rope": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _F]),

@@ -433,6 +433,22 @@ class Context:
         self._exit()
         return out
 
+    def op_attention_qk8_blocks(self, q8, k8, v, heads: int, q_exp: int, k_exp: int, score_bound_log2: float):
+        """op_attention_qk8 with the output as block-scaled e4m3: returns (bytes uint8 [S, heads*128], scale bytes uint8 [heads, ceil(S/16)]);
+        value = e4m3(byte) * 2^(scale - 127), one scale per 16 queries x one head's 128 columns."""
+        s = v.shape[0]
+        q8 = q8.view(torch.uint8).contiguous()
+        k8 = k8.view(torch.uint8).contiguous()
+        v = _req(v, torch.bfloat16, "v")
+        out8 = torch.empty((s, heads * 128), dtype=torch.uint8, device=v.device)
+        nrb = (s + 15) // 16
+        bs = torch.full((heads, nrb), 127, dtype=torch.uint8, device=v.device)
+        self._enter()
+        check(lib().flux2mi_op_attention_qk8_blocks(self.handle, _ptr(q8), _ptr(k8), _ptr(v), None, _ptr(out8), _ptr(bs), nrb, s, heads, q_exp, k_exp,
+                                                    float(score_bound_log2)))
+        self._exit()
+        return out8, bs
+
     def op_attention_prescaled_range(self, qkv: torch.Tensor, heads: int, score_bound_log2: float, q0: int, nq: int, nk: int) -> torch.Tensor:
         """Queries [q0, q0+nq) against the key prefix [0, nk) of the full V^T image (the KV-extraction pass's launch shape);
         rows outside the query range come back zero."""

@@ -1411,7 +1411,15 @@ extern "C" int flux2mi_op_attention_prescaled(flux2mi_ctx* ctx, const void* qkv_
 // [S, heads*128]; P, O as in the bf16 form (attention64b.hip, QK8).  score_bound_log2 as flux2mi_op_attention_prescaled.
 extern "C" int flux2mi_op_attention_qk8(flux2mi_ctx* ctx, const void* q8, const void* k8, const void* v, void* out, int S, int heads, int q_exp, int k_exp,
                                         float score_bound_log2) {
-    F2_REQUIRE(ctx && q8 && k8 && v && out && S > 0 && heads > 0, FLUX2MI_ERR_INVALID_ARG, "op_attention_qk8: bad argument");
+    return flux2mi_op_attention_qk8_blocks(ctx, q8, k8, v, out, nullptr, nullptr, 0, S, heads, q_exp, k_exp, score_bound_log2);
+}
+
+// The same with the output as block-scaled e4m3 (what the fp8 models' proj / linear2 consume): out8 bytes [S, heads*128], bs one e8m0 byte
+// per 16 queries x one head's 128 columns at bs[head * bs_ld + row / 16] (value = byte's power of two x the e4m3 value).  out8 = nullptr:
+// the bf16 output `out`.
+extern "C" int flux2mi_op_attention_qk8_blocks(flux2mi_ctx* ctx, const void* q8, const void* k8, const void* v, void* out, void* out8, void* bs, int bs_ld,
+                                               int S, int heads, int q_exp, int k_exp, float score_bound_log2) {
+    F2_REQUIRE(ctx && q8 && k8 && v && (out || (out8 && bs)) && S > 0 && heads > 0, FLUX2MI_ERR_INVALID_ARG, "op_attention_qk8: bad argument");
     const int d = heads * 128, s_pad = attn_s_pad(S);
     F2_TRY(ctx->scratch.reserve((size_t)heads * 128 * s_pad * 2 + 256 * 4));
     uint16_t* vt = ctx->scratch.as<uint16_t>();
@@ -1419,7 +1427,8 @@ extern "C" int flux2mi_op_attention_qk8(flux2mi_ctx* ctx, const void* q8, const 
     // v_transpose reads V at column v_col0 = 2 * heads * 128 of a [S, ldqkv] matrix: hand it the V matrix shifted back by that
     F2_LAUNCH(launch_v_transpose_only(ctx->stream, reinterpret_cast<const uint16_t*>(v) - 2 * d, d, S, heads, vt, s_pad), "v_transpose");
     const int r = launch_attention64b_qk8(ctx->stream, reinterpret_cast<const uint8_t*>(q8), reinterpret_cast<const uint8_t*>(k8), d, q_exp, k_exp, vt, s_pad,
-                                          reinterpret_cast<uint16_t*>(out), d, S, S, heads, !attention_uses_fixed_offset(score_bound_log2, true));
+                                          reinterpret_cast<uint16_t*>(out), d, S, S, heads, !attention_uses_fixed_offset(score_bound_log2, true),
+                                          reinterpret_cast<uint8_t*>(out8), d, reinterpret_cast<uint8_t*>(bs), bs_ld);
     F2_LAUNCH(r, "op_attention_qk8");
     return FLUX2MI_OK;
 }

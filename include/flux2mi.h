@@ -510,6 +510,10 @@ int flux2mi_op_attention_prescaled(flux2mi_ctx* ctx, const void* qkv, void* out,
    [S, heads*128]; softmax, P and P V as in the bf16 form.  Not a restatement of the reference (its quantised variants are weight-only). */
 int flux2mi_op_attention_qk8(flux2mi_ctx* ctx, const void* q8, const void* k8, const void* v, void* out, int S, int heads, int q_exp, int k_exp,
                              float score_bound_log2);
+/* the same with the output as block-scaled e4m3, the form proj / linear2 of an fp8 model consume: out8 bytes [S, heads*128] and one e8m0
+   scale byte per 16 queries x one head's 128 columns at bs[head * bs_ld + row / 16] (bs_ld >= ceil(S / 16)); out8 NULL: bf16 `out` */
+int flux2mi_op_attention_qk8_blocks(flux2mi_ctx* ctx, const void* q8, const void* k8, const void* v, void* out, void* out8, void* bs, int bs_ld,
+                                    int S, int heads, int q_exp, int k_exp, float score_bound_log2);
 /* the same with queries [q0, q0+nq) against the key PREFIX [0, nk) of a V^T image holding all S keys — the launch shape of the
    KV-extraction pass, whose reference queries see [text | reference] only (Flux2Attention.swift:407-425: the additive mask is a
    key-prefix limit; Flux2Transformer.swift:346-457).  Only out rows [q0, q0+nq) are written */

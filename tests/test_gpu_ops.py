@@ -699,6 +699,44 @@ def test_attention_e4m3_qk(ctx, S, heads, doff):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("S,heads", [(448, 2), (1153, 3), (4608, 2)])
+def test_attention_e4m3_qk_block_scaled_output(ctx, S, heads):
+    """The output form proj / linear2 of an fp8 model consume (attention64b.hip, AttnBlocksOut): e4m3 bytes + one power-of-two scale per
+    16 queries x one head's 128 columns.  De-quantised it is the bf16 output of the same call to e4m3 precision; every scale byte is the
+    exact exponent of its block's maximum (checked against the oracle's fp8_block_exponents on the bf16 output: equal or, where the
+    f32 maximum and its bf16 rounding straddle a power-of-two boundary, one apart); ragged last row block; bit-reproducible."""
+    import math
+    g = torch.Generator().manual_seed(S + heads)
+    d = heads * 128
+    x = torch.randn((S, 3 * d), generator=g)
+    q = x[:, :d].view(S, heads, 128); k = x[:, d:2 * d].view(S, heads, 128)
+    q = q / q.pow(2).mean(-1, keepdim=True).sqrt(); k = k / k.pow(2).mean(-1, keepdim=True).sqrt()
+    c = math.log2(math.e) / math.sqrt(128.0)
+    q8 = ((q * c).reshape(S, d) * 2.0 ** 7).clamp(-448, 448).to(torch.float8_e4m3fn)
+    k8 = (k.reshape(S, d) * 2.0 ** 4).clamp(-448, 448).to(torch.float8_e4m3fn)
+    vv = x[:, 2 * d:] * torch.exp2(torch.randint(-6, 7, (1, heads, 1), generator=g).float()).expand(S, heads, 128).reshape(S, d)   # heads of different magnitude
+    v = vv.to(torch.bfloat16)
+    bound = 1.5 * 128.0 * c
+    ref = ctx.op_attention_qk8(q8.cuda(), k8.cuda(), v.cuda(), heads, 7, 4, bound).float().cpu()
+    out8, bs = ctx.op_attention_qk8_blocks(q8.cuda(), k8.cuda(), v.cuda(), heads, 7, 4, bound)
+    out8, bs = out8.cpu(), bs.cpu()
+    scale = torch.exp2(bs.float() - 127.0)                                        # [heads, row blocks]
+    deq = out8.view(torch.float8_e4m3fn).float().view(S, heads, 128) * scale.t().repeat_interleave(16, 0)[:S].unsqueeze(-1)
+    deq = deq.reshape(S, d)
+    assert torch.isfinite(deq).all()
+    assert rel_l2(deq, ref) < 3e-2                                                # e4m3: 2^-4 relative per element, ~2.6e-2 rms
+    blk = torch.nn.functional.pad(ref, (0, 0, 0, (-S) % 16)).view(-1, 16, heads, 128)
+    e_ref = R.fp8_block_exponents(blk.abs().amax(dim=(1, 3))).t()                 # [heads, row blocks]
+    diff = (127 - bs.int()) - e_ref.int()
+    assert int(diff.abs().max()) <= 1 and float((diff != 0).float().mean()) < 0.05, (int(diff.abs().max()), float((diff != 0).float().mean()))
+    # no element saturates and the largest of a block uses the top binade
+    top = out8.view(torch.float8_e4m3fn).float().abs().view(S, heads, 128)
+    assert float(top.max()) <= 448.0
+    o2, b2 = ctx.op_attention_qk8_blocks(q8.cuda(), k8.cuda(), v.cuda(), heads, 7, 4, bound)
+    assert torch.equal(o2.cpu(), out8) and torch.equal(b2.cpu(), bs)
+
+
+@pytest.mark.gpu
 def test_attention_e4m3_qk_negative_exponent(ctx):
     """Operands larger than e4m3's 448 are scaled DOWN (k8 = k 2^-3 for keys of magnitude ~600, e.g. a checkpoint whose key-norm weights
     are large): the scale operand carries 2^+3, the scores are the same as with any other split of the powers of two."""

@@ -210,3 +210,57 @@ def test_truncating_u8_cast():
     x[0, :, 0, 3] = (200.9 / 127.5) - 1.0
     out = R.postprocess_vae_output(x)
     assert out[0, :, 0].tolist() == [0, 0, 127, 200, 255, 255]
+
+
+# ---- the fp8 emulation's block quantiser (the MI355X path's own scheme: test infrastructure for the -m gpu parity tests) ----
+def test_fp8_block_exponents_exact_at_the_boundaries():
+    """dev.h fp8_block_exp / oracle fp8_block_exponents: the largest e with amax 2^e <= 448, from the float's fields (no log2 rounding)."""
+    amax = torch.tensor([448.0, 448.0000305, 447.99997, 224.0, 0.875, 0.8750001, 3.5, 3.5000002, 1e-30, 0.0, 3e38, 5e-20])
+    e = R.fp8_block_exponents(amax).tolist()
+    assert e[:8] == [0, -1, 0, 1, 9, 8, 7, 6]
+    assert e[8] == 60 and e[9] == 60 and e[10] == -60 and e[11] == 60        # clamped to [-60, 60]; an all-zero block takes 60
+    for a, ee in zip(amax[:8].tolist(), e[:8]):
+        assert a * 2.0 ** ee <= 448.0 < a * 2.0 ** (ee + 1)
+
+
+def test_fake_quant_e4m3_blocks_properties():
+    """16 rows x 128 columns per block: blocks are independent, a block's values keep e4m3's relative precision (2^-4) whatever its
+    magnitude, an all-zero block stays zero, a partial last row block is padded with zeros, `mag` only lowers the exponent."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((1, 37, 256), generator=g)
+    x[:, :16, :128] *= 2.0 ** 20
+    x[:, 16:32, 128:] *= 2.0 ** -20
+    x[:, 32:, :128] = 0
+    q = R.fake_quant_e4m3_blocks(x)
+    assert q.shape == x.shape and torch.all(q[:, 32:, :128] == 0)
+    nz = x != 0
+    # above the subnormals of its block (2^-6 of the block's scaled range) a value is rounded to 3 mantissa bits
+    big = nz & (x.abs() > x.abs().amax() * 0)   # every non-zero value: check the bound block by block
+    for rs, cs in ((slice(0, 16), slice(0, 128)), (slice(16, 32), slice(128, 256)), (slice(0, 16), slice(128, 256)), (slice(32, 37), slice(128, 256))):
+        xb, qb = x[:, rs, cs], q[:, rs, cs]
+        top = xb.abs().amax()
+        ok = xb.abs() >= top * 2.0 ** -14
+        assert float(((qb - xb).abs()[ok] / xb.abs()[ok]).max()) <= 2.0 ** -4 + 1e-6
+    # independence: changing one block leaves the others bit-identical
+    y = x.clone()
+    y[:, :16, :128] *= 3.0
+    qy = R.fake_quant_e4m3_blocks(y)
+    assert torch.equal(qy[:, 16:], q[:, 16:]) and torch.equal(qy[:, :16, 128:], q[:, :16, 128:])
+    # a bound instead of the maximum: same values unless they fall into the subnormals
+    qm = R.fake_quant_e4m3_blocks(x, mag=x * 1.9)
+    assert float((qm - q).abs().max() / q.abs().max()) < 1e-6 or torch.allclose(qm, q, rtol=2.0 ** -3, atol=0)
+
+
+def test_fp8_emulation_uses_blocks_only_in_plain_forwards_with_aligned_text():
+    import flux2mi
+    syn = flux2mi.synthetic
+    cfg = syn.DIT_PRESETS["tiny"]
+    P = syn.make_dit_weights(cfg, seed=3, std=0.05)
+    for s_txt, expect in ((64, True), (16, False)):
+        inp = syn.make_inputs(cfg, 64, 64, s_txt=s_txt)
+        lat = R.pack_patchified_to_sequence(inp["noise"])
+        with R.fp8_block_gemms():
+            R.dit_forward(P, cfg, lat, inp["txt"].float(), torch.tensor([0.5]), None, R.image_position_ids(64, 64), R.text_position_ids(s_txt))
+            assert R._FP8_ACT_BLOCKS is expect
+    R.dit_forward(P, cfg, lat, inp["txt"].float(), torch.tensor([0.5]), None, R.image_position_ids(64, 64), R.text_position_ids(s_txt))
+    assert R._FP8_ACT_BLOCKS is False
