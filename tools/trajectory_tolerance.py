@@ -7,6 +7,8 @@ weights and inputs.  Prints per-step latent rel-L2 and the u8 image statistics a
   python tools/trajectory_tolerance.py 28 1024 --oracle-only F the oracle side alone, on any CPU (no GPU, no library): 28 forwards
                                                                at S 4608 = 28 x ~1-2 min; per-step latents + image -> F (torch.save)
   python tools/trajectory_tolerance.py 28 1024 --against F     the HIP side on a GPU box against that file
+  python tools/trajectory_tolerance.py 28 256 --fp8            weight_format 1 against the oracle running the same e4m3 emulation, and both
+                                                               against the f32 oracle (profiles/r03_i_trajectory_tolerance_fp8_256.json)
 
 The split form exists because BASELINE config B itself (1024 x 1024, S 4608) costs ~30-50 min of CPU oracle time — more than one GPU-box
 call allows; weights and inputs are seeded on the CPU in all three forms, so both sides see bit-identical bf16 parameters.
