@@ -295,7 +295,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16" if args.weights == "bf16" else "fp8 (e4m3 block GEMMs and attention Q K^T; bf16 P V, f32 residual)",
+        "dtype": "bf16" if args.weights == "bf16" else "fp8 (e4m3 block GEMMs with block-scaled activations, e4m3 attention Q K^T; bf16 P V, f32 residual)",
         "data": "synthetic",
         "config": {"workload": f"Flux.2 {args.model} {args.weights}, {H}x{W}, {T} denoise steps + {args.vae} VAE decode + "
                                f"image all-gather + D2H, 1 image per GPU per bench step (BASELINE.json configs[1])",

@@ -63,6 +63,35 @@ def test_config_c_dev_width_blocks(flux2mi, ctx):
     assert rel_l2(out1, out4) > 1e-3
 
 
+def test_dev_width_fp8_blocks(flux2mi, ctx):
+    """Dev width with e4m3 weights (not a BASELINE configuration; the widest shapes of the fp8 path): linear2's K = 24576 is 192 K-tiles
+    of block scales per row block, 48 heads of e4m3 Q K^T with block-scaled output, the guidance embedder live.  Same statements as the
+    Klein-9B-width test below."""
+    from flux2mi import synthetic as syn
+    from flux2mi.api import DiT
+    cfg = DEV_W
+    P = syn.make_dit_weights(cfg, seed=41, device="cuda")
+    inp = syn.make_inputs(cfg, 512, 512, s_txt=512)
+    lat = R.pack_patchified_to_sequence(inp["noise"])
+    ii, ti = R.image_position_ids(512, 512), R.text_position_ids(512)
+    dit = DiT(ctx, cfg, weights="fp8").load(P).finalize()
+    out8 = dit.forward(lat.cuda(), inp["txt"].cuda(), 0.6, 4.0, ii.cuda(), ti.cuda()).cpu()
+    dit.close()
+    Pc = _cpu(P)
+    del P
+    args = (Pc, cfg, lat, inp["txt"].float(), torch.tensor([0.6]), torch.tensor([4.0]), ii, ti)
+    ref32 = R.dit_forward(*args)[0]
+    with R.fp8_block_gemms():
+        ref8 = R.dit_forward(*args)[0]
+    q, e8 = rel_l2(ref8, ref32), rel_l2(out8, ref8)
+    print(f"Dev width fp8: q {q:.3e}, HIP vs emulation {e8:.3e}, HIP vs f32 oracle {rel_l2(out8, ref32):.3e}")
+    assert torch.isfinite(out8).all()
+    # e4m3 noise at this width (K 6144 ... 24576, synthetic weights): q = 9.3e-2; the HIP path sits 7.1e-2 from the emulation, the same
+    # ~3/4 of q as at the narrower widths
+    assert e8 < 0.8 * q and e8 < 8e-2, (e8, q)
+    assert 0.5 * q < rel_l2(out8, ref32) < 1.5 * q
+
+
 # ------------------------------------------------------------------------------------------------ D
 def test_config_d_klein9b_width_fp8(flux2mi, ctx):
     """Klein-9B width (d 4096, 32 heads, J 12288) with e4m3 block GEMMs, one double + one single block,
