@@ -917,8 +917,10 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     };
     // fp8 models, plain forwards: the activations of proj / mlp_out / linear2 in 16-row x 128-column e4m3 blocks with power-of-two
     // scales (kernels.h, GemmProblem::a_bscale), written by the producing epilogues instead of a row-quantise pass over bf16 copies.
-    // Row ranges start at multiples of 64 (the scale table is read by aligned scalar loads).  FLUX2MI_FP8_BLOCKS=0 (dev library): rows
-    static const int bsa_mode = [] {   // 2 (dev library): block-quantise passes in place of the fused epilogues (bisection aid)
+    // Row ranges start at multiples of 64 (the scale table is read by aligned scalar loads).  FLUX2MI_FP8_BLOCKS (dev library): 0 = the
+    // row-wise activations with their quantisation passes (A/B runs), 2 = blocks by stand-alone quantisation passes instead of the fused
+    // epilogues (bisection aid)
+    static const int bsa_mode = [] {
         const char* e = F2_DEV_ENV("FLUX2MI_FP8_BLOCKS");
         return e ? atoi(e) : 1;
     }();
@@ -934,7 +936,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         q.a_bscale = xbs + r0 / 16;
         q.a_bscale_ld = bs_ld;
     };
-    // the SwiGLU hidden of a producing GEMM: rows from r0 of xq (row pitch ld), hidden column 0 at byte column c0 = K-tile c0 / 128
+    // the SwiGLU hidden of a producing GEMM: rows from r0 of xq2 (row pitch ld), hidden column 0 at byte column c0 = K-tile c0 / 128
     auto hidden_blocks = [&](GemmProblem& q, int r0, int ld, int c0) {
         if (!bsa_fused) return;
         q.c2_q8 = xq2 + (size_t)r0 * ld + c0;
@@ -942,7 +944,8 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         q.c2_bs = xbs + (size_t)(c0 / 128) * bs_ld + r0 / 16;
         q.c2_bs_ld = bs_ld;
     };
-    // interim: the attention output (bf16 comb columns [0, d), row pitch ld) into blocks by its own pass
+    // the attention output (bf16 comb columns [0, d), row pitch ld) into blocks by its own pass: where the attention kernel does not write
+    // them itself (e4m3 Q K^T switched off in the dev library)
     auto quant_attn_blocks = [&](int ld) { return launch_quantize_blocks_fp8(st, comb, ld, xq2, ld, xbs, bs_ld, S, d); };
     // joint attention per query range; keys = all S rows except for the reference queries of the
     // extraction pass, which see [txt | ref] only.  Also moves the reference K / V^T to / from the cache.
@@ -1135,10 +1138,10 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         F2_LAUNCH(launch_qk_norm_rope_vt(st, qkv, 3 * d, S, H, 0, w.qn, w.kn, w.qn, w.kn, cos_tab, sin_tab, vt, s_pad, q_mul, qk8_buf, w.q8_exp,
                                          w.k8_exp), "qk_norm_rope");
         F2_TRY(attend(m->cfg.n_double + i, comb, 4 * d, w.score_bound, w.q8_exp, w.k8_exp));
-        if (bsa && !bsa_fused) F2_LAUNCH(launch_quantize_blocks_fp8(st, comb, 4 * d, xq2, 4 * d, xbs, bs_ld, S, 4 * d), "quantize(attn | ff hidden, blocks)");
-        else if (bsa && !attn_blocks) F2_LAUNCH(quant_attn_blocks(4 * d), "quantize(attn out, blocks)");   // the hidden columns are in place already
-        else if (bsa) {}
-        else F2_LAUNCH(quant(comb, 4 * d, 4 * d), "quantize(attn | ff hidden)");
+        // linear2's operand: nothing to do when both producers wrote block-scaled e4m3 themselves
+        if (!bsa) F2_LAUNCH(quant(comb, 4 * d, 4 * d), "quantize(attn | ff hidden)");
+        else if (!bsa_fused) F2_LAUNCH(launch_quantize_blocks_fp8(st, comb, 4 * d, xq2, 4 * d, xbs, bs_ld, S, 4 * d), "quantize(attn | ff hidden, blocks)");
+        else if (!attn_blocks) F2_LAUNCH(quant_attn_blocks(4 * d), "quantize(attn out, blocks)");   // the hidden columns are in place already
         {
             GemmProblem p[2];
             for (int r = 0; r < n_rng; ++r) {
