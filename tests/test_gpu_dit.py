@@ -177,7 +177,7 @@ def _fp8_case(ctx, cfg, s_txt, h, w, std=0.05, tweak=None):
     return outs, ref32, ref8
 
 
-@pytest.mark.parametrize("s_txt,h,w", [(16, 128, 128), (19, 80, 112)])
+@pytest.mark.parametrize("s_txt,h,w", [(16, 128, 128), (19, 80, 112), (64, 80, 112), (128, 128, 128)])
 def test_tiny_forward_fp8(flux2mi, ctx, s_txt, h, w):
     """fp8 model vs the oracle running the same e4m3 emulation (weights at std 0.05 so that the
     block GEMMs matter: quantisation moves the output by q ~ 1.1e-2 rel-L2).  e4m3 rounding is
@@ -189,6 +189,8 @@ def test_tiny_forward_fp8(flux2mi, ctx, s_txt, h, w):
       * rel-L2(HIP fp8, f32 oracle) within [0.5 q, 1.5 q] (the noise level is the expected one);
       * (fp8 - bf16) of the HIP path points the same way as the oracle's (cosine > 0.7)."""
     from flux2mi import synthetic as syn
+    # (text lengths 64 / 128: the block-scaled activations of proj / mlp_out / linear2 — 16 x 128 e4m3 blocks written by the SwiGLU and
+    # attention epilogues — at tiny shapes: S = 64 + 35 = 99 ends in a partial row block inside a partial tile)
     outs, ref32, ref8 = _fp8_case(ctx, syn.DIT_PRESETS["tiny"], s_txt, h, w)
     assert torch.isfinite(outs["fp8"]).all()
     assert rel_l2(outs["bf16"], ref32) < 2e-2
