@@ -61,6 +61,12 @@ struct ProfState {
 };
 
 struct flux2mi_dp;   // dp.cpp: the RCCL communicator of a data-parallel batch
+struct flux2mi_dit;
+// dit.cpp, for flux2mi_generate: between on and off, plain forwards that get the SAME text embedding pointer / length and the SAME id
+// pointers reuse the text rows of the input projection (context_embedder: it does not depend on the step) and the RoPE tables of the
+// previous call instead of recomputing them — the caller guarantees that the contents behind those pointers do not change in between.
+// Results are bit-identical to the uncached forward.  Off (the default) outside a generation.
+void flux2mi_dit_step_cache(flux2mi_dit* m, bool on);
 
 struct flux2mi_ctx {
     int device = 0;

@@ -93,6 +93,14 @@ struct flux2mi_dit {
     DevBuf stage_raw, stage_bf16, stage_w, stage_d, stage_q8;
     // forward workspace
     DevBuf hs, xn, qkv, vt, comb, mods, rope, lat_bf16, xq, xs, qk8, xbs, xq2;
+    // flux2mi_dit_step_cache (common.h): what the last plain forward of the running generation projected / tabulated
+    struct StepCache {
+        bool on = false, txt_ok = false, rope_ok = false;
+        const void* txt = nullptr;
+        const int32_t *txt_ids = nullptr, *img_ids = nullptr;
+        int s_txt = 0, s_lat = 0;
+        DevBuf hs_txt;   // f32 [s_txt, d]: the text rows of the residual stream right behind txt_in
+    } step_cache;
     DevBuf splitk_ws;   // proj_out ([s_out, d] x [128, d]^T: 32 tiles of 128x128 at 1024^2, 48 K-tiles): split-K workspace (kernels.h)
     int ws_S = 0;
 };
@@ -325,7 +333,7 @@ extern "C" int flux2mi_dit_destroy(flux2mi_dit* m) {
         if (b.scale) (void)hipFree(b.scale);
     }
     DevBuf* ws[] = {&m->stage_raw, &m->stage_bf16, &m->stage_w, &m->stage_d, &m->stage_q8, &m->hs, &m->xn, &m->qkv, &m->vt, &m->comb, &m->mods,
-                    &m->rope, &m->lat_bf16, &m->xq, &m->xs, &m->splitk_ws, &m->qk8, &m->xbs, &m->xq2};
+                    &m->rope, &m->lat_bf16, &m->xq, &m->xs, &m->splitk_ws, &m->qk8, &m->xbs, &m->xq2, &m->step_cache.hs_txt};
     for (DevBuf* w : ws) w->release();
     delete m;
     return FLUX2MI_OK;
@@ -829,8 +837,13 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     F2_LAUNCH(launch_gemv(st, m->mod_single, temb, mod_sgl, 3 * d, d, 1, 0), "mod_single");
     F2_LAUNCH(launch_gemv(st, m->final_mod, temb, mod_fin, 2 * d, d, 1, 0), "final_mod");
     // ---- RoPE tables from the ids of this call (Flux2Transformer.swift:153-154, :370-371)
+    flux2mi_dit::StepCache& sc = m->step_cache;
+    const bool sc_on = sc.on && mode == FWD_PLAIN;
+    if (!sc_on) sc.txt_ok = sc.rope_ok = false;   // any other forward rewrites the tables / is not the generation's own
     if (mode == FWD_PLAIN) {
-        F2_LAUNCH(launch_rope_tables(st, txt_ids, s_txt, img_ids, s_lat, cos_tab, sin_tab, pos_tab), "rope_tables");
+        const bool reuse = sc_on && sc.rope_ok && sc.txt_ids == txt_ids && sc.img_ids == img_ids && sc.s_txt == s_txt && sc.s_lat == s_lat;
+        if (!reuse) F2_LAUNCH(launch_rope_tables(st, txt_ids, s_txt, img_ids, s_lat, cos_tab, sin_tab, pos_tab), "rope_tables");
+        if (sc_on) { sc.rope_ok = true; sc.txt_ids = txt_ids; sc.img_ids = img_ids; if (sc.s_txt != s_txt || sc.s_lat != s_lat) sc.txt_ok = false; sc.s_txt = s_txt; sc.s_lat = s_lat; }
     } else {
         // [txt | ref] rows (the gap rows of a cached pass get their ids too when given; unused otherwise)
         if (mode == FWD_KV_EXTRACT) {
@@ -849,7 +862,18 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         GemmProblem p[2];
         p[0] = mk(reinterpret_cast<const uint16_t*>(txt_emb), J, m->txt_in, J, hs, d, s_txt, d, J, EPI_F32);
         p[1] = mk(m->lat_bf16.as<uint16_t>(), 128, m->img_in, 128, hs + (size_t)out0 * d, d, s_lat, d, 128, EPI_F32);
-        F2_TRY(run_gemm(m, p, 2, 0, "embedders"));
+        const size_t txt_bytes = (size_t)s_txt * d * 4;
+        if (sc_on && sc.txt_ok && sc.txt == txt_emb) {   // the text rows as the previous step of this generation projected them
+            F2_CHECK_HIP(hipMemcpyAsync(hs, sc.hs_txt.ptr, txt_bytes, hipMemcpyDeviceToDevice, st));
+            F2_TRY(run_gemm(m, p + 1, 1, 0, "embedder(img)"));
+        } else {
+            F2_TRY(run_gemm(m, p, 2, 0, "embedders"));
+            if (sc_on) {
+                F2_TRY(sc.hs_txt.reserve(txt_bytes));
+                F2_CHECK_HIP(hipMemcpyAsync(sc.hs_txt.ptr, hs, txt_bytes, hipMemcpyDeviceToDevice, st));
+                sc.txt = txt_emb; sc.txt_ok = true;
+            }
+        }
     }
     if (mode == FWD_KV_EXTRACT) {
         uint16_t* rb = m->lat_bf16.as<uint16_t>() + (size_t)s_lat * 128;
@@ -1171,6 +1195,16 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
 }
 
 }  // namespace
+
+void flux2mi_dit_step_cache(flux2mi_dit* m, bool on) {
+    if (!m) return;
+    static const bool allowed = [] {   // FLUX2MI_STEP_CACHE=0 (dev library): every step recomputes (A/B runs)
+        const char* e = F2_DEV_ENV("FLUX2MI_STEP_CACHE");
+        return e ? atoi(e) != 0 : true;
+    }();
+    m->step_cache.on = on && allowed;
+    m->step_cache.txt_ok = m->step_cache.rope_ok = false;
+}
 
 extern "C" int flux2mi_dit_forward(flux2mi_dit* m, const float* latents, int s_img, const void* txt_emb, int s_txt,
                                    float timestep, float guidance, const int32_t* img_ids, const int32_t* txt_ids,

@@ -30,7 +30,9 @@ struct GenScratch {
 struct GenGuard {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     flux2mi_kv_cache* kv = nullptr;
+    flux2mi_dit* cached = nullptr;   // flux2mi_dit_step_cache is on for this model
     ~GenGuard() {
+        if (cached) flux2mi_dit_step_cache(cached, false);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (ev2) (void)hipEventDestroy(ev2);
@@ -142,6 +144,9 @@ extern "C" int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae*
     }
 #define GEN_TRY(expr) F2_TRY(expr)
 
+    // the text projection and the RoPE tables do not change from step to step: the embeddings and ids live in this call's buffers
+    flux2mi_dit_step_cache(dit, true);
+    guard.cached = dit;
     std::vector<uint8_t> ckpt_host;
     F2_CHECK_HIP(hipEventRecord(ev0, st));
     // ---- "6. Denoising Loop" (:1933-2052)

@@ -216,3 +216,28 @@ def test_generation_is_bit_reproducible(flux2mi, ctx):
     for r in runs[1:]:
         assert torch.equal(r.latents, runs[0].latents)
         assert np.array_equal(r.image, runs[0].image)
+
+
+def test_step_cache_is_per_generation(flux2mi, ctx):
+    """flux2mi_generate reuses the text rows of the input projection and the RoPE tables from step to step (they do not depend on the
+    step: dit.cpp, flux2mi_dit_step_cache).  The cache does not outlive a call: new embedding CONTENTS behind the same device pointer
+    are picked up by the next generation, whose result equals a fresh pipeline's bit for bit.  (Cached against uncached forwards,
+    same box: identical image bytes — profiles/r03_m_step_cache_ab.txt.)"""
+    from flux2mi import synthetic as syn
+    from flux2mi.pipeline import Flux2Pipeline
+    cfg, vcfg = syn.DIT_PRESETS["tiny"], syn.VAE_PRESETS["tiny"]
+    P, VP = syn.make_dit_weights(cfg), syn.make_vae_weights(vcfg)
+    inp = syn.make_inputs(cfg, 128, 96, s_txt=16)
+    emb = inp["txt"].to(torch.bfloat16).cuda().contiguous()
+    gen = lambda pipe, e: pipe.generate_with_result("textToImage", height=128, width=96, steps=3, precomputed_embeddings=e, noise=inp["noise"],
+                                                    return_latents=True)
+    pipe = Flux2Pipeline(model=cfg, vae_variant=vcfg).load_models(P, VP)
+    r1 = gen(pipe, emb)
+    ptr = emb.data_ptr()
+    emb.mul_(0.5)                                   # same buffer, new contents
+    assert emb.data_ptr() == ptr
+    r2 = gen(pipe, emb)
+    fresh = Flux2Pipeline(model=cfg, vae_variant=vcfg).load_models(P, VP)
+    r3 = gen(fresh, emb.clone())
+    assert not torch.equal(r1.latents, r2.latents)
+    assert torch.equal(r2.latents, r3.latents) and np.array_equal(r2.image, r3.image)
