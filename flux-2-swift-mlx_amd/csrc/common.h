@@ -67,6 +67,9 @@ struct flux2mi_dit;
 // previous call instead of recomputing them — the caller guarantees that the contents behind those pointers do not change in between.
 // Results are bit-identical to the uncached forward.  Off (the default) outside a generation.
 void flux2mi_dit_step_cache(flux2mi_dit* m, bool on);
+// With the cache on: the timestep embeddings and modulation vectors of the coming steps (timesteps ts[0..n), one guidance value) in one
+// pass over the weights; a plain forward whose (timestep, guidance) is among them takes its vectors from there.
+int flux2mi_dit_prepare_steps(flux2mi_dit* m, const float* ts, int n, float guidance);
 
 struct flux2mi_ctx {
     int device = 0;

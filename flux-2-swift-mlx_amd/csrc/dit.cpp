@@ -100,6 +100,10 @@ struct flux2mi_dit {
         const int32_t *txt_ids = nullptr, *img_ids = nullptr;
         int s_txt = 0, s_lat = 0;
         DevBuf hs_txt;   // f32 [s_txt, d]: the text rows of the residual stream right behind txt_in
+        // flux2mi_dit_prepare_steps: rows of the forward's `mods` layout (256 + 19 d floats), one per timestep
+        std::vector<float> ts;
+        float guidance = 0.f;
+        DevBuf mods_all;
     } step_cache;
     DevBuf splitk_ws;   // proj_out ([s_out, d] x [128, d]^T: 32 tiles of 128x128 at 1024^2, 48 K-tiles): split-K workspace (kernels.h)
     int ws_S = 0;
@@ -333,7 +337,7 @@ extern "C" int flux2mi_dit_destroy(flux2mi_dit* m) {
         if (b.scale) (void)hipFree(b.scale);
     }
     DevBuf* ws[] = {&m->stage_raw, &m->stage_bf16, &m->stage_w, &m->stage_d, &m->stage_q8, &m->hs, &m->xn, &m->qkv, &m->vt, &m->comb, &m->mods,
-                    &m->rope, &m->lat_bf16, &m->xq, &m->xs, &m->splitk_ws, &m->qk8, &m->xbs, &m->xq2, &m->step_cache.hs_txt};
+                    &m->rope, &m->lat_bf16, &m->xq, &m->xs, &m->splitk_ws, &m->qk8, &m->xbs, &m->xq2, &m->step_cache.hs_txt, &m->step_cache.mods_all};
     for (DevBuf* w : ws) w->release();
     delete m;
     return FLUX2MI_OK;
@@ -812,8 +816,13 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     float* cos_tab = m->rope.as<float>();
     float* sin_tab = cos_tab + (size_t)S * 128;
     float* pos_tab = sin_tab + (size_t)S * 128;
-    // mods layout
-    float* emb = m->mods.as<float>();          // [256]
+    // mods layout (this forward's own buffer, or the row flux2mi_dit_prepare_steps computed for this timestep)
+    const size_t mods_stride = 256 + (size_t)19 * d;
+    int pre_row = -1;
+    if (m->step_cache.on && mode == FWD_PLAIN && m->step_cache.guidance == guidance)
+        for (size_t k = 0; k < m->step_cache.ts.size(); ++k)
+            if (m->step_cache.ts[k] == timestep) { pre_row = (int)k; break; }
+    float* emb = pre_row >= 0 ? m->step_cache.mods_all.as<float>() + (size_t)pre_row * mods_stride : m->mods.as<float>();   // [256]
     float* tmp = emb + 256;                    // [d]
     float* temb = tmp + d;                     // [d]
     float* mod_img = temb + d;                 // [6d]  set0 (shift,scale,gate), set1 (shift,scale,gate)
@@ -823,6 +832,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
 
     // ---- timestep (+guidance) embedding: sinusoid(1000 t) -> Linear -> SiLU -> Linear
     // (Flux2Transformer.swift:145-149, Flux2Embeddings.swift:124-142)
+    if (pre_row < 0) {
     F2_LAUNCH(launch_sinusoid(st, timestep * 1000.0f, emb), "sinusoid");
     F2_LAUNCH(launch_gemv(st, m->time_in, emb, tmp, d, 256, 0, 0), "time_in.in");
     F2_LAUNCH(launch_gemv(st, m->time_out, tmp, temb, d, d, 1, 0), "time_in.out");
@@ -836,6 +846,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     F2_LAUNCH(launch_gemv(st, m->mod_txt, temb, mod_txt, 6 * d, d, 1, 0), "mod_txt");
     F2_LAUNCH(launch_gemv(st, m->mod_single, temb, mod_sgl, 3 * d, d, 1, 0), "mod_single");
     F2_LAUNCH(launch_gemv(st, m->final_mod, temb, mod_fin, 2 * d, d, 1, 0), "final_mod");
+    }
     // ---- RoPE tables from the ids of this call (Flux2Transformer.swift:153-154, :370-371)
     flux2mi_dit::StepCache& sc = m->step_cache;
     const bool sc_on = sc.on && mode == FWD_PLAIN;
@@ -1196,6 +1207,41 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
 
 }  // namespace
 
+int flux2mi_dit_prepare_steps(flux2mi_dit* m, const float* ts, int n, float guidance) {
+    flux2mi_dit::StepCache& sc = m->step_cache;
+    sc.ts.clear();
+    if (!sc.on || n <= 0 || !m->finalized) return FLUX2MI_OK;
+    F2_CHECK_HIP(hipSetDevice(m->ctx->device));
+    hipStream_t st = m->ctx->stream;
+    const int d = m->cfg.dim;
+    const long ms = 256 + (long)19 * d;
+    F2_TRY(sc.mods_all.reserve((size_t)n * ms * 4));
+    float* base = sc.mods_all.as<float>();
+    // the forward's sequence (dit_forward_impl) with V vectors per launch: emb | tmp | temb | mod_img | mod_txt | mod_sgl | mod_fin per row
+    for (int k = 0; k < n; ++k) F2_LAUNCH(launch_sinusoid(st, ts[k] * 1000.0f, base + (size_t)k * ms), "sinusoid");
+    for (int v0 = 0; v0 < n; v0 += 32) {
+        const int V = n - v0 < 32 ? n - v0 : 32;
+        float* emb = base + (size_t)v0 * ms;
+        float *tmp = emb + 256, *temb = tmp + d, *mod_img = temb + d, *mod_txt = mod_img + 6 * d, *mod_sgl = mod_txt + 6 * d, *mod_fin = mod_sgl + 3 * d;
+        F2_LAUNCH(launch_gemv_multi(st, m->time_in, emb, ms, tmp, ms, d, 256, V, 0, 0), "time_in.in");
+        F2_LAUNCH(launch_gemv_multi(st, m->time_out, tmp, ms, temb, ms, d, d, V, 1, 0), "time_in.out");
+        if (m->cfg.guidance_embeds) {   // one guidance value: its sinusoid once (the scratch of m->mods), read by every vector (stride 0)
+            F2_TRY(m->mods.reserve((size_t)ms * 4));
+            float* gemb = m->mods.as<float>();
+            F2_LAUNCH(launch_sinusoid(st, guidance * 1000.0f, gemb), "sinusoid(g)");
+            F2_LAUNCH(launch_gemv_multi(st, m->guid_in, gemb, 0, tmp, ms, d, 256, V, 0, 0), "guidance_in.in");
+            F2_LAUNCH(launch_gemv_multi(st, m->guid_out, tmp, ms, temb, ms, d, d, V, 1, 1), "guidance_in.out");
+        }
+        F2_LAUNCH(launch_gemv_multi(st, m->mod_img, temb, ms, mod_img, ms, 6 * d, d, V, 1, 0), "mod_img");
+        F2_LAUNCH(launch_gemv_multi(st, m->mod_txt, temb, ms, mod_txt, ms, 6 * d, d, V, 1, 0), "mod_txt");
+        F2_LAUNCH(launch_gemv_multi(st, m->mod_single, temb, ms, mod_sgl, ms, 3 * d, d, V, 1, 0), "mod_single");
+        F2_LAUNCH(launch_gemv_multi(st, m->final_mod, temb, ms, mod_fin, ms, 2 * d, d, V, 1, 0), "final_mod");
+    }
+    sc.ts.assign(ts, ts + n);
+    sc.guidance = guidance;
+    return FLUX2MI_OK;
+}
+
 void flux2mi_dit_step_cache(flux2mi_dit* m, bool on) {
     if (!m) return;
     static const bool allowed = [] {   // FLUX2MI_STEP_CACHE=0 (dev library): every step recomputes (A/B runs)
@@ -1203,6 +1249,7 @@ void flux2mi_dit_step_cache(flux2mi_dit* m, bool on) {
         return e ? atoi(e) != 0 : true;
     }();
     m->step_cache.on = on && allowed;
+    m->step_cache.ts.clear();
     m->step_cache.txt_ok = m->step_cache.rope_ok = false;
 }
 

@@ -40,6 +40,45 @@ __global__ __launch_bounds__(256) void gemv_kernel(const uint16_t* __restrict__ 
     if (lane == 0) out[n] = accumulate ? out[n] + acc : acc;
 }
 
+// The same for up to GEMV_MULTI vectors at once (x_v = x + v xs, out_v = out + v os): the weights are read once, every vector goes through
+// the single-vector kernel's arithmetic in its order (same per-lane chunks, same expression, same wave reduction): the results are the
+// single-vector kernel's.  For flux2mi_generate: the timestep MLP and the modulation projections of ALL steps in one pass.
+constexpr int GEMV_MULTI = 32;
+__global__ __launch_bounds__(256) void gemv_multi_kernel(const uint16_t* __restrict__ W, const float* __restrict__ x, long xs,
+                                                         float* __restrict__ out, long os, int N, int K, int V, int silu_in, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const uint16_t* wr = W + (size_t)n * K;
+    float acc[GEMV_MULTI];
+#pragma unroll
+    for (int v = 0; v < GEMV_MULTI; ++v) acc[v] = 0.f;
+    for (int k = lane * 8; k < K; k += 64 * 8) {
+        const uint4 w = *reinterpret_cast<const uint4*>(wr + k);
+#pragma unroll
+        for (int v = 0; v < GEMV_MULTI; ++v) {
+            if (v < V) {
+                const float4 xa = *reinterpret_cast<const float4*>(x + v * xs + k);
+                const float4 xb = *reinterpret_cast<const float4*>(x + v * xs + k + 4);
+                float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                if (silu_in) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[j] = silu_f(xv[j]);
+                }
+                acc[v] += lo_bf16(w.x) * xv[0] + hi_bf16(w.x) * xv[1] + lo_bf16(w.y) * xv[2] + hi_bf16(w.y) * xv[3] +
+                          lo_bf16(w.z) * xv[4] + hi_bf16(w.z) * xv[5] + lo_bf16(w.w) * xv[6] + hi_bf16(w.w) * xv[7];
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < GEMV_MULTI; ++v) {
+        if (v < V) {
+            const float a = wave_sum(acc[v]);
+            if (lane == 0) out[v * os + n] = accumulate ? out[v * os + n] + a : a;
+        }
+    }
+}
+
 // ---- sinusoidal embedding: [cos(v f_i) | sin(v f_i)], f_i = exp(-ln(1e4) i/128), i < 128
 __global__ void sinusoid_kernel(float value, float* __restrict__ emb) {
     const int i = threadIdx.x;  // 128 threads
@@ -307,6 +346,12 @@ int launch_gemv(hipStream_t stream, const uint16_t* W, const float* x, float* ou
                 int accumulate) {
     if (N <= 0 || K <= 0 || (K & 7)) return 1;
     hipLaunchKernelGGL(gemv_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, W, x, out, N, K, silu_in, accumulate);
+    EW_DONE();
+}
+int launch_gemv_multi(hipStream_t stream, const uint16_t* W, const float* x, long xs, float* out, long os, int N, int K, int V, int silu_in,
+                      int accumulate) {
+    if (N <= 0 || K <= 0 || (K & 7) || V <= 0 || (xs & 3) || V > GEMV_MULTI) return 1;
+    hipLaunchKernelGGL(gemv_multi_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, W, x, xs, out, os, N, K, V, silu_in, accumulate);
     EW_DONE();
 }
 int launch_sinusoid(hipStream_t stream, float value, float* emb) {

@@ -213,6 +213,9 @@ int launch_rope_tables(hipStream_t stream, const int32_t* txt_ids, int s_txt, co
 int launch_gemv(hipStream_t stream, const uint16_t* W, const float* x, float* out, int N, int K, int silu_in,
                 int accumulate);
 // emb f32[256] = [cos(1000 t f_i) | sin(1000 t f_i)] (Flux2Embeddings.swift:27-44)
+// V <= 32 vectors x + v xs -> out + v os through launch_gemv's arithmetic (identical results), the weights read once
+int launch_gemv_multi(hipStream_t stream, const uint16_t* W, const float* x, long xs, float* out, long os, int N, int K, int V, int silu_in,
+                      int accumulate);
 int launch_sinusoid(hipStream_t stream, float value, float* emb);
 int launch_silu_inplace(hipStream_t stream, float* x, int n);
 int launch_f32_to_bf16(hipStream_t stream, const float* in, uint16_t* out, int64_t n);

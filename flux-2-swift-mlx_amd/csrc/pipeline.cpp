@@ -147,6 +147,7 @@ extern "C" int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae*
     // the text projection and the RoPE tables do not change from step to step: the embeddings and ids live in this call's buffers
     flux2mi_dit_step_cache(dit, true);
     guard.cached = dit;
+    F2_TRY(flux2mi_dit_prepare_steps(dit, sigmas.data(), n_steps, p->guidance));   // timestep MLP + modulation vectors of every step at once
     std::vector<uint8_t> ckpt_host;
     F2_CHECK_HIP(hipEventRecord(ev0, st));
     // ---- "6. Denoising Loop" (:1933-2052)

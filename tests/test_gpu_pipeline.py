@@ -220,7 +220,7 @@ def test_generation_is_bit_reproducible(flux2mi, ctx):
 
 def test_step_cache_is_per_generation(flux2mi, ctx):
     """flux2mi_generate reuses the text rows of the input projection and the RoPE tables from step to step (they do not depend on the
-    step: dit.cpp, flux2mi_dit_step_cache).  The cache does not outlive a call: new embedding CONTENTS behind the same device pointer
+    step: dit.cpp, flux2mi_dit_step_cache) and computes the timestep / modulation vectors of all steps in one pass (flux2mi_dit_prepare_steps).  The cache does not outlive a call: new embedding CONTENTS behind the same device pointer
     are picked up by the next generation, whose result equals a fresh pipeline's bit for bit.  (Cached against uncached forwards,
     same box: identical image bytes — profiles/r03_m_step_cache_ab.txt.)"""
     from flux2mi import synthetic as syn
