@@ -767,15 +767,24 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     const bool q8_out = FP8 && !CONV && epi == EPI_SWIGLU && p.c2_q8 != nullptr;
     if constexpr (FP8 && !CONV) {
         if (q8_out) {
+            // |g u| = |acc_g acc_u| x (column scale of g x column scale of u) x (row scale)^2: the column products once per lane
+            f32x4 cgu[2][2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) cgu[hh][jj] = fs_col[4 * hh + jj] * fs_col[4 * hh + jj + 2];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 float mx = 0.f;
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const f32x4 pr = acc[i][4 * hh + jj] * acc[i][4 * hh + jj + 2] * cgu[hh][jj];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(accv(i, 4 * hh + jj)[r] * accv(i, 4 * hh + jj + 2)[r]));
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(pr[r]));
+                    }
+                mx *= fs_row[i] * fs_row[i] * 1.0000005f;   // (a hair up: the factors are regrouped against the values' own rounding)
                 // both waves of the row, all lanes: one LDS maximum per row block (non-negative floats order like their bit patterns;
                 // a chain of six lane exchanges per row block cost 3 us per tile)
                 mx = row16_max_nonneg(mx);   // 4 lanes per wave go to the LDS instead of 64
