@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""bench.py — Flux.2 Klein-4B 1024x1024 @ 28 steps on N MI355X (BASELINE.json configs[1]).
+"""bench.py — Flux.2 Klein-4B 1024x1024 @ 28 steps on N MI355X (BASELINE.json configs[1]); `--config A..E` selects the other
+BASELINE.json configurations under the same JSON contract (C: Dev 50 steps; D: Klein-9B fp8; E: Dev at strength 0.7 with the RePaint
+step hook, `--reference` for its I2I form), e.g. `--gpus 8 --config D`, `--gpus 4 --config E`.
 
 One bench "step" = one batch of N images (one per GPU, batch-level data parallel): the
 28 denoise steps of the DiT, VAE decode, the all-gather of the decoded u8 images and the D2H
@@ -39,18 +41,44 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+# BASELINE.json `configs`, by letter (A = configs[0] ... E = configs[4]).  `--gpus` is the caller's: D is quoted on 8, E on 4.
+CONFIGS = {
+    "A": {"name": "configs[0]: Klein-4B bf16, 256x256, 4 steps, batch 1 (the reference's CPU-runnable plumbing case, here on the GPU)",
+          "model": "klein-4b", "weights": "bf16", "height": 256, "width": 256, "denoise_steps": 4, "strength": 1.0, "repaint": False},
+    "B": {"name": "configs[1]: Klein-4B bf16, 1024x1024, 28 steps, batch 1 per GPU (the headline)",
+          "model": "klein-4b", "weights": "bf16", "height": 1024, "width": 1024, "denoise_steps": 28, "strength": 1.0, "repaint": False},
+    "C": {"name": "configs[2]: Dev (32B) bf16, 1024x1024, 50 steps, batch 1 per GPU",
+          "model": "dev", "weights": "bf16", "height": 1024, "width": 1024, "denoise_steps": 50, "strength": 1.0, "repaint": False},
+    "D": {"name": "configs[3]: Klein-9B fp8 weights, 1024x1024, 28 steps, one image per GPU (quoted at batch 8 on 8 GPUs)",
+          "model": "klein-9b", "weights": "fp8", "height": 1024, "width": 1024, "denoise_steps": 28, "strength": 1.0, "repaint": False},
+    "E": {"name": "configs[4]: Dev image-to-image at strength 0.7 with the Flux2MaskedInpaintingChain RePaint step hook, 1024x1024, "
+                  "one image per GPU (quoted at batch 4 on 4 GPUs)",
+          "model": "dev", "weights": "bf16", "height": 1024, "width": 1024, "denoise_steps": 50, "strength": 0.7, "repaint": True},
+}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="timed batches (one image per GPU each)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="klein-4b")
-    ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--denoise-steps", type=int, default=28)
+    ap.add_argument("--config", default="B", choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration (default B = configs[1], the headline); sets the defaults of --model / --weights / "
+                         "--height / --width / --denoise-steps / --strength / --repaint, each of which may still be given explicitly")
+    ap.add_argument("--model", default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--denoise-steps", type=int, default=None)
     ap.add_argument("--vae", default="standard", choices=["standard", "small"])
-    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
+    ap.add_argument("--weights", default=None, choices=["bf16", "fp8"],
                     help="transformer block-GEMM format; the headline (BASELINE.json configs[1]) is bf16")
+    ap.add_argument("--strength", type=float, default=None, help="< 1: image-to-image start from seeded init latents (config E: 0.7)")
+    ap.add_argument("--repaint", action="store_true", default=None,
+                    help="run the Flux2MaskedInpaintingChain RePaint step hook every step (config E)")
+    ap.add_argument("--reference", action="store_true",
+                    help="config E's I2I form: one 1024^2 reference image (4096 reference tokens behind the output tokens, S = 8704)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the extra untimed generations that fill roofline_secondary / roofline_hbm (profiler runs)")
     ap.add_argument("--attn-softmax", default="auto", choices=["auto", "online"],
                     help="auto: fixed zero softmax offset where the QK-RMSNorm weights bound the scores, a per-query data "
                          "offset otherwise (what a checkpoint with larger norm scales gets: exact for any scores); "
@@ -60,7 +88,11 @@ def parse_args(argv=None):
                     help="skip the register-only MFMA stream after the timed region (roofline.mfma_stream): profiler runs")
     ap.add_argument("--prof-class", type=int, default=0, help="kernel class timed with HIP events (0 = linear1 GEMM)")
     ap.add_argument("--dry-run", action="store_true", help="harness self-test on CPU/gloo: no GPU, no compute")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    for k, v in CONFIGS[args.config].items():
+        if k != "name" and getattr(args, k) is None:
+            setattr(args, k, v)
+    return args
 
 
 def launch_ranks(args) -> int:
@@ -147,14 +179,17 @@ def main():
     if not dry:
         from flux2mi.pipeline import Flux2Pipeline
         pipe = Flux2Pipeline(model=args.model, vae_variant=args.vae, device=dev.index, quantization=args.weights)
-        P = syn.make_dit_weights(cfg, seed=1234, device=dev)
+        # per-tensor seeds, generated on the GPU one tensor at a time (Dev is 64 GB: no second copy of the model anywhere)
+        # the CPU-oracle leg needs the tensors themselves: Klein-4B only (a Dev forward is minutes of host time and 64 GB of host memory)
+        need_host_copy = rank == 0 and not args.no_cpu_baseline and world == 1 and args.model == "klein-4b"
+        P = syn.make_dit_weights(cfg, seed=1234, device=dev) if need_host_copy else syn.LazyDitWeights(cfg, seed=1234, device=dev)
         VP = syn.make_vae_weights(vcfg, seed=4321, device=dev)
         pipe.load_models(P, VP)
         if world > 1:
             par.attach_context(pipe.ctx)   # this rank's RCCL communicator, on the stream the pipeline generates on
         if args.attn_softmax == "online":
             pipe.transformer.set_attention_softmax("online")
-        if not (rank == 0 and not args.no_cpu_baseline):
+        if not need_host_copy:
             del P
             P = None
         del VP
@@ -173,6 +208,32 @@ def main():
         g7.manual_seed(7)
         emb_all = torch.randn(emb_shape, generator=g7, device=dev, dtype=torch.float32).to(torch.bfloat16)
     guidance = 4.0
+    # config E (Flux2MaskedInpaintingChain.swift:380-431): VAE-encoded source latents (seed 99 + rank), blend noise drawn once, a
+    # centred square mask over 25 % of the tokens; strength < 1 starts from the source latents; --reference appends them as one reference image
+    strength = float(args.strength)
+    chain = ref_lat = ref_ids = init_lat = None
+    if (args.repaint or strength < 1.0 or args.reference) and not dry:
+        from flux2mi import api
+        from flux2mi.pipeline import Flux2MaskedInpaintingChain
+        g99 = torch.Generator(device=dev)
+        g99.manual_seed(99 + rank)
+        src_lat = torch.randn((1, s_img, 128), generator=g99, device=dev)
+        if strength < 1.0:
+            init_lat = src_lat
+        if args.repaint:
+            blend = torch.randn((1, s_img, 128), generator=g99, device=dev)
+            hh, ww = H // 16, W // 16
+            mask = torch.zeros((hh, ww), device=dev)
+            mask[hh // 4: hh - hh // 4, ww // 4: ww - ww // 4] = 1.0
+            chain = Flux2MaskedInpaintingChain(pipe, src_lat, mask.reshape(1, s_img, 1), blend)
+        if args.reference:
+            ref_lat = src_lat
+            ref_ids = torch.from_numpy(api.reference_position_ids([H // 16], [W // 16])).to(dev)
+    hook_calls = [0]
+
+    def on_step(ctx_, latents):
+        hook_calls[0] += 1
+        return chain.on_step(ctx_, latents)
     img_dev = torch.zeros((1, H, W, 3), dtype=torch.uint8, device=dev)      # this rank's decoded image, in HBM
     host_batch = torch.empty((world, H, W, 3), dtype=torch.uint8, pin_memory=not dry) if rank == 0 else None
 
@@ -182,9 +243,11 @@ def main():
             res = None
             img_dev.fill_(rank + 1)                                                  # placeholder, no compute
         else:
-            res = pipe.generate_with_result("textToImage", height=H, width=W, steps=T, guidance=guidance,
-                                            precomputed_embeddings=emb[rank], noise=noise, image_device=img_dev[0],
-                                            return_latents=True)
+            res = pipe.generate_with_result("imageToImage" if ref_lat is not None else "textToImage", height=H, width=W, steps=T,
+                                            guidance=guidance, precomputed_embeddings=emb[rank], noise=noise, image_device=img_dev[0],
+                                            return_latents=True, init_latents=init_lat, strength=strength,
+                                            on_step=on_step if chain is not None else None,
+                                            reference_latents=ref_lat, reference_ids=ref_ids)
         imgs = par.all_gather_images(img_dev)                                        # collective 2 (device buffers)
         if rank == 0:
             host_batch.copy_(imgs, non_blocking=False)                               # the batch's D2H copy
@@ -236,7 +299,15 @@ def main():
         assert hist["levels_used"] > 16, f"decoded image is degenerate: {hist}"
 
     K = args.steps
-    total_denoise_steps = world * K * T
+    # strength < 1 runs the tail of the schedule (E: 35 of 50): the generation reports it; the dry run asks the host scheduler
+    if res is not None:
+        T_eff = int(res.effectiveSteps)
+    else:
+        from flux2mi import api as _api
+        T_eff = len(_api.set_timesteps(T, s_img, max(0.01, min(1.0, strength)))[0]) - 1
+    if chain is not None:
+        assert hook_calls[0] == (K + args.warmup) * T_eff, f"RePaint hook ran {hook_calls[0]} times for {(K + args.warmup) * T_eff} steps"
+    total_denoise_steps = world * K * T_eff
     value = total_denoise_steps / elapsed
     sec_per_image = elapsed / K   # latency of one image (every rank produces one per batch)
 
@@ -244,7 +315,8 @@ def main():
     step_ms = 0.0
     peak = 5000.0 if args.weights == "fp8" else 2500.0
     blocks = cfg["n_double"] + cfg["n_single"]
-    step_flops = blocks * (26.0 * S * d * d + 4.0 * S * S * d) + 2.0 * (s_img * 128 * d * 2 + s_txt * cfg["joint_dim"] * d)
+    S_all = S + (s_img if args.reference else 0)                # reference tokens ride along in every block (I2I, S = 8704)
+    step_flops = blocks * (26.0 * S_all * d * d + 4.0 * S_all * S_all * d) + 2.0 * ((S_all - s_txt) * 128 * d + s_img * 128 * d + s_txt * cfg["joint_dim"] * d)
     if not dry:
         # ---- roofline of the dominant kernel: single-stream linear1 GEMM [S,d] x [9d,d]^T
         flops_per_launch = prof_flops / max(n_launch, 1)
@@ -271,17 +343,36 @@ def main():
                     "mfma_stream": stream_tf, "frac_of_mfma_stream": round(achieved / stream_tf, 4) if stream_tf else None,
                     "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
                     "flops_per_launch": flops_per_launch}
-        step_ms = ms_denoise / (K * T)
+        step_ms = ms_denoise / (K * T_eff)
+
+    # ---- the other kernels' rooflines: one extra SHORT generation per kernel class AFTER the timed region (same
+    # model, same inputs, 4 denoise steps, HIP events around every launch of the class on the library's stream), and one decode for
+    # the two VAE classes.  MFMA-bound classes against the dense peak, HBM-bound classes (work = algorithmic bytes) against 8 TB/s.
+    roofline_secondary = roofline_hbm = None
+    if not dry and not args.no_secondary:
+        roofline_secondary, roofline_hbm = secondary_rooflines(pipe, torch, dev, H, W, peak, stream_tf, lambda n: pipe.generate_with_result(
+            "imageToImage" if ref_lat is not None else "textToImage", height=H, width=W, steps=n, guidance=guidance,
+            precomputed_embeddings=emb_all[0], noise=noise, skip_decode=True, reference_latents=ref_lat, reference_ids=ref_ids))
 
     # ---- the decode tail with BOTH decoders (outside the timed region): the timed region uses --vae (default: standard, the
     # larger one); the reference pipeline's own default is the small decoder (Flux2Pipeline.swift:303)
     decode_by_vae = None
     if not dry:
         decode_by_vae = {v: time_vae_decode(pipe.ctx, v, syn, dev, H, W) for v in ("standard", "small")}
+        if roofline_secondary is not None:
+            # the whole decode against the MFMA peak on SURVEY §8(d)'s nominal FLOPs (1024^2: 10.475 / 5.997 TFLOP, scaled by the pixel count)
+            for v, tf in (("standard", 10.475), ("small", 5.997)):
+                fl = tf * (H * W) / (1024.0 * 1024.0)
+                ach = fl / (decode_by_vae[v] * 1e-3)
+                roofline_secondary.append({"kernel": f"VAE decode, whole ({v} decoder: every launch, latents -> u8 image)", "bound": "mfma",
+                                           "achieved": round(ach, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+                                           "ms": decode_by_vae[v], "nominal_tflop": round(fl, 3),
+                                           "measured": "synchronised wall time over 5 back-to-back decodes after the timed region"})
 
     cpu_baseline = None
     if world == 1 and not dry and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(P, cfg, syn, H, W, T, s_txt)
+        cpu_baseline = run_cpu_baseline(P, cfg, syn, H, W, T, s_txt) if P is not None else \
+            {"skipped": f"the oracle leg is timed for Klein-4B only ({args.model}: one fp32 CPU forward is minutes and the tensors do not fit the host)"}
 
     out = {
         "metric": f"denoise-steps/sec (Flux.2 {args.model} {H}x{W} @ {T} steps; seconds/image reported alongside)"
@@ -297,9 +388,15 @@ def main():
         "vs_baseline": None,
         "dtype": "bf16" if args.weights == "bf16" else "fp8 (e4m3 block GEMMs with block-scaled activations, e4m3 attention Q K^T; bf16 P V, f32 residual)",
         "data": "synthetic",
-        "config": {"workload": f"Flux.2 {args.model} {args.weights}, {H}x{W}, {T} denoise steps + {args.vae} VAE decode + "
-                               f"image all-gather + D2H, 1 image per GPU per bench step (BASELINE.json configs[1])",
-                   "images_per_bench_step": world, "s_txt": s_txt, "s_img": s_img, "parallelism": f"dp{world}"},
+        "config": {"workload": f"Flux.2 {args.model} {args.weights}, {H}x{W}, {T} denoise steps"
+                               + (f" at strength {strength} ({T_eff} effective)" if strength < 1.0 else "")
+                               + (" + RePaint step hook every step" if args.repaint else "")
+                               + (f" + one {H}x{W} reference image (S = {S_all})" if args.reference else "")
+                               + f" + {args.vae} VAE decode + image all-gather + D2H, 1 image per GPU per bench step",
+                   "baseline_config": f"{args.config} = BASELINE.json {CONFIGS[args.config]['name']}",
+                   "matches_baseline_config": all(getattr(args, k) == v for k, v in CONFIGS[args.config].items() if k != "name"),
+                   "images_per_bench_step": world, "s_txt": s_txt, "s_img": s_img, "effective_denoise_steps": T_eff,
+                   "parallelism": f"dp{world}"},
         "seconds_per_image": round(sec_per_image, 4),
         "denoise_ms_per_denoise_step": round(step_ms, 3),
         "decode_ms_per_image": round(ms_decode / K, 3),
@@ -313,6 +410,8 @@ def main():
         "output_check": {"latents_finite": True, "image_crc32": checksum, "u8_histogram": hist},
         "model_load_s": round(t_load, 2),
         "roofline": roofline,
+        "roofline_secondary": roofline_secondary,
+        "roofline_hbm": roofline_hbm,
         "card": card,
         "cpu_baseline": cpu_baseline,
     }
@@ -320,6 +419,43 @@ def main():
         out["dry_run"] = True
     print(json.dumps(out), flush=True)
     par.finalize()
+
+
+def secondary_rooflines(pipe, torch, dev, H, W, peak, stream_tf, short_generation, steps=4):
+    """[MFMA-bound entries], [HBM-bound entries]: achieved = work of the class's launches / their summed HIP-event time."""
+    ctx = pipe.ctx
+    where = f"one extra {steps}-step generation after the timed region (same model and inputs; HIP events around every launch of the class)"
+
+    def entry(cls, n, ms, work, unit, pk, extra=None):
+        ach = work / max(ms * 1e-3, 1e-12) / (1e12 if unit == "TFLOP/s" else 1e9)
+        e = {"kernel": ctx.prof_kernel_name(cls), "bound": "mfma" if unit == "TFLOP/s" else "hbm", "achieved": round(ach, 2), "peak": pk,
+             "unit": unit, "frac": round(ach / pk, 4), "launches": n, "avg_launch_ms": round(ms / max(n, 1), 4),
+             "work_per_launch": work / max(n, 1), "measured": where}
+        if unit == "TFLOP/s" and stream_tf:
+            e["frac_of_mfma_stream"] = round(ach / stream_tf, 4)
+        e.update(extra or {})
+        return e
+
+    mfma, hbm = [], []
+    for cls in (2, 4, 7, 5):                          # attention, linear2, proj + mlp_out, LayerNorm + modulate
+        ctx.prof_begin(cls)
+        short_generation(steps)
+        n, ms, work = ctx.prof_end()
+        if n:
+            (hbm if cls == 5 else mfma).append(entry(cls, n, ms, work, "GB/s" if cls == 5 else "TFLOP/s", 8000.0 if cls == 5 else peak))
+    if pipe.vae is not None:
+        g = torch.Generator(device=dev)
+        g.manual_seed(11)
+        z = torch.randn((1, 32, H // 8, W // 8), generator=g, device=dev, dtype=torch.float32)
+        pipe.vae.decode(z, want_f32=False)
+        for cls in (3, 6):                            # VAE convolutions, GroupNorm apply
+            ctx.prof_begin(cls)
+            pipe.vae.decode(z, want_f32=False)
+            n, ms, work = ctx.prof_end()
+            if n:
+                one = {"measured": "one extra decode after the timed region (HIP events around every launch of the class)"}
+                (hbm if cls == 6 else mfma).append(entry(cls, n, ms, work, "GB/s" if cls == 6 else "TFLOP/s", 8000.0 if cls == 6 else 2500.0, one))
+    return mfma, hbm
 
 
 class CardSampler:

@@ -80,6 +80,9 @@ PROTOTYPES = {
     "flux2mi_ctx_create": (_I, [_I, _P, C.POINTER(_P)]),
     "flux2mi_ctx_destroy": (_I, [_P]),
     "flux2mi_ctx_sync": (_I, [_P]),
+    "flux2mi_ctx_memory_stats": (_I, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "flux2mi_ctx_reset_peak": (_I, [_P]),
+    "flux2mi_ctx_trim": (_I, [_P, C.POINTER(C.c_size_t)]),
     "flux2mi_buffer_alloc": (_I, [_P, C.c_size_t, C.POINTER(_P)]),
     "flux2mi_buffer_free": (_I, [_P, _P]),
     "flux2mi_buffer_upload": (_I, [_P, _P, _P, C.c_size_t]),
@@ -148,6 +151,8 @@ PROTOTYPES = {
     "flux2mi_dit_load_safetensors": (_I, [_P, C.c_char_p, _PI, _PI]),
     "flux2mi_dit_set_tensor_q8": (_I, [_P, C.c_char_p, _P, _P, _I64, _I64]),
     "flux2mi_dit_merge_lora": (_I, [_P, C.c_char_p, _I, _P, _P, _I, _F]),
+    "flux2mi_dit_merge_lora_checked": (_I, [_P, C.c_char_p, _I, _P, _I64, _I64, _I, _P, _I64, _I64, _F]),
+    "flux2mi_dit_slot_shape": (_I, [_P, C.c_char_p, C.POINTER(_I64), C.POINTER(_I64)]),
     "flux2mi_dit_param_bytes": (_I64, [_P]),
     "flux2mi_dit_forward": (_I, [_P, _P, _I, _P, _I, _F, _F, _P, _P, _P, _I]),
     "flux2mi_dit_set_attention_softmax": (_I, [_P, _I]),

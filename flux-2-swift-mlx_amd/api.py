@@ -111,6 +111,22 @@ class Context:
     def sync(self):
         check(lib().flux2mi_ctx_sync(self.handle))
 
+    # ---- MLX.Memory (Flux2CLI/InpaintCommand.swift:253-271): what the library holds on this GPU
+    def memory_stats(self) -> dict:
+        """{"active", "peak", "cache"} in bytes: MLX.Memory.activeMemory / peakMemory / cacheMemory (cache = trimmable workspaces)."""
+        a, p, w = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        check(lib().flux2mi_ctx_memory_stats(self.handle, C.byref(a), C.byref(p), C.byref(w)))
+        return {"active": int(a.value), "peak": int(p.value), "cache": int(w.value)}
+
+    def reset_peak_memory(self):
+        check(lib().flux2mi_ctx_reset_peak(self.handle))
+
+    def clear_cache(self) -> int:
+        """MLX.Memory.clearCache(): release the library's workspaces on this GPU; returns the bytes given back."""
+        f = C.c_size_t(0)
+        check(lib().flux2mi_ctx_trim(self.handle, C.byref(f)))
+        return int(f.value)
+
     def close(self):
         if self.handle:
             for ref in list(self._children):
@@ -289,7 +305,11 @@ class Context:
            "+ SwiGLU rows, and V^T = W_v x^T; fp8 weights: gemm256s_kernel<NI, FP8>)",
         1: "gemm256s_kernel (bf16 / fp8) / gemm_bf16_128x128_kernel (every DiT GEMM)",
         2: "attn64b_kernel (fixed / per-query data offset) / attn_fwd_kernel (joint attention)",
-        3: "conv2d_g128_kernel / conv2d_kernel (VAE convolutions)",
+        3: "gemm256s_kernel<NI, false, CONV> / conv2d_g128_kernel / conv2d_kernel (VAE convolutions)",
+        4: "gemm256s_kernel (single_blocks.linear2: [S,4d] x [d,4d]^T, one round of tiles, x += gate*y epilogue)",
+        5: "layernorm_modulate_kernel (LayerNorm + AdaLN modulate; work = algorithmic bytes: f32 row in, bf16 / e4m3 row out)",
+        6: "gn_apply_padded_kernel (GroupNorm apply + SiLU into the zero-haloed operand; work = algorithmic bytes)",
+        7: "gemm256s_kernel (double blocks' attention proj and mlp_out: the one-round N = d GEMMs)",
     }
 
     def prof_kernel_name(self, kernel_class: int) -> str:
@@ -670,12 +690,20 @@ class DiT:
         return self
 
     def merge_lora(self, name: str, lora_a: torch.Tensor, lora_b: torch.Tensor, scale: float):
-        """W[name] += scale * (B A); A [rank,in], B [out,rank] (WeightLoader.mergeLoRAWeights)."""
-        a, b = lora_a.contiguous(), lora_b.to(lora_a.dtype).contiguous()
-        dt = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}[a.dtype]
-        assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[1]
-        check(lib().flux2mi_dit_merge_lora(self.handle, name.encode(), dt, a.data_ptr(), b.data_ptr(), a.shape[0], float(scale)))
+        """W[name] += scale * (B A); A [rank,in], B [out,rank], each in its own float dtype (WeightLoader.mergeLoRAWeights).
+        The factors' shapes are checked against the weight by the library (Flux2MIError SHAPE for another model's LoRA)."""
+        a, b = lora_a.contiguous(), lora_b.contiguous()
+        dts = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}
+        assert a.dim() == 2 and b.dim() == 2
+        check(lib().flux2mi_dit_merge_lora_checked(self.handle, name.encode(), dts[a.dtype], a.data_ptr(), a.shape[0], a.shape[1],
+                                                   dts[b.dtype], b.data_ptr(), b.shape[0], b.shape[1], float(scale)))
         return self
+
+    def slot_shape(self, name: str):
+        """[out, in] of the weight a checkpoint key addresses."""
+        r, c = C.c_int64(0), C.c_int64(0)
+        check(lib().flux2mi_dit_slot_shape(self.handle, name.encode(), C.byref(r), C.byref(c)))
+        return int(r.value), int(c.value)
 
     @property
     def param_bytes(self) -> int:

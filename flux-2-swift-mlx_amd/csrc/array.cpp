@@ -39,7 +39,7 @@ int make(flux2mi_ctx* ctx, const int64_t* shape, int ndim, bool alloc, flux2mi_a
     }
     if (a->numel() > (int64_t)1 << 40) { delete a; flux2mi_set_error("array: too many elements"); return FLUX2MI_ERR_SHAPE; }
     if (alloc) {
-        if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&a->data, (size_t)a->numel() * 4) != hipSuccess) {
+        if (hipSetDevice(ctx->device) != hipSuccess || f2_malloc((void**)&a->data, (size_t)a->numel() * 4) != hipSuccess) {
             flux2mi_set_error("array: hipMalloc(%lld B) failed", (long long)a->numel() * 4);
             delete a;
             return FLUX2MI_ERR_OOM;
@@ -121,7 +121,7 @@ extern "C" int flux2mi_array_free(flux2mi_array* a) {
     if (a->owned && a->data) {
         (void)hipSetDevice(a->ctx->device);
         (void)hipStreamSynchronize(a->ctx->stream);   // work reading it may still be queued
-        (void)hipFree(a->data);
+        f2_free(a->data);
     }
     delete a;
     return FLUX2MI_OK;

@@ -5,6 +5,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
+#include <unordered_map>
+#include <unordered_set>
 
 #include "common.h"
 #include "kernels.h"
@@ -22,28 +25,119 @@ void flux2mi_set_error(const char* fmt, ...) {
 extern "C" const char* flux2mi_last_error(void) { return g_err; }
 extern "C" int flux2mi_version(void) { return FLUX2MI_VERSION; }
 
-// ------------------------------------------------------------------ DevBuf
+// ------------------------------------------------------------------ accounted device memory + DevBuf
+// MLX.Memory.{activeMemory, peakMemory, cacheMemory, clearCache} (mlx-swift 0.31.6; called at Flux2CLI/InpaintCommand.swift:253-271,
+// CompareEncoders.swift:112,142) report MLX's allocator.  Here: one table of the library's live device allocations per process.
+namespace {
+struct MemTable {
+    std::mutex mu;
+    struct Rec { size_t bytes; int device; bool workspace; };
+    std::unordered_map<void*, Rec> live;
+    std::unordered_set<DevBuf*> bufs;
+    size_t active[FLUX2MI_MAX_DEVICES] = {0}, workspace[FLUX2MI_MAX_DEVICES] = {0}, peak[FLUX2MI_MAX_DEVICES] = {0};
+    int generating = 0;
+};
+MemTable& mem() {
+    static MemTable* t = new MemTable();   // never destroyed: DevBufs of static objects may outlive any static table
+    return *t;
+}
+}  // namespace
+
+hipError_t f2_malloc(void** p, size_t bytes, bool workspace) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return e;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= FLUX2MI_MAX_DEVICES) dev = 0;
+    MemTable& t = mem();
+    std::lock_guard<std::mutex> g(t.mu);
+    t.live[*p] = MemTable::Rec{bytes, dev, workspace};
+    (workspace ? t.workspace : t.active)[dev] += bytes;
+    const size_t total = t.active[dev] + t.workspace[dev];
+    if (total > t.peak[dev]) t.peak[dev] = total;
+    return hipSuccess;
+}
+void f2_free(void* p) {
+    if (!p) return;
+    {
+        MemTable& t = mem();
+        std::lock_guard<std::mutex> g(t.mu);
+        auto it = t.live.find(p);
+        if (it != t.live.end()) {
+            (it->second.workspace ? t.workspace : t.active)[it->second.device] -= it->second.bytes;
+            t.live.erase(it);
+        }
+    }
+    (void)hipFree(p);
+}
+GenerationInFlight::GenerationInFlight() { std::lock_guard<std::mutex> g(mem().mu); ++mem().generating; }
+GenerationInFlight::~GenerationInFlight() { std::lock_guard<std::mutex> g(mem().mu); --mem().generating; }
+
+DevBuf::DevBuf() { std::lock_guard<std::mutex> g(mem().mu); mem().bufs.insert(this); }
+DevBuf::~DevBuf() {
+    release();
+    std::lock_guard<std::mutex> g(mem().mu);
+    mem().bufs.erase(this);
+}
 int DevBuf::reserve(size_t n) {
     if (n <= bytes) return FLUX2MI_OK;
-    if (ptr) {
-        (void)hipFree(ptr);
-        ptr = nullptr;
-        bytes = 0;
-    }
+    release();
     const size_t rounded = (n + 255) & ~(size_t)255;
-    hipError_t e = hipMalloc(&ptr, rounded);
+    hipError_t e = f2_malloc(&ptr, rounded, !keep);
     if (e != hipSuccess) {
         ptr = nullptr;
         flux2mi_set_error("hipMalloc(%zu bytes) failed: %s", rounded, hipGetErrorString(e));
         return FLUX2MI_ERR_OOM;
     }
+    (void)hipGetDevice(&device);
     bytes = rounded;
     return FLUX2MI_OK;
 }
 void DevBuf::release() {
-    if (ptr) (void)hipFree(ptr);
+    if (ptr) f2_free(ptr);
     ptr = nullptr;
     bytes = 0;
+}
+
+extern "C" int flux2mi_ctx_memory_stats(flux2mi_ctx* ctx, size_t* active_bytes, size_t* peak_bytes, size_t* workspace_bytes) {
+    F2_REQUIRE(ctx, FLUX2MI_ERR_INVALID_ARG, "ctx_memory_stats: NULL ctx");
+    MemTable& t = mem();
+    std::lock_guard<std::mutex> g(t.mu);
+    const int d = ctx->device < FLUX2MI_MAX_DEVICES ? ctx->device : 0;
+    if (active_bytes) *active_bytes = t.active[d];
+    if (peak_bytes) *peak_bytes = t.peak[d];
+    if (workspace_bytes) *workspace_bytes = t.workspace[d];
+    return FLUX2MI_OK;
+}
+extern "C" int flux2mi_ctx_reset_peak(flux2mi_ctx* ctx) {
+    F2_REQUIRE(ctx, FLUX2MI_ERR_INVALID_ARG, "ctx_reset_peak: NULL ctx");
+    MemTable& t = mem();
+    std::lock_guard<std::mutex> g(t.mu);
+    const int d = ctx->device < FLUX2MI_MAX_DEVICES ? ctx->device : 0;
+    t.peak[d] = t.active[d] + t.workspace[d];
+    return FLUX2MI_OK;
+}
+extern "C" int flux2mi_ctx_trim(flux2mi_ctx* ctx, size_t* freed_bytes) {
+    F2_REQUIRE(ctx, FLUX2MI_ERR_INVALID_ARG, "ctx_trim: NULL ctx");
+    if (freed_bytes) *freed_bytes = 0;
+    F2_CHECK_HIP(hipSetDevice(ctx->device));
+    std::vector<DevBuf*> victims;
+    {
+        MemTable& t = mem();
+        std::lock_guard<std::mutex> g(t.mu);
+        if (t.generating > 0) return FLUX2MI_OK;   // the workspaces are in use (a hook called us): nothing to give back now
+        for (DevBuf* b : t.bufs)
+            if (b->ptr && !b->keep && b->device == ctx->device) victims.push_back(b);
+    }
+    if (victims.empty()) return FLUX2MI_OK;
+    F2_CHECK_HIP(hipDeviceSynchronize());   // work queued on any context of this device may still use them
+    size_t freed = 0;
+    for (DevBuf* b : victims) {
+        freed += b->bytes;
+        b->release();
+    }
+    if (freed_bytes) *freed_bytes = freed;
+    return FLUX2MI_OK;
 }
 
 // ------------------------------------------------------------------ context
@@ -89,7 +183,7 @@ extern "C" int flux2mi_ctx_destroy(flux2mi_ctx* ctx) {
 extern "C" int flux2mi_buffer_alloc(flux2mi_ctx* ctx, size_t bytes, void** out) {
     F2_REQUIRE(ctx && out && bytes > 0, FLUX2MI_ERR_INVALID_ARG, "buffer_alloc: bad argument");
     F2_CHECK_HIP(hipSetDevice(ctx->device));
-    hipError_t e = hipMalloc(out, bytes);
+    hipError_t e = f2_malloc(out, bytes);
     if (e != hipSuccess) {
         flux2mi_set_error("buffer_alloc: hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
         return FLUX2MI_ERR_OOM;
@@ -101,7 +195,7 @@ extern "C" int flux2mi_buffer_free(flux2mi_ctx* ctx, void* p) {
     if (!p) return FLUX2MI_OK;
     F2_CHECK_HIP(hipSetDevice(ctx->device));
     F2_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // queued work may still read it
-    F2_CHECK_HIP(hipFree(p));
+    f2_free(p);
     return FLUX2MI_OK;
 }
 // host -> device in stream order; the host bytes may be reused on return

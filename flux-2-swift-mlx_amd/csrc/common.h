@@ -42,12 +42,30 @@ void flux2mi_set_error(const char* fmt, ...);
     } while (0)
 
 // kernel classes for flux2mi_prof_begin (bit masks passed to prof_before/after)
-enum { PROF_LINEAR1 = 1 << 0, PROF_DIT_GEMM = 1 << 1, PROF_ATTENTION = 1 << 2, PROF_VAE_CONV = 1 << 3 };
+// classes 5 and 6 are HBM-bound: their prof_after "flops" argument carries the ALGORITHMIC BYTES of the launch
+enum { PROF_LINEAR1 = 1 << 0, PROF_DIT_GEMM = 1 << 1, PROF_ATTENTION = 1 << 2, PROF_VAE_CONV = 1 << 3, PROF_LINEAR2 = 1 << 4,
+       PROF_LN_MODULATE = 1 << 5, PROF_GN_APPLY = 1 << 6, PROF_PROJ_MLPOUT = 1 << 7 };
 
-// Grow-only device buffer (no allocation inside the steady-state loop).
+// Accounted device memory: every hipMalloc / hipFree of the library goes through these two, so that
+// flux2mi_ctx_memory_stats (the MLX.Memory.activeMemory / peakMemory / cacheMemory of the shim) reports what the library holds.
+// workspace = true: bytes of a trimmable DevBuf ("cache" in MLX's terms: held for reuse, given back by flux2mi_ctx_trim).
+#define FLUX2MI_MAX_DEVICES 16
+hipError_t f2_malloc(void** p, size_t bytes, bool workspace = false);
+void f2_free(void* p);
+// RAII mark of a running flux2mi_generate: flux2mi_ctx_trim leaves the workspaces alone while one is in flight.
+struct GenerationInFlight { GenerationInFlight(); ~GenerationInFlight(); };
+
+// Grow-only device buffer (no allocation inside the steady-state loop).  Registered process-wide so that flux2mi_ctx_trim can
+// release the ones of its device; `keep` marks buffers whose contents are built once (derived weights) and must survive a trim.
 struct DevBuf {
     void* ptr = nullptr;
     size_t bytes = 0;
+    int device = -1;
+    bool keep = false;
+    DevBuf();
+    ~DevBuf();
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
     int reserve(size_t n);
     void release();
     template <class T> T* as() { return reinterpret_cast<T*>(ptr); }

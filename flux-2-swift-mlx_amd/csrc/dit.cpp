@@ -310,9 +310,9 @@ extern "C" int flux2mi_dit_create(flux2mi_ctx* ctx, const flux2mi_dit_config* cf
     build_registry(m);
     for (Buf& b : m->bufs) {
         const size_t bytes = b.fp8 ? (size_t)b.rows * b.cols : (size_t)b.rows * b.cols * 2;
-        hipError_t e = b.fp8 ? hipMalloc((void**)&b.q, bytes) : hipMalloc((void**)&b.ptr, bytes);
+        hipError_t e = b.fp8 ? f2_malloc((void**)&b.q, bytes) : f2_malloc((void**)&b.ptr, bytes);
         if (e == hipSuccess && b.fp8) {
-            e = hipMalloc((void**)&b.scale, (size_t)b.rows * 4);
+            e = f2_malloc((void**)&b.scale, (size_t)b.rows * 4);
             m->param_bytes += (int64_t)b.rows * 4;
         }
         if (e != hipSuccess) {
@@ -332,9 +332,9 @@ extern "C" int flux2mi_dit_destroy(flux2mi_dit* m) {
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     for (Buf& b : m->bufs) {
-        if (b.ptr) (void)hipFree(b.ptr);
-        if (b.q) (void)hipFree(b.q);
-        if (b.scale) (void)hipFree(b.scale);
+        if (b.ptr) f2_free(b.ptr);
+        if (b.q) f2_free(b.q);
+        if (b.scale) f2_free(b.scale);
     }
     DevBuf* ws[] = {&m->stage_raw, &m->stage_bf16, &m->stage_w, &m->stage_d, &m->stage_q8, &m->hs, &m->xn, &m->qkv, &m->vt, &m->comb, &m->mods,
                     &m->rope, &m->lat_bf16, &m->xq, &m->xs, &m->splitk_ws, &m->qk8, &m->xbs, &m->xq2, &m->step_cache.hs_txt, &m->step_cache.mods_all};
@@ -417,11 +417,16 @@ extern "C" int flux2mi_dit_set_tensor_q8(flux2mi_dit* m, const char* name, const
 // (WeightLoader.mergeLoRAWeights, Loading/WeightLoader.swift:736-856, non-quantised branch: the
 // delta is formed in the weight dtype and added in it).  `name` is any checkpoint key of the target
 // weight (BFL or diffusers); the delta goes through the same layout transform as the weight did.
-extern "C" int flux2mi_dit_merge_lora(flux2mi_dit* m, const char* name, int dtype, const void* A, const void* B, int rank,
-                                      float scale) {
-    F2_REQUIRE(m && name && A && B && rank > 0, FLUX2MI_ERR_INVALID_ARG, "dit_merge_lora: bad argument");
-    F2_REQUIRE(dtype == FLUX2MI_F32 || dtype == FLUX2MI_BF16 || dtype == FLUX2MI_F16, FLUX2MI_ERR_INVALID_ARG,
-               "dit_merge_lora(%s): unsupported dtype %d", name, dtype);
+// The shapes come from the file, never from the target: A [a_rows = rank, a_cols = in], B [b_rows = out, b_cols = rank] must fit the
+// weight `name` addresses ([out, in]) or the call fails with FLUX2MI_ERR_SHAPE naming the layer (the reference fails with a shape
+// error in `matmul` for a LoRA trained at another width; reading rank x cols elements from a smaller tensor would run past it).
+// A and B may have different float dtypes (each is converted to bf16 on its own).
+extern "C" int flux2mi_dit_merge_lora_checked(flux2mi_dit* m, const char* name, int dtype_a, const void* A, int64_t a_rows, int64_t a_cols,
+                                              int dtype_b, const void* B, int64_t b_rows, int64_t b_cols, float scale) {
+    F2_REQUIRE(m && name && A && B && a_rows > 0 && a_rows <= INT32_MAX, FLUX2MI_ERR_INVALID_ARG, "dit_merge_lora: bad argument");
+    for (int dtype : {dtype_a, dtype_b})
+        F2_REQUIRE(dtype == FLUX2MI_F32 || dtype == FLUX2MI_BF16 || dtype == FLUX2MI_F16, FLUX2MI_ERR_INVALID_ARG,
+                   "dit_merge_lora(%s): unsupported dtype %d", name, dtype);
     auto it = m->slots.find(name);
     if (it == m->slots.end()) {
         flux2mi_set_error("dit_merge_lora: unknown key '%s'", name);
@@ -429,6 +434,12 @@ extern "C" int flux2mi_dit_merge_lora(flux2mi_dit* m, const char* name, int dtyp
     }
     const Slot& s = it->second;
     Buf& b = m->bufs[s.buf];
+    F2_REQUIRE(a_rows == b_cols, FLUX2MI_ERR_SHAPE, "dit_merge_lora(%s): lora_A [%lld, %lld] and lora_B [%lld, %lld] disagree on the rank", name,
+               (long long)a_rows, (long long)a_cols, (long long)b_rows, (long long)b_cols);
+    F2_REQUIRE(a_cols == s.cols && b_rows == s.rows, FLUX2MI_ERR_SHAPE,
+               "dit_merge_lora(%s): LoRA is for a [%lld, %lld] weight, this model's is [%d, %d] (a LoRA of another model width?)", name,
+               (long long)b_rows, (long long)a_cols, s.rows, s.cols);
+    const int rank = (int)a_rows;
     F2_REQUIRE(!b.fp8, FLUX2MI_ERR_UNSUPPORTED,
                "dit_merge_lora(%s): fp8 weights (merge into the bf16 checkpoint before loading with weight_format 1)", name);
     F2_REQUIRE(b.got_rows() >= b.rows, FLUX2MI_ERR_NOT_LOADED, "dit_merge_lora(%s): base weight not loaded", name);
@@ -437,16 +448,17 @@ extern "C" int flux2mi_dit_merge_lora(flux2mi_dit* m, const char* name, int dtyp
     const int64_t rows = s.rows, cols = s.cols;
     // A, B -> bf16 on the device; A^T so that delta = B (A^T)^T is the library's C = X W^T form
     const size_t na = (size_t)rank * cols, nb = (size_t)rows * rank;
-    F2_TRY(m->stage_raw.reserve((na > nb ? na : nb) * dtype_size(dtype)));
+    const size_t raw_a = na * dtype_size(dtype_a), raw_b = nb * dtype_size(dtype_b);
+    F2_TRY(m->stage_raw.reserve(raw_a > raw_b ? raw_a : raw_b));
     F2_TRY(m->stage_bf16.reserve((2 * na + nb) * 2 + 1024));
     uint16_t* a16 = m->stage_bf16.as<uint16_t>();
     uint16_t* at16 = a16 + ((na + 127) & ~(size_t)127);
     uint16_t* b16 = at16 + ((na + 127) & ~(size_t)127);
-    F2_CHECK_HIP(hipMemcpyAsync(m->stage_raw.ptr, A, na * dtype_size(dtype), hipMemcpyDefault, st));
-    F2_LAUNCH(launch_convert_to_bf16(st, m->stage_raw.ptr, dtype, a16, (int64_t)na), "lora A->bf16");
+    F2_CHECK_HIP(hipMemcpyAsync(m->stage_raw.ptr, A, raw_a, hipMemcpyDefault, st));
+    F2_LAUNCH(launch_convert_to_bf16(st, m->stage_raw.ptr, dtype_a, a16, (int64_t)na), "lora A->bf16");
     F2_LAUNCH(launch_transpose_bf16(st, a16, at16, rank, (int)cols), "lora A^T");
-    F2_CHECK_HIP(hipMemcpyAsync(m->stage_raw.ptr, B, nb * dtype_size(dtype), hipMemcpyDefault, st));
-    F2_LAUNCH(launch_convert_to_bf16(st, m->stage_raw.ptr, dtype, b16, (int64_t)nb), "lora B->bf16");
+    F2_CHECK_HIP(hipMemcpyAsync(m->stage_raw.ptr, B, raw_b, hipMemcpyDefault, st));
+    F2_LAUNCH(launch_convert_to_bf16(st, m->stage_raw.ptr, dtype_b, b16, (int64_t)nb), "lora B->bf16");
     // delta (bf16, checkpoint row order) = scale * B A
     F2_TRY(m->stage_w.reserve((size_t)rows * cols * 2));
     GemmProblem p = mk(b16, rank, at16, rank, m->stage_w.ptr, (int)cols, (int)rows, (int)cols, rank, EPI_BF16);
@@ -459,6 +471,32 @@ extern "C" int flux2mi_dit_merge_lora(flux2mi_dit* m, const char* name, int dtyp
     F2_LAUNCH(launch_bf16_add_inplace(st, b.ptr + off, m->stage_d.as<uint16_t>() + off, rows * cols), "lora merge");
     F2_CHECK_HIP(hipStreamSynchronize(st));
     m->lora_merged = true;
+    return FLUX2MI_OK;
+}
+
+// The unchecked form: A and B are TRUSTED to be [rank, in] and [out, rank] of the addressed weight's own in / out (callers that built
+// the factors from flux2mi_dit_slot_shape, e.g. synthetic tests); files go through flux2mi_dit_merge_lora_checked.
+extern "C" int flux2mi_dit_merge_lora(flux2mi_dit* m, const char* name, int dtype, const void* A, const void* B, int rank,
+                                      float scale) {
+    F2_REQUIRE(m && name && rank > 0, FLUX2MI_ERR_INVALID_ARG, "dit_merge_lora: bad argument");
+    auto it = m->slots.find(name);
+    if (it == m->slots.end()) {
+        flux2mi_set_error("dit_merge_lora: unknown key '%s'", name);
+        return FLUX2MI_ERR_UNKNOWN_KEY;
+    }
+    return flux2mi_dit_merge_lora_checked(m, name, dtype, A, rank, it->second.cols, dtype, B, it->second.rows, rank, scale);
+}
+
+// [out, in] of the weight a checkpoint key addresses (FLUX2MI_ERR_UNKNOWN_KEY when the model has none of that name)
+extern "C" int flux2mi_dit_slot_shape(flux2mi_dit* m, const char* name, int64_t* rows, int64_t* cols) {
+    F2_REQUIRE(m && name, FLUX2MI_ERR_INVALID_ARG, "dit_slot_shape: NULL argument");
+    auto it = m->slots.find(name);
+    if (it == m->slots.end()) {
+        flux2mi_set_error("dit_slot_shape: unknown key '%s'", name);
+        return FLUX2MI_ERR_UNKNOWN_KEY;
+    }
+    if (rows) *rows = it->second.rows;
+    if (cols) *cols = it->second.cols;
     return FLUX2MI_OK;
 }
 
@@ -934,7 +972,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         return p;
     };
     // LayerNorm + modulate of the text rows with (sh0, sc0) and of the live image rows with (sh1, sc1)
-    auto ln_mod = [&](const float* sh0, const float* sc0, const float* sh1, const float* sc1) {
+    auto ln_mod_launch = [&](const float* sh0, const float* sc0, const float* sh1, const float* sc1) {
         if (img0 == s_txt) {
             return f8 ? launch_layernorm_modulate_fp8(st, hs, xq, xs, S, d, s_txt, sh0, sc0, sh1, sc1)
                       : launch_layernorm_modulate(st, hs, xn, S, d, s_txt, sh0, sc0, sh1, sc1);
@@ -945,6 +983,13 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
         if (r) return r;
         return f8 ? launch_layernorm_modulate_fp8(st, hs + o, xq + o, xs + img0, n_img, d, 0, sh1, sc1, sh1, sc1)
                   : launch_layernorm_modulate(st, hs + o, xn + o, n_img, d, 0, sh1, sc1, sh1, sc1);
+    };
+    // algorithmic bytes of one call: the f32 residual rows read once, the normalised rows written once (bf16, or e4m3 + a scale)
+    auto ln_mod = [&](const float* sh0, const float* sc0, const float* sh1, const float* sc1) {
+        prof_before(m->ctx, PROF_LN_MODULATE);
+        const int r = ln_mod_launch(sh0, sc0, sh1, sc1);
+        prof_after(m->ctx, PROF_LN_MODULATE, (double)(s_txt + n_img) * ((double)d * (f8 ? 5.0 : 6.0) + (f8 ? 4.0 : 0.0)));
+        return r;
     };
     // quantise rows of a bf16 activation into xq/xs before the GEMM that consumes it (fp8 only)
     auto quant = [&](const uint16_t* a, int ld, int cols) {
@@ -1098,7 +1143,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
             p[1] = blk(comb, d, img0, w.proj[1], hs + (size_t)img0 * d, d, n_img, d, d, EPI_GATE_RESID);
             p[1].vec = mod_img + 2 * d;
             if (bsa) { with_blocks(p[0], 0); with_blocks(p[1], img0); }
-            F2_TRY(run_gemm(m, p, 2, 0, "dbl.proj"));
+            F2_TRY(run_gemm(m, p, 2, PROF_PROJ_MLPOUT, "dbl.proj"));
         }
         // feed-forward half: LN -> modulate(set 1) -> Linear(d->6d) SwiGLU -> Linear(3d->d)
         F2_LAUNCH(ln_mod(mod_txt + 3 * d, mod_txt + 4 * d, mod_img + 3 * d, mod_img + 4 * d), "ln_mod(ff)");
@@ -1120,7 +1165,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
             p[1] = blk(comb, 3 * d, img0, w.mlp_out[1], hs + (size_t)img0 * d, d, n_img, d, 3 * d, EPI_GATE_RESID);
             p[1].vec = mod_img + 5 * d;
             if (bsa) { with_blocks(p[0], 0); with_blocks(p[1], img0); }
-            F2_TRY(run_gemm(m, p, 2, 0, "dbl.mlp_out"));
+            F2_TRY(run_gemm(m, p, 2, PROF_PROJ_MLPOUT, "dbl.mlp_out"));
         }
     }
 
@@ -1184,7 +1229,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
                 p[r].vec = mod_sgl + 2 * d;
                 if (bsa) with_blocks(p[r], rng0[r]);
             }
-            F2_TRY(run_gemm(m, p, n_rng, 0, "single.linear2"));
+            F2_TRY(run_gemm(m, p, n_rng, PROF_LINEAR2, "single.linear2"));
         }
     }
 
@@ -1296,7 +1341,7 @@ extern "C" int flux2mi_kv_cache_create(flux2mi_dit* m, int s_txt, int s_ref, flu
     c->s_ref = s_ref;
     c->layer_elems = (size_t)2 * s_ref * m->cfg.dim;
     const size_t bytes = c->layer_elems * (size_t)(m->cfg.n_double + m->cfg.n_single) * 2;
-    hipError_t e = hipMalloc((void**)&c->data, bytes);
+    hipError_t e = f2_malloc((void**)&c->data, bytes);
     if (e != hipSuccess) {
         flux2mi_set_error("kv_cache_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         delete c;
@@ -1323,7 +1368,7 @@ extern "C" int flux2mi_kv_cache_destroy(flux2mi_kv_cache* c) {
     if (!c) return FLUX2MI_OK;
     (void)hipSetDevice(c->dit->ctx->device);
     (void)hipStreamSynchronize(c->dit->ctx->stream);
-    if (c->data) (void)hipFree(c->data);
+    if (c->data) f2_free(c->data);
     delete c;
     return FLUX2MI_OK;
 }
@@ -1508,8 +1553,8 @@ extern "C" int flux2mi_op_attention_qk8_blocks(flux2mi_ctx* ctx, const void* q8,
     F2_TRY(ctx->scratch.reserve((size_t)heads * 128 * s_pad * 2 + 256 * 4));
     uint16_t* vt = ctx->scratch.as<uint16_t>();
     F2_CHECK_HIP(hipMemsetAsync(vt, 0, (size_t)heads * 128 * s_pad * 2, ctx->stream));
-    // v_transpose reads V at column v_col0 = 2 * heads * 128 of a [S, ldqkv] matrix: hand it the V matrix shifted back by that
-    F2_LAUNCH(launch_v_transpose_only(ctx->stream, reinterpret_cast<const uint16_t*>(v) - 2 * d, d, S, heads, vt, s_pad), "v_transpose");
+    // a V matrix of its own ([S, d], first V column 0), not the fused [q | k | v] row
+    F2_LAUNCH(launch_v_transpose_only(ctx->stream, reinterpret_cast<const uint16_t*>(v), d, S, heads, vt, s_pad, /*v_col0=*/0), "v_transpose");
     const int r = launch_attention64b_qk8(ctx->stream, reinterpret_cast<const uint8_t*>(q8), reinterpret_cast<const uint8_t*>(k8), d, q_exp, k_exp, vt, s_pad,
                                           reinterpret_cast<uint16_t*>(out), d, S, S, heads, !attention_uses_fixed_offset(score_bound_log2, true),
                                           reinterpret_cast<uint8_t*>(out8), d, reinterpret_cast<uint8_t*>(bs), bs_ld);

@@ -7,9 +7,64 @@
 // the decoded u8 images.  Both run on the CONTEXT'S stream, in stream order with flux2mi_textenc_forward / flux2mi_generate:
 // no host synchronisation, no second stream to hand over to.  One process per GPU; the 128-byte unique id travels from rank 0
 // to the others through whatever side channel the host already has (a TCP store, a file, an environment variable).
-#include <rccl/rccl.h>
+//
+// RCCL is bound at run time (dlopen on the first flux2mi_dp_unique_id / flux2mi_dp_init), not linked: single-GPU hosts and hosts whose
+// ROCm lives elsewhere load libflux2mi.so without it; the dp entry points then return FLUX2MI_ERR_UNSUPPORTED naming what was tried.
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and constants only
+#include <stdlib.h>
+
+#include <mutex>
 
 #include "common.h"
+
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    std::string tried;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+void rccl_open() {
+    std::vector<std::string> names;
+    if (const char* e = getenv("FLUX2MI_RCCL_LIB")) names.push_back(e);                 // an explicit file
+    if (const char* e = getenv("ROCM_PATH")) names.push_back(std::string(e) + "/lib/librccl.so.1");
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    names.push_back("librccl.so.1");                                                   // the loader's search path / an already loaded RCCL
+    names.push_back("librccl.so");
+    for (const std::string& n : names) {
+        g_rccl.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (g_rccl.handle) break;
+        g_rccl.tried += (g_rccl.tried.empty() ? "" : ", ") + n;
+    }
+    if (!g_rccl.handle) return;
+    bool ok = true;
+    auto sym = [&](const char* name) { void* p = dlsym(g_rccl.handle, name); if (!p) { ok = false; g_rccl.tried = std::string("symbol ") + name; } return p; };
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(sym("ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(sym("ncclCommInitRank"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(sym("ncclCommDestroy"));
+    g_rccl.Broadcast = reinterpret_cast<decltype(g_rccl.Broadcast)>(sym("ncclBroadcast"));
+    g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(sym("ncclAllGather"));
+    g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(sym("ncclAllReduce"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) { dlclose(g_rccl.handle); g_rccl.handle = nullptr; }
+}
+// 0 when RCCL is bound; FLUX2MI_ERR_UNSUPPORTED (with the error string set) otherwise
+int rccl_require() {
+    std::call_once(g_rccl_once, rccl_open);
+    if (g_rccl.handle) return FLUX2MI_OK;
+    flux2mi_set_error("data parallelism needs RCCL and none could be loaded (tried: %s); set FLUX2MI_RCCL_LIB or ROCM_PATH", g_rccl.tried.c_str());
+    return FLUX2MI_ERR_UNSUPPORTED;
+}
+}  // namespace
 
 struct flux2mi_dp {
     ncclComm_t comm = nullptr;
@@ -22,15 +77,16 @@ static_assert(NCCL_UNIQUE_ID_BYTES == FLUX2MI_DP_UNIQUE_ID_BYTES, "unique id siz
     do {                                                                                                      \
         ncclResult_t _r = (expr);                                                                             \
         if (_r != ncclSuccess) {                                                                              \
-            flux2mi_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r));          \
+            flux2mi_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, g_rccl.GetErrorString(_r));          \
             return FLUX2MI_ERR_HIP;                                                                           \
         }                                                                                                     \
     } while (0)
 
 extern "C" int flux2mi_dp_unique_id(uint8_t* id) {
     F2_REQUIRE(id, FLUX2MI_ERR_INVALID_ARG, "dp_unique_id: NULL");
+    F2_TRY(rccl_require());
     ncclUniqueId u;
-    F2_CHECK_NCCL(ncclGetUniqueId(&u));
+    F2_CHECK_NCCL(g_rccl.GetUniqueId(&u));
     memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
     return FLUX2MI_OK;
 }
@@ -38,15 +94,16 @@ extern "C" int flux2mi_dp_unique_id(uint8_t* id) {
 extern "C" int flux2mi_dp_init(flux2mi_ctx* ctx, int rank, int world, const uint8_t* id) {
     F2_REQUIRE(ctx && id && world >= 1 && rank >= 0 && rank < world, FLUX2MI_ERR_INVALID_ARG, "dp_init: rank %d of %d", rank, world);
     F2_REQUIRE(ctx->dp == nullptr, FLUX2MI_ERR_INVALID_ARG, "dp_init: the context already has a communicator (flux2mi_dp_finalize first)");
+    F2_TRY(rccl_require());
     F2_CHECK_HIP(hipSetDevice(ctx->device));
     ncclUniqueId u;
     memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
     flux2mi_dp* d = new flux2mi_dp();
     d->rank = rank;
     d->world = world;
-    ncclResult_t r = ncclCommInitRank(&d->comm, world, u, rank);
+    ncclResult_t r = g_rccl.CommInitRank(&d->comm, world, u, rank);
     if (r != ncclSuccess) {
-        flux2mi_set_error("dp_init: ncclCommInitRank(rank %d of %d, device %d) -> %s", rank, world, ctx->device, ncclGetErrorString(r));
+        flux2mi_set_error("dp_init: ncclCommInitRank(rank %d of %d, device %d) -> %s", rank, world, ctx->device, g_rccl.GetErrorString(r));
         delete d;
         return FLUX2MI_ERR_HIP;
     }
@@ -59,11 +116,11 @@ extern "C" int flux2mi_dp_finalize(flux2mi_ctx* ctx) {
     if (!ctx->dp) return FLUX2MI_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    ncclResult_t r = ncclCommDestroy(ctx->dp->comm);
+    ncclResult_t r = g_rccl.CommDestroy(ctx->dp->comm);
     delete ctx->dp;
     ctx->dp = nullptr;
     if (r != ncclSuccess) {
-        flux2mi_set_error("dp_finalize: ncclCommDestroy -> %s", ncclGetErrorString(r));
+        flux2mi_set_error("dp_finalize: ncclCommDestroy -> %s", g_rccl.GetErrorString(r));
         return FLUX2MI_ERR_HIP;
     }
     return FLUX2MI_OK;
@@ -78,7 +135,7 @@ extern "C" int flux2mi_dp_broadcast_embeddings(flux2mi_ctx* ctx, void* embedding
     F2_REQUIRE(ctx->dp, FLUX2MI_ERR_NOT_LOADED, "dp_broadcast_embeddings: flux2mi_dp_init has not been called on this context");
     F2_REQUIRE(root >= 0 && root < ctx->dp->world, FLUX2MI_ERR_INVALID_ARG, "dp_broadcast_embeddings: root %d of %d", root, ctx->dp->world);
     F2_CHECK_HIP(hipSetDevice(ctx->device));
-    F2_CHECK_NCCL(ncclBroadcast(embeddings, embeddings, (size_t)elems, ncclBfloat16, root, ctx->dp->comm, ctx->stream));
+    F2_CHECK_NCCL(g_rccl.Broadcast(embeddings, embeddings, (size_t)elems, ncclBfloat16, root, ctx->dp->comm, ctx->stream));
     return FLUX2MI_OK;
 }
 
@@ -88,7 +145,7 @@ extern "C" int flux2mi_dp_all_gather_images(flux2mi_ctx* ctx, const uint8_t* loc
     F2_REQUIRE(ctx && local_images && all_images && bytes_per_rank > 0, FLUX2MI_ERR_INVALID_ARG, "dp_all_gather_images: bad argument");
     F2_REQUIRE(ctx->dp, FLUX2MI_ERR_NOT_LOADED, "dp_all_gather_images: flux2mi_dp_init has not been called on this context");
     F2_CHECK_HIP(hipSetDevice(ctx->device));
-    F2_CHECK_NCCL(ncclAllGather(local_images, all_images, (size_t)bytes_per_rank, ncclUint8, ctx->dp->comm, ctx->stream));
+    F2_CHECK_NCCL(g_rccl.AllGather(local_images, all_images, (size_t)bytes_per_rank, ncclUint8, ctx->dp->comm, ctx->stream));
     return FLUX2MI_OK;
 }
 
@@ -100,7 +157,7 @@ extern "C" int flux2mi_dp_all_reduce_max(flux2mi_ctx* ctx, double* value) {
     F2_TRY(ctx->scratch.reserve(256));
     double* d = ctx->scratch.as<double>();
     F2_CHECK_HIP(hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    F2_CHECK_NCCL(ncclAllReduce(d, d, 1, ncclDouble, ncclMax, ctx->dp->comm, ctx->stream));
+    F2_CHECK_NCCL(g_rccl.AllReduce(d, d, 1, ncclDouble, ncclMax, ctx->dp->comm, ctx->stream));
     F2_CHECK_HIP(hipMemcpyAsync(value, d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     F2_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     return FLUX2MI_OK;

@@ -175,9 +175,10 @@ int launch_qk_norm_rope_vt(hipStream_t stream, uint16_t* qkv, int ldqkv, int S, 
                            const uint16_t* kscale1, const float* cos_tab, const float* sin_tab,
                            uint16_t* vt, int s_pad, float q_mul = 1.0f,
                            uint8_t* qk8 = nullptr, int q8_exp = 0, int k8_exp = 0);
-// V half of the above only (standalone attention op).
+// V half of the above only (standalone attention op).  v_col0: first V column of a row (default: 2 d, the fused [q | k | v] row;
+// 0 for a V matrix of its own).
 int launch_v_transpose_only(hipStream_t stream, const uint16_t* qkv, int ldqkv, int S, int heads, uint16_t* vt,
-                            int s_pad);
+                            int s_pad, int v_col0 = -1);
 // cos/sin f32 [S,128] from position ids i32 [S,4] (Flux2RoPE.swift:129-169); rows [0,s_txt)
 // come from txt_ids, the rest from img_ids.
 // Copy the V^T columns of keys [key0, key0 + nkeys) between the attention operand vt

@@ -317,16 +317,18 @@ extern "C" int flux2mi_dit_load_lora_safetensors(flux2mi_dit* dit, const char* p
         auto b = ts.find(base + ".lora_B.weight");
         if (b == ts.end()) continue;
         const TensorInfo &A = kv.second, &B = b->second;
-        const int dt = st_dtype(A.dtype);
-        if (dt < 0 || st_dtype(B.dtype) != dt || A.shape.size() != 2 || B.shape.size() != 2 || A.shape[0] != B.shape[1] ||
-            !bytes_match(A, dt == FLUX2MI_F32 ? 4 : 2) || !bytes_match(B, dt == FLUX2MI_F32 ? 4 : 2)) {
-            flux2mi_set_error("load_lora: '%s': pair '%s': A [rank, in] / B [out, rank] of one float dtype expected", path, base.c_str());
+        const int dta = st_dtype(A.dtype), dtb = st_dtype(B.dtype);
+        if (dta < 0 || dtb < 0 || A.shape.size() != 2 || B.shape.size() != 2 || A.shape[0] != B.shape[1] ||
+            !bytes_match(A, dta == FLUX2MI_F32 ? 4 : 2) || !bytes_match(B, dtb == FLUX2MI_F32 ? 4 : 2)) {
+            flux2mi_set_error("load_lora: '%s': pair '%s': float A [rank, in] / B [out, rank] expected", path, base.c_str());
             return FLUX2MI_ERR_SHAPE;
         }
         std::string layer = base;
         for (const char* pre : {"base_model.model.", "transformer.", "diffusion_model."})
             if (layer.compare(0, strlen(pre), pre) == 0) layer = layer.substr(strlen(pre));
-        const int r = flux2mi_dit_merge_lora(dit, (layer + ".weight").c_str(), dt, data + A.begin, data + B.begin, (int)A.shape[0], s);
+        // shapes from the FILE: a LoRA of another model width with the same key names is a shape error, not an over-read of the mapping
+        const int r = flux2mi_dit_merge_lora_checked(dit, (layer + ".weight").c_str(), dta, data + A.begin, A.shape[0], A.shape[1], dtb,
+                                                     data + B.begin, B.shape[0], B.shape[1], s);
         if (r == FLUX2MI_ERR_UNKNOWN_KEY) {
             if (!unmatched++) first_unmatched = layer;
             continue;

@@ -454,10 +454,11 @@ int launch_qk_norm_rope_vt(hipStream_t stream, uint16_t* qkv, int ldqkv, int S, 
 }
 
 int launch_v_transpose_only(hipStream_t stream, const uint16_t* qkv, int ldqkv, int S, int heads, uint16_t* vt,
-                            int s_pad) {
-    if (S <= 0 || heads <= 0 || (ldqkv & 7) || s_pad < attn_s_pad(S)) return 1;
+                            int s_pad, int v_col0) {
+    if (v_col0 < 0) v_col0 = 2 * heads * 128;   // the fused [q | k | v] row
+    if (S <= 0 || heads <= 0 || (ldqkv & 7) || (v_col0 & 7) || v_col0 + heads * 128 > ldqkv || s_pad < attn_s_pad(S)) return 1;
     hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, heads), dim3(256), 0, stream, qkv, ldqkv, S,
-                       2 * heads * 128, vt, s_pad);
+                       v_col0, vt, s_pad);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

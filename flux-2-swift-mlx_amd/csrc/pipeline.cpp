@@ -60,6 +60,7 @@ extern "C" int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae*
                "generate: strength %.3f < 1 requires init_latents", strength);
     F2_CHECK_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    GenerationInFlight in_flight;   // flux2mi_ctx_trim (MLX.Memory.clearCache) from a callback leaves the workspaces alone
 
     int H = 0, W = 0;
     flux2mi_validate_dimensions(p->height, p->width, &H, &W);  // :1191

@@ -131,7 +131,7 @@ extern "C" int flux2mi_textenc_create(flux2mi_ctx* ctx, const flux2mi_textenc_co
     }
     for (TBuf& b : m->bufs) {
         const size_t bytes = (size_t)b.rows * b.cols * 2;
-        hipError_t e = hipMalloc((void**)&b.ptr, bytes);
+        hipError_t e = f2_malloc((void**)&b.ptr, bytes);
         if (e != hipSuccess) {
             flux2mi_set_error("textenc_create: hipMalloc(%zu) for %s failed: %s", bytes, b.label.c_str(), hipGetErrorString(e));
             flux2mi_textenc_destroy(m);
@@ -148,7 +148,7 @@ extern "C" int flux2mi_textenc_destroy(flux2mi_textenc* m) {
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     for (TBuf& b : m->bufs)
-        if (b.ptr) (void)hipFree(b.ptr);
+        if (b.ptr) f2_free(b.ptr);
     DevBuf* ws[] = {&m->stage_raw, &m->stage_bf16, &m->stage_gu, &m->hs, &m->xn, &m->qkv, &m->vt, &m->attn, &m->hid, &m->ones, &m->splitk_ws};
     for (DevBuf* w : ws) w->release();
     delete m;

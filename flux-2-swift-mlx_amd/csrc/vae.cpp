@@ -219,7 +219,7 @@ extern "C" int flux2mi_vae_create(flux2mi_ctx* ctx, const flux2mi_vae_config* cf
         if (p.kind == PK_CONV_W) bytes = (size_t)pad32((int)p.shape[0]) * (p.i_pad ? p.i_pad : p.shape[1]) * p.shape[2] * p.shape[3] * 2;
         else if (p.kind == PK_LINEAR_W) bytes = (size_t)p.shape[0] * p.shape[1] * 2;
         else bytes = (size_t)p.shape[0] * 4;
-        hipError_t e = hipMalloc(&p.ptr, bytes);
+        hipError_t e = f2_malloc(&p.ptr, bytes);
         if (e != hipSuccess) {
             flux2mi_set_error("vae_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
             flux2mi_vae_destroy(v);
@@ -235,7 +235,7 @@ extern "C" int flux2mi_vae_destroy(flux2mi_vae* v) {
     (void)hipSetDevice(v->ctx->device);
     (void)hipStreamSynchronize(v->ctx->stream);
     for (Param& p : v->params)
-        if (p.ptr) (void)hipFree(p.ptr);
+        if (p.ptr) f2_free(p.ptr);
     DevBuf* bufs[] = {&v->stage_raw, &v->stage_bf16, &v->act[0], &v->act[1], &v->act[2], &v->act[3], &v->aq, &v->ak,
                       &v->av, &v->avt, &v->scores, &v->probs, &v->gn_partial, &v->gn_ab, &v->zin, &v->img_in, &v->gn_chan};
     for (DevBuf* b : bufs) b->release();
@@ -299,6 +299,7 @@ extern "C" int flux2mi_vae_finalize(flux2mi_vae* v) {
         const ConvW& c = v->upsample[i];
         if (c.w < 0 || c.ks != 3 || c.cin % 64 != 0) continue;
         const int cout_pad = pad32(c.cout);
+        v->up_phase[i].keep = true;   // derived weights, built once: not a workspace flux2mi_ctx_trim may release
         F2_TRY(v->up_phase[i].reserve((size_t)16 * cout_pad * c.cin * 2));
         F2_LAUNCH(launch_upsample_phase_weights(v->ctx->stream, reinterpret_cast<const uint16_t*>(v->params[c.w].ptr), cout_pad, c.cin,
                                                 v->up_phase[i].as<uint16_t>()), "upsample_phase_weights");
@@ -394,7 +395,11 @@ struct Dec {
     // GroupNorm(+SiLU) of plain x -> zero-haloed y
     int gn_padded(const GNW& g, const uint16_t* x, uint16_t* y, int H, int Wd, int silu) {
         F2_TRY(gn_affine(g, x, (int64_t)H * Wd));
-        F2_LAUNCH(launch_groupnorm_apply_padded(st, x, y, H, Wd, g.c, v->gn_ab.as<float>(), silu), "groupnorm_apply_padded");
+        prof_before(v->ctx, PROF_GN_APPLY);
+        const int r = launch_groupnorm_apply_padded(st, x, y, H, Wd, g.c, v->gn_ab.as<float>(), silu);
+        // algorithmic bytes: the plain bf16 image read once, the zero-haloed bf16 image written once
+        prof_after(v->ctx, PROF_GN_APPLY, 2.0 * g.c * ((double)H * Wd + (double)(H + 2) * (Wd + 2)));
+        F2_LAUNCH(r, "groupnorm_apply_padded");
         if (y == stats_of) stats_of = nullptr;
         return FLUX2MI_OK;
     }

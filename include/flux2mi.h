@@ -62,6 +62,18 @@ const char* flux2mi_last_error(void);
 int flux2mi_ctx_create(int device, void* hip_stream, flux2mi_ctx** out);
 int flux2mi_ctx_destroy(flux2mi_ctx* ctx);
 int flux2mi_ctx_sync(flux2mi_ctx* ctx);                 /* == MLX eval(): stream synchronise */
+/* MLX.Memory.activeMemory / peakMemory / cacheMemory (mlx-swift 0.31.6 `Memory`; called at Flux2CLI/InpaintCommand.swift:253-255 and
+ * CompareEncoders.swift:112,142).  Device bytes the library holds on the context's GPU, from its own allocation table (every
+ * allocation of the library is accounted; the caller's own hipMallocs are not): `active` = weights, flux2mi_array / flux2mi_buffer
+ * objects, KV caches and derived weights; `workspace` = the grow-only activation / staging workspaces kept between calls for reuse
+ * (MLX's "cache": memory held but given back on request); `peak` = the largest active + workspace seen since the process started or
+ * since flux2mi_ctx_reset_peak (MLX: `Memory.peakMemory = 0`).  Any of the three pointers may be NULL. */
+int flux2mi_ctx_memory_stats(flux2mi_ctx* ctx, size_t* active_bytes, size_t* peak_bytes, size_t* workspace_bytes);
+int flux2mi_ctx_reset_peak(flux2mi_ctx* ctx);
+/* MLX.Memory.clearCache() (Flux2CLI/InpaintCommand.swift:271): synchronises the device and releases every workspace of this GPU;
+ * the next forward / decode reserves what it needs again (results unchanged).  Called from a callback of a running
+ * flux2mi_generate it releases nothing.  *freed_bytes (may be NULL) = bytes given back. */
+int flux2mi_ctx_trim(flux2mi_ctx* ctx, size_t* freed_bytes);
 /* Plain device buffers for a host without a HIP binding of its own (the Swift shim: prompt embeddings, token ids, image bytes).
  * upload: the host bytes may be reused on return; download: behind everything queued on the stream, synchronises. */
 int flux2mi_buffer_alloc(flux2mi_ctx* ctx, size_t bytes, void** out);
@@ -266,14 +278,21 @@ int flux2mi_dit_load_safetensors(flux2mi_dit* dit, const char* path, int* n_load
 /* One quanto qint8 tensor: data int8 [rows,cols], scale f32 [rows]; weight = data * scale (:347-363). */
 int flux2mi_dit_set_tensor_q8(flux2mi_dit* dit, const char* name, const int8_t* data, const float* scale,
                               int64_t rows, int64_t cols);
-/* LoRA merge into the resident bf16 weight: W += scale * (B A), A [rank,in], B [out,rank] of `dtype`
- * (WeightLoader.mergeLoRAWeights :736-856, LoRA/LoRAConfig.swift:7-35; scale = alpha/rank x user scale).
- * `name` = checkpoint key of the target weight.  Not available for weight_format 1. */
+/* LoRA merge into the resident bf16 weight: W += scale * (B A) (WeightLoader.mergeLoRAWeights :736-856, LoRA/LoRAConfig.swift:7-35;
+ * scale = alpha/rank x user scale).  `name` = checkpoint key of the target weight.  Not available for weight_format 1.
+ * _checked: A [a_rows = rank, a_cols = in] of dtype_a, B [b_rows = out, b_cols = rank] of dtype_b, shapes as the FILE states them;
+ * FLUX2MI_ERR_SHAPE (naming the layer) unless they fit the addressed [out, in] weight — what the reference's matmul reports for a
+ * LoRA of another model width.  The short form trusts A / B to have the target's own in / out (flux2mi_dit_slot_shape). */
+int flux2mi_dit_merge_lora_checked(flux2mi_dit* dit, const char* name, int dtype_a, const void* A, int64_t a_rows, int64_t a_cols,
+                                   int dtype_b, const void* B, int64_t b_rows, int64_t b_cols, float scale);
 int flux2mi_dit_merge_lora(flux2mi_dit* dit, const char* name, int dtype, const void* A, const void* B, int rank,
-                           float scale); /* `loadLoRA(LoRAConfig)`, weights side (Flux2Pipeline.swift:618-663, LoRA/LoRALoader.swift:132-140, WeightLoader.swift:736-856):
- * every `<layer>.lora_A.weight` / `.lora_B.weight` pair of the file, prefixes `base_model.model.` / `transformer.` /
- * `diffusion_model.` stripped in sequence, scale = (metadata lora_alpha / lora_rank, default 1) x user_scale.  Layers the
- * transformer does not have are skipped and counted; a file matching no layer is FLUX2MI_ERR_INVALID_ARG. */
+                           float scale);
+int flux2mi_dit_slot_shape(flux2mi_dit* dit, const char* name, int64_t* rows, int64_t* cols);
+/* `loadLoRA(LoRAConfig)`, weights side (Flux2Pipeline.swift:618-663, LoRA/LoRALoader.swift:132-140, WeightLoader.swift:736-856):
+ * every `<layer>.lora_A.weight` / `.lora_B.weight` pair of the file (each factor in its own float dtype), prefixes
+ * `base_model.model.` / `transformer.` / `diffusion_model.` stripped in sequence, scale = (metadata lora_alpha / lora_rank,
+ * default 1) x user_scale.  Layers the transformer does not have are skipped and counted; a file matching no layer is
+ * FLUX2MI_ERR_INVALID_ARG; a pair whose shapes do not fit its layer is FLUX2MI_ERR_SHAPE. */
 int flux2mi_dit_load_lora_safetensors(flux2mi_dit* dit, const char* path, float user_scale, int* n_merged, int* n_unmatched);
 /* error if a tensor is missing */
 int64_t flux2mi_dit_param_bytes(const flux2mi_dit* dit);

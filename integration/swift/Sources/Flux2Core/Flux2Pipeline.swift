@@ -31,6 +31,7 @@ import CFlux2MI
 import CoreGraphics
 import Foundation
 import ImageIO
+import MLX
 
 // MARK: - Public types of the generation API (Flux2Pipeline.swift:16-87)
 
@@ -655,7 +656,7 @@ public final class Flux2Pipeline: @unchecked Sendable {
         let n = flux2mi_reference_position_ids(&lh, &lw, Int32(images.count), 10, &ids, Int32(total))
         guard Int(n) == total else { throw Flux2Error.generationFailed("reference position ids") }
         // one contiguous [1, total, 128] array: the packed sequences back to back
-        let all = try MLXArray.uninitialized([1, total, 128])
+        let all = try rethrowing { try MLXArray.uninitialized([1, total, 128]) }
         var off = 0
         for a in parts {
             try check(flux2mi_array_copy_to(MIContext.current, a.handle, all.data + off, Int64(a.count)))
@@ -687,11 +688,11 @@ extension Flux2Pipeline {
         let resized = try DeviceBuffer(bytes: targetHeight * targetWidth * 4)
         try check(flux2mi_image_resample_u8(MIContext.current, src.ptr.assumingMemoryBound(to: UInt8.self), Int32(image.height), Int32(image.width), 4, nil,
                                             resized.ptr.assumingMemoryBound(to: UInt8.self), Int32(targetHeight), Int32(targetWidth)))
-        let x = try MLXArray.uninitialized([1, 3, targetHeight, targetWidth])
+        let x = try rethrowing { try MLXArray.uninitialized([1, 3, targetHeight, targetWidth]) }
         try check(flux2mi_preprocess_image_for_vae(MIContext.current, resized.ptr.assumingMemoryBound(to: UInt8.self), Int32(targetHeight), Int32(targetWidth), 4, x.data))
-        let z = try MLXArray.uninitialized([1, 32, targetHeight / 8, targetWidth / 8])
+        let z = try rethrowing { try MLXArray.uninitialized([1, 32, targetHeight / 8, targetWidth / 8]) }
         try check(flux2mi_vae_encode(vae, x.data, Int32(targetHeight), Int32(targetWidth), z.data))
-        let packed = try MLXArray.uninitialized([1, (targetHeight / 16) * (targetWidth / 16), 128])
+        let packed = try rethrowing { try MLXArray.uninitialized([1, (targetHeight / 16) * (targetWidth / 16), 128]) }
         try check(flux2mi_vae_latents_to_packed(MIContext.current, z.data, flux2mi_vae_bn_mean(vae), flux2mi_vae_bn_var(vae), packed.data,
                                                 Int32(targetHeight / 16), Int32(targetWidth / 16)))
         eval(packed)

@@ -10,7 +10,9 @@
 //   Flux2DownloadProgressCallback      Loading/ModelDownloader.swift:7
 //   SchedulerOverrides, LoRAConfig, LoRAInfo    LoRA/LoRAConfig.swift:7-121
 // Only what the pipeline's public surface touches is declared here, with the reference's names, cases and member names.
+import CFlux2MI
 import Foundation
+import MLX
 
 public enum Flux2Error: Error, LocalizedError {
     case modelNotLoaded(String)
@@ -20,6 +22,27 @@ public enum Flux2Error: Error, LocalizedError {
     case imageProcessingFailed(String)
     case generationFailed(String)
     case generationCancelled
+}
+
+/// Maps every status of `enum flux2mi_status` onto the reference's error type (Flux2Core.swift:14-40).
+@inline(__always) func check(_ status: Int32) throws {
+    guard status != FLUX2MI_OK.rawValue else { return }
+    let msg = String(cString: flux2mi_last_error())
+    switch flux2mi_status(rawValue: UInt32(status)) {
+    case FLUX2MI_ERR_INVALID_ARG:  throw Flux2Error.invalidConfiguration(msg)
+    case FLUX2MI_ERR_HIP:          throw Flux2Error.generationFailed(msg)
+    case FLUX2MI_ERR_NOT_LOADED:   throw Flux2Error.modelNotLoaded(msg)
+    case FLUX2MI_ERR_SHAPE:        throw Flux2Error.invalidConfiguration(msg)
+    case FLUX2MI_ERR_CANCELLED:    throw Flux2Error.generationCancelled
+    case FLUX2MI_ERR_UNSUPPORTED:  throw Flux2Error.invalidConfiguration(msg)
+    case FLUX2MI_ERR_OOM:          throw Flux2Error.insufficientMemory(required: 0, available: 0)
+    case FLUX2MI_ERR_UNKNOWN_KEY:  throw Flux2Error.weightLoadingFailed(msg)
+    default:                       throw Flux2Error.generationFailed(msg)
+    }
+}
+/// The same for errors thrown inside module `MLX` of this package (array allocation).
+func rethrowing<T>(_ body: () throws -> T) throws -> T {
+    do { return try body() } catch let e as MIStatusError { try check(e.status); fatalError("unreachable") }
 }
 
 public enum Flux2Model: String, CaseIterable, Sendable {

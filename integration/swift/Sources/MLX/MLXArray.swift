@@ -1,10 +1,14 @@
-// MLXArray.swift — the `MLX` / `MLXRandom` façade of the shim (SURVEY §8b, row "MLXArray in the public API").
+// MLXArray.swift — module `MLX` of the shim: the part of mlx-swift's `MLX` module that code OUTSIDE Flux2Core uses (SURVEY §8b, row
+// "MLXArray in the public API"), under the module name those files import.
 //
 // The reference hands `MLXArray`s across its public API (`Flux2StepHook`, `precomputedEmbeddings`, `initLatents`,
-// `encodeImageToPackedSequence`, `packMaskForLatentBlending`) and code OUTSIDE Flux2Core computes with them:
-//   Flux2Chains/Flux2MaskedInpaintingChain.swift:380-403   MLXRandom.seed / normal, eval, MLXArray(Float), + - *
-//   Flux2CLI/InpaintCommand.swift:253-271                   .shape, eval
-// This file gives that code the same names over `flux2mi_array` handles, so it compiles and runs unchanged.
+// `encodeImageToPackedSequence`, `packMaskForLatentBlending`) and the chains / CLI compute with them:
+//   Flux2Chains/Flux2MaskedInpaintingChain.swift:18-19      @preconcurrency import MLX / MLXRandom
+//   Flux2Chains/Flux2MaskedInpaintingChain.swift:380-403    MLXRandom.seed / normal, eval, MLXArray(Float), `1 - a`, `a * b`, `a + b`, .shape
+//   Flux2CLI/InpaintCommand.swift:17, 253-271               import MLX; MLX.Memory.activeMemory / peakMemory / cacheMemory / clearCache()
+// This module gives that code the same names over `flux2mi_array` handles and the library's allocation table, so it compiles and
+// runs unchanged.  tests/test_swift_mlx_surface.py extracts every MLX name those files use (fixture tests/golden/mlx_surface_used.json)
+// and requires a public declaration here for each.  `package` members are the seam to the `Flux2Core` target of this package.
 import CFlux2MI
 
 /// One process-wide context per GPU (the reference is one-generation-at-a-time too, Flux2Pipeline.swift:135).
@@ -17,25 +21,18 @@ public enum MIContext {
     }()
 }
 
-/// Maps every status of `enum flux2mi_status` onto the reference's error type (Flux2Core.swift:14-40).
-@inline(__always) func check(_ status: Int32) throws {
+/// A non-zero `flux2mi_status` with the library's message; `Flux2Core.check(_:)` maps it onto `Flux2Error`.
+package struct MIStatusError: Error {
+    package let status: Int32
+    package let message: String
+}
+@inline(__always) package func miCheck(_ status: Int32) throws {
     guard status != FLUX2MI_OK.rawValue else { return }
-    let msg = String(cString: flux2mi_last_error())
-    switch flux2mi_status(rawValue: UInt32(status)) {
-    case FLUX2MI_ERR_INVALID_ARG:  throw Flux2Error.invalidConfiguration(msg)
-    case FLUX2MI_ERR_HIP:          throw Flux2Error.generationFailed(msg)
-    case FLUX2MI_ERR_NOT_LOADED:   throw Flux2Error.modelNotLoaded(msg)
-    case FLUX2MI_ERR_SHAPE:        throw Flux2Error.invalidConfiguration(msg)
-    case FLUX2MI_ERR_CANCELLED:    throw Flux2Error.generationCancelled
-    case FLUX2MI_ERR_UNSUPPORTED:  throw Flux2Error.invalidConfiguration(msg)
-    case FLUX2MI_ERR_OOM:          throw Flux2Error.insufficientMemory(required: 0, available: 0)
-    case FLUX2MI_ERR_UNKNOWN_KEY:  throw Flux2Error.weightLoadingFailed(msg)
-    default:                       throw Flux2Error.generationFailed(msg)
-    }
+    throw MIStatusError(status: status, message: String(cString: flux2mi_last_error()))
 }
 
 public final class MLXArray: @unchecked Sendable {
-    let handle: OpaquePointer
+    package let handle: OpaquePointer
     /// arrays this one was computed from: kept alive until the result is released (work may still be queued)
     private let inputs: [MLXArray]
 
@@ -61,15 +58,15 @@ public final class MLXArray: @unchecked Sendable {
     }
 
     /// Uninitialised owning array (outputs of encodeImageToPackedSequence / packMaskForLatentBlending, the initial noise's siblings).
-    static func uninitialized(_ shape: [Int]) throws -> MLXArray {
+    package static func uninitialized(_ shape: [Int]) throws -> MLXArray {
         var h: OpaquePointer?
         var sh = shape.map { Int64($0) }
-        try check(flux2mi_array_alloc(MIContext.current, &sh, Int32(sh.count), &h))
+        try miCheck(flux2mi_array_alloc(MIContext.current, &sh, Int32(sh.count), &h))
         return MLXArray(handle: h!)
     }
 
     /// Non-owning view over device memory (the hook's latent buffer, an encoder output).
-    static func borrowing(_ ptr: UnsafeMutablePointer<Float>, shape: [Int]) -> MLXArray {
+    package static func borrowing(_ ptr: UnsafeMutablePointer<Float>, shape: [Int]) -> MLXArray {
         var h: OpaquePointer?
         var sh = shape.map { Int64($0) }
         let s = flux2mi_array_wrap(MIContext.current, ptr, &sh, Int32(sh.count), &h)
@@ -78,8 +75,8 @@ public final class MLXArray: @unchecked Sendable {
     }
 
     public var shape: [Int] { (0..<Int(flux2mi_array_ndim(handle))).map { Int(flux2mi_array_dim(handle, Int32($0))) } }
-    var data: UnsafeMutablePointer<Float> { flux2mi_array_data(handle) }
-    var count: Int { shape.reduce(1, *) }
+    package var data: UnsafeMutablePointer<Float> { flux2mi_array_data(handle) }
+    package var count: Int { shape.reduce(1, *) }
 
     public func asArray() -> [Float] {
         var out = [Float](repeating: 0, count: count)
@@ -114,6 +111,25 @@ public func * (a: Int, b: MLXArray) -> MLXArray { MLXArray(Float(a)) * b }
 
 /// `eval(_:)`: every op above is already enqueued on the context's stream; evaluation = stream synchronisation.
 public func eval(_ arrays: MLXArray...) { flux2mi_ctx_sync(MIContext.current) }
+
+/// `MLX.Memory` (mlx-swift 0.31.6 `Memory`; callers: Flux2CLI/InpaintCommand.swift:253-255, 271 and CompareEncoders.swift:112, 142):
+/// the numbers come from the library's own allocation table (flux2mi_ctx_memory_stats) — active = weights, arrays, buffers, KV caches;
+/// cache = the grow-only workspaces kept between calls; peak = the largest active + cache seen.  `clearCache()` = flux2mi_ctx_trim.
+public enum Memory {
+    static func stats() -> (active: Int, peak: Int, cache: Int) {
+        var a = 0, p = 0, c = 0
+        let s = flux2mi_ctx_memory_stats(MIContext.current, &a, &p, &c)
+        precondition(s == 0, String(cString: flux2mi_last_error()))
+        return (a, p, c)
+    }
+    public static var activeMemory: Int { stats().active }
+    public static var cacheMemory: Int { stats().cache }
+    public static var peakMemory: Int {
+        get { stats().peak }
+        set { flux2mi_ctx_reset_peak(MIContext.current) }     // mlx-swift: assigning (0) resets the high-water mark
+    }
+    public static func clearCache() { flux2mi_ctx_trim(MIContext.current, nil) }
+}
 
 /// `MLXRandom.seed(_:)` + keyless `MLXRandom.normal(_:)` — MLX's Threefry stream: the global key is split on every
 /// draw, (state, sub) = split(state), and the draw uses `sub` (flux2mi.h, "MLX-compatible random stream").

@@ -459,3 +459,109 @@ def test_lora_prefixes_overrides_and_no_match(flux2mi, ctx, tmp_path):
     c = pipe.generate_with_result("textToImage", custom_sigmas=sig, **kw)
     assert torch.equal(a.latents, b.latents) and torch.equal(a.latents, c.latents)
     pipe.clearAll()
+
+
+def test_lora_of_another_width_is_a_shape_error_and_changes_nothing(flux2mi, ctx, tmp_path):
+    """a LoRA trained for another model width carries the same key names (Klein-9B vs 4B, Dev vs Klein).  The
+    factors' shapes come from the FILE and must fit the addressed weight: FLUX2MI_ERR_SHAPE naming the layer (the reference fails in
+    `matmul`), no read past the mapped tensor, the weights untouched — for a narrower file (the over-read case), a wider one, a
+    rank mismatch between A and B, and through the per-layer entry point as well."""
+    from safetensors.torch import save_file
+    from flux2mi import Flux2Error
+    from flux2mi.pipeline import Flux2Pipeline
+    syn, cfg, P, inp, lat = _setup()
+    vcfg = syn.VAE_PRESETS["tiny"]
+    pipe = Flux2Pipeline(model=cfg, vae_variant=vcfg).load_models(P, syn.make_vae_weights(vcfg))
+    base = _fwd(pipe.transformer, cfg, inp, lat, 64, 64, 16)
+    key = "single_blocks.0.linear2.weight"
+    out_f, in_f = P[key].shape
+    assert pipe.transformer.slot_shape(key) == (out_f, in_f)
+    g = torch.Generator().manual_seed(5)
+    cases = {"narrower": ((4, in_f // 2), (out_f // 2, 4)), "wider": ((4, in_f * 2), (out_f * 2, 4)), "in only": ((4, in_f // 2), (out_f, 4)),
+             "out only": ((4, in_f), (out_f + 32, 4))}
+    for name, (sa, sb) in cases.items():
+        path = str(tmp_path / "w.safetensors")
+        save_file({"transformer.single_blocks.0.linear2.lora_A.weight": torch.randn(sa, generator=g).to(torch.bfloat16),
+                   "transformer.single_blocks.0.linear2.lora_B.weight": torch.randn(sb, generator=g).to(torch.bfloat16)}, path)
+        with pytest.raises(Flux2Error) as e:
+            pipe.load_lora(path)
+        assert e.value.code == flux2mi._lib.ERR_SHAPE and "single_blocks.0.linear2" in str(e.value), (name, str(e.value))
+        assert not pipe.hasLoRA
+    with pytest.raises(Flux2Error) as e:     # A and B disagree on the rank
+        pipe.transformer.merge_lora(key, torch.zeros((4, in_f)), torch.zeros((out_f, 8)), 1.0)
+    assert e.value.code == flux2mi._lib.ERR_SHAPE
+    assert torch.equal(_fwd(pipe.transformer, cfg, inp, lat, 64, 64, 16), base)
+    pipe.clearAll()
+
+
+def test_lora_factors_of_different_float_dtypes(flux2mi, ctx, tmp_path):
+    """lora_A f32 with lora_B bf16 (and the reverse) is accepted — each factor is converted on its own — and merges to
+    the same weights as the all-bf16 file of the same (bf16-representable) values."""
+    from safetensors.torch import save_file
+    from flux2mi.pipeline import Flux2Pipeline
+    syn, cfg, P, inp, lat = _setup()
+    vcfg = syn.VAE_PRESETS["tiny"]
+    key = "double_blocks.0.img_attn.proj.weight"
+    g = torch.Generator().manual_seed(6)
+    A = (torch.randn((4, P[key].shape[1]), generator=g) * 0.1).to(torch.bfloat16)
+    B = (torch.randn((P[key].shape[0], 4), generator=g) * 0.1).to(torch.bfloat16)
+    outs = []
+    for da, db in [(torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16), (torch.float16, torch.float32)]:
+        path = str(tmp_path / "m.safetensors")
+        save_file({"double_blocks.0.img_attn.proj.lora_A.weight": A.to(da), "double_blocks.0.img_attn.proj.lora_B.weight": B.to(db)}, path)
+        pipe = Flux2Pipeline(model=cfg, vae_variant=vcfg).load_models(P, syn.make_vae_weights(vcfg))
+        assert pipe.load_lora(path) == 1
+        outs.append(_fwd(pipe.transformer, cfg, inp, lat, 64, 64, 16))
+        pipe.clearAll()
+    assert torch.equal(outs[0], outs[1])
+    assert rel_l2(outs[2], outs[0]) < 2e-3      # f16 rounds the bf16 values' small ones differently
+
+
+def test_memory_stats_and_trim(flux2mi, ctx):
+    """MLX.Memory.{activeMemory, peakMemory, cacheMemory, clearCache} (Flux2CLI/InpaintCommand.swift:253-271) on the C ABI:
+    flux2mi_ctx_memory_stats reports the library's own allocation table — weights count as active exactly (param_bytes), a forward
+    grows the workspace ("cache"), peak >= active + cache, trim gives the workspace back and the next forward is bit-identical; from
+    inside a generation's hook trim releases nothing; destroying the model returns active to where it was."""
+    from flux2mi import api, synthetic as syn
+    from flux2mi.pipeline import Flux2Pipeline
+    _, cfg, P, inp, lat = _setup()
+    ctx.clear_cache()
+    m0 = ctx.memory_stats()
+    dit = api.DiT(ctx, cfg).load(P).finalize()
+    ctx.clear_cache()                                   # staging buffers of the ingestion
+    m1 = ctx.memory_stats()
+    assert m1["active"] - m0["active"] == dit.param_bytes
+    assert m1["cache"] == m0["cache"] and m1["peak"] >= m1["active"]
+    out1 = _fwd(dit, cfg, inp, lat, 64, 64, 16)
+    m2 = ctx.memory_stats()
+    assert m2["cache"] > m1["cache"] and m2["active"] == m1["active"] and m2["peak"] >= m2["active"] + m2["cache"]
+    freed = ctx.clear_cache()
+    m3 = ctx.memory_stats()
+    assert freed == m2["cache"] - m3["cache"] > 0 and m3["cache"] == m1["cache"] and m3["peak"] == m2["peak"]
+    ctx.reset_peak_memory()
+    assert ctx.memory_stats()["peak"] == m3["active"] + m3["cache"]
+    assert torch.equal(_fwd(dit, cfg, inp, lat, 64, 64, 16), out1)
+    arr = api.MLXArray(ctx, torch.zeros((1, 64, 128)))          # a flux2mi_array counts as active memory, exactly
+    assert ctx.memory_stats()["active"] == m3["active"] + 64 * 128 * 4
+    del arr
+    dit.close()
+    ctx.clear_cache()
+    assert ctx.memory_stats()["active"] == m0["active"]
+
+    # a hook that calls clearCache() mid-generation: nothing is released, the result equals the undisturbed run
+    vcfg = syn.VAE_PRESETS["tiny"]
+    pipe = Flux2Pipeline(model=cfg, vae_variant=vcfg).load_models(P, syn.make_vae_weights(vcfg))
+    kw = dict(height=64, width=64, steps=3, precomputed_embeddings=inp["txt"], noise=inp["noise"])
+    ref = pipe.generate_with_result("textToImage", **kw)
+    freed_in_hook = []
+
+    def hook(c, latents):
+        freed_in_hook.append(pipe.ctx.clear_cache())
+        return latents
+    got = pipe.generate_with_result("textToImage", on_step=hook, **kw)
+    assert freed_in_hook == [0, 0, 0]
+    assert torch.equal(got.latents, ref.latents) and torch.equal(torch.as_tensor(got.image), torch.as_tensor(ref.image))
+    assert pipe.ctx.clear_cache() > 0                   # after the generation the decoder's and the DiT's workspaces go
+    again = pipe.generate_with_result("textToImage", **kw)
+    assert torch.equal(again.latents, ref.latents) and torch.equal(torch.as_tensor(again.image), torch.as_tensor(ref.image))
+    pipe.clearAll()

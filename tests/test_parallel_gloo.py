@@ -85,3 +85,25 @@ def test_bench_refuses_world_size_mismatch():
     assert "WORLD_SIZE" in r.stderr
     r, out = _run_bench(["--gpus", "1", "--dry-run"], env_extra={"WORLD_SIZE": "2", "RANK": "0"})
     assert r.returncode != 0 and out is None
+
+
+@pytest.mark.parametrize("config, gpus, expect", [
+    ("D", 2, {"model": "klein-9b", "dtype_starts": "fp8", "steps_eff": 28, "hook": False}),
+    ("E", 2, {"model": "dev", "dtype_starts": "bf16", "steps_eff": 35, "hook": True}),
+    ("C", 1, {"model": "dev", "dtype_starts": "bf16", "steps_eff": 50, "hook": False}),
+])
+def test_bench_config_entry_points_dry_run(config, gpus, expect):
+    """`bench.py --gpus N --config {C,D,E}` (VERDICT r3 #6b): the multi-GPU entry points of BASELINE.json configs[2..4] emit the same
+    JSON contract, `config.workload` names what runs and `config.baseline_config` the BASELINE entry; E's effective step count comes
+    from the host scheduler (50 steps at strength 0.7 -> 35).  --dry-run: gloo, no compute."""
+    r, out = _run_bench(["--gpus", str(gpus), "--dry-run", "--config", config, "--steps", "1", "--warmup", "0", "--height", "64", "--width", "64"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out["n_gpus"] == gpus and out["scaling"] == "weak" and out["unit"] == "denoise-steps/s"
+    c = out["config"]
+    assert expect["model"] in c["workload"] and c["baseline_config"].startswith(f"{config} = BASELINE.json configs[")
+    assert c["effective_denoise_steps"] == expect["steps_eff"] and c["parallelism"] == f"dp{gpus}"
+    assert ("RePaint step hook" in c["workload"]) == expect["hook"]
+    assert out["dtype"].startswith(expect["dtype_starts"])
+    assert c["matches_baseline_config"] is False          # 64x64 here: the line says so itself
+    for k in ("roofline", "roofline_secondary", "roofline_hbm", "cpu_baseline"):
+        assert k in out

@@ -1,4 +1,4 @@
-"""CPU: the Swift shim's `Flux2Pipeline` (integration/swift/Sources/Flux2MIShim/Flux2Pipeline.swift) has EXACTLY the reference's public
+"""CPU: the Swift shim's `Flux2Pipeline` (integration/swift/Sources/Flux2Core/Flux2Pipeline.swift) has EXACTLY the reference's public
 surface — every `public func / init / var / let` of `Flux2Pipeline`, `Flux2GenerationResult` and `Flux2StepContext` in
 Sources/Flux2Core/Pipeline/{Flux2Pipeline,Flux2Pipeline+ChainHelpers}.swift, with the same argument labels, order, types, default
 values, `async` / `throws` and return type — so that Flux2CLI and the chains compile against it unchanged (north_star).
@@ -14,7 +14,8 @@ import pytest
 from tests.swift_api import key, public_api
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHIM = os.path.join(ROOT, "integration", "swift", "Sources", "Flux2MIShim")
+SHIM = os.path.join(ROOT, "integration", "swift", "Sources", "Flux2Core")
+SOURCES = os.path.join(ROOT, "integration", "swift", "Sources")
 FIXTURE = os.path.join(ROOT, "tests", "golden", "flux2pipeline_public_api.json")
 # public members the shim has and the reference does not: the hook through which the host supplies FluxTextEncoders' tokenizer
 SHIM_ONLY = {"var promptTokenizer: Flux2PromptTokenizer? {get set}"}
@@ -89,8 +90,9 @@ def test_chain_call_site_type_checks_on_paper():
 def test_every_c_function_the_shim_calls_is_declared():
     hdr = open(os.path.join(ROOT, "include", "flux2mi.h")).read()
     declared = set(re.findall(r"\b(flux2mi_[a-z0-9_]+)\s*\(", hdr)) | set(re.findall(r"\b(flux2mi_[a-z0-9_]+)\b", hdr))
-    for f in sorted(os.listdir(SHIM)):
-        if f.endswith(".swift"):
-            src = re.sub(r"//[^\n]*", "", open(os.path.join(SHIM, f)).read())
-            for name in set(re.findall(r"\b(flux2mi_[a-z0-9_]+)\s*\(", src)):
-                assert name in declared, f"{f}: {name} is not in include/flux2mi.h"
+    for mod in sorted(os.listdir(SOURCES)):
+        for f in sorted(os.listdir(os.path.join(SOURCES, mod))):
+            if f.endswith(".swift"):
+                src = re.sub(r"//[^\n]*", "", open(os.path.join(SOURCES, mod, f)).read())
+                for name in set(re.findall(r"\b(flux2mi_[a-z0-9_]+)\s*\(", src)):
+                    assert name in declared, f"{mod}/{f}: {name} is not in include/flux2mi.h"
