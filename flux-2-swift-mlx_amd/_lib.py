@@ -155,6 +155,8 @@ PROTOTYPES = {
     "flux2mi_dit_slot_shape": (_I, [_P, C.c_char_p, C.POINTER(_I64), C.POINTER(_I64)]),
     "flux2mi_dit_param_bytes": (_I64, [_P]),
     "flux2mi_dit_forward": (_I, [_P, _P, _I, _P, _I, _F, _F, _P, _P, _P, _I]),
+    "flux2mi_dit_forward_block": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _F, _F, _P, _P, _P]),
+    "flux2mi_dit_last_modulation": (_I, [_P, _P, _I64]),
     "flux2mi_dit_set_attention_softmax": (_I, [_P, _I]),
     "flux2mi_dit_attention_softmax_info": (_I, [_P, _PI, _PI]),
     "flux2mi_kv_cache_create": (_I, [_P, _I, _I, C.POINTER(_P)]),

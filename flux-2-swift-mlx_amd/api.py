@@ -735,6 +735,42 @@ class DiT:
         self.ctx._exit()
         return out
 
+    def forward_block(self, layer: int, hs_in: Optional[torch.Tensor], txt_emb: torch.Tensor, timestep: float, guidance: float,
+                      img_ids: torch.Tensor, txt_ids: torch.Tensor, with_final: bool = False, latents: Optional[torch.Tensor] = None):
+        """ONE block on a given residual stream: hs_in f32 [S_txt + S_img, d] (text rows first) -> f32 of the same shape.
+        layer: double blocks first, then single blocks (flux2mi_dit_forward_block; teacher-forced parity tests).  with_final: also
+        the output layer applied to the result, f32 [S_img, 128].  hs_in=None + latents: OBSERVE the whole forward's own stream behind
+        block `layer` (and, with_final, its prediction)."""
+        txt = _req(txt_emb.reshape(-1, txt_emb.shape[-1]), torch.bfloat16, "txt_emb")
+        ii, ti = _req(img_ids, torch.int32, "img_ids"), _req(txt_ids, torch.int32, "txt_ids")
+        s_txt = txt.shape[0]
+        if hs_in is not None:
+            hs = _req(hs_in.reshape(-1, hs_in.shape[-1]), torch.float32, "hs_in")
+            lat, s_img = None, hs.shape[0] - s_txt
+            out = torch.empty_like(hs)
+        else:
+            hs, lat = None, _req(latents.reshape(-1, 128), torch.float32, "latents")
+            s_img = lat.shape[0]
+            out = torch.empty((s_txt + s_img, self.cfg.dim), dtype=torch.float32, device=lat.device)
+        fin = torch.empty((s_img, 128), dtype=torch.float32, device=out.device) if with_final else None
+        self.ctx._enter()
+        check(lib().flux2mi_dit_forward_block(self.handle, layer, _ptr(hs), _ptr(lat), _ptr(out), s_img, _ptr(txt), s_txt, timestep, guidance,
+                                              _ptr(ii), _ptr(ti), _ptr(fin)))
+        self.ctx._exit()
+        return (out, fin) if with_final else out
+
+    def last_modulation(self) -> dict:
+        """temb and the modulation vectors of the last forward (flux2mi_dit_last_modulation), as f32 CPU tensors."""
+        d = self.cfg.dim
+        buf = torch.empty(256 + 19 * d, dtype=torch.float32, device=self.ctx.device)
+        self.ctx._enter()
+        check(lib().flux2mi_dit_last_modulation(self.handle, _ptr(buf), buf.numel()))
+        self.ctx._exit()
+        b = buf.cpu()
+        o = 256 + d
+        return {"sinusoid": b[:256], "temb": b[o:o + d], "img": b[o + d:o + 7 * d], "txt": b[o + 7 * d:o + 13 * d], "single": b[o + 13 * d:o + 16 * d],
+                "final": b[o + 16 * d:o + 18 * d]}
+
     def forward_kv_extract(self, cache: "KVCache", latents, ref_latents, txt_emb, timestep: float, guidance: float,
                            img_ids, txt_ids, ref_ids) -> torch.Tensor:
         """`forwardKVExtract` (Flux2Transformer.swift:346-446): fills `cache`, returns f32 [S_out,128]."""

@@ -107,6 +107,8 @@ struct flux2mi_dit {
     } step_cache;
     DevBuf splitk_ws;   // proj_out ([s_out, d] x [128, d]^T: 32 tiles of 128x128 at 1024^2, 48 K-tiles): split-K workspace (kernels.h)
     int ws_S = 0;
+    // flux2mi_dit_forward_block (parity tests): run ONE block of a plain forward on a caller-supplied residual stream
+    struct BlockTap { int layer = -1; const float* hs_in = nullptr; float* hs_out = nullptr; } tap;
 };
 
 namespace {
@@ -1104,7 +1106,19 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     // (only when the V^T launch fills the chip on its own: at 256x256 it is 36 workgroups and the step got 12 % slower)
     const bool vt_gemm = vt_gemm_on && mode == FWD_PLAIN && (s_txt & 15) == 0 && (long)((d + 255) / 256) * ((S + 255) / 256) >= 160;
     // ---- double-stream blocks (Flux2TransformerBlock.swift:80-168)
+    // flux2mi_dit_forward_block: only block tap.layer runs, from tap.hs_in to tap.hs_out ([S, d] f32, text rows first)
+    const flux2mi_dit::BlockTap tap = mode == FWD_PLAIN ? m->tap : flux2mi_dit::BlockTap();
+    // (hs_in == nullptr: observe only — every block runs on the forward's own stream, the stream behind tap.layer is copied out)
+    auto tap_skip = [&](int layer) { return tap.layer >= 0 && tap.hs_in != nullptr && layer != tap.layer; };
+    auto tap_in = [&](int layer) -> hipError_t {
+        return layer == tap.layer && tap.hs_in ? hipMemcpyAsync(hs, tap.hs_in, (size_t)S * d * 4, hipMemcpyDeviceToDevice, st) : hipSuccess;
+    };
+    auto tap_out = [&](int layer) -> hipError_t {
+        return layer == tap.layer ? hipMemcpyAsync(tap.hs_out, hs, (size_t)S * d * 4, hipMemcpyDeviceToDevice, st) : hipSuccess;
+    };
     for (int i = 0; i < m->cfg.n_double; ++i) {
+        if (tap_skip(i)) continue;
+        F2_CHECK_HIP(tap_in(i));
         const flux2mi_dit::Dbl& w = m->dbl[i];
         // attention half: LN -> modulate(set 0) per stream
         F2_LAUNCH(ln_mod(mod_txt + 0 * d, mod_txt + 1 * d, mod_img + 0 * d, mod_img + 1 * d), "ln_mod(attn)");
@@ -1167,6 +1181,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
             if (bsa) { with_blocks(p[0], 0); with_blocks(p[1], img0); }
             F2_TRY(run_gemm(m, p, 2, PROF_PROJ_MLPOUT, "dbl.mlp_out"));
         }
+        F2_CHECK_HIP(tap_out(i));
     }
 
     // ---- single-stream blocks on the concatenated stream (Flux2SingleBlock.swift:59-98,
@@ -1176,6 +1191,8 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
     const int rng0[2] = {0, img0}, rngn[2] = {img0 == s_txt ? S : s_txt, n_img};
     const bool qk_fuse = qk_fuse_ok && (long)((S + 255) / 256) * ((9 * d + 255) / 256) >= 100;
     for (int i = 0; i < m->cfg.n_single; ++i) {
+        if (tap_skip(m->cfg.n_double + i)) continue;
+        F2_CHECK_HIP(tap_in(m->cfg.n_double + i));
         const flux2mi_dit::Sgl& w = m->sgl[i];
         F2_LAUNCH(ln_mod(mod_sgl, mod_sgl + d, mod_sgl, mod_sgl + d), "ln_mod(single)");
         if (qk_fuse && vt_gemm) {
@@ -1231,6 +1248,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
             }
             F2_TRY(run_gemm(m, p, n_rng, PROF_LINEAR2, "single.linear2"));
         }
+        F2_CHECK_HIP(tap_out(m->cfg.n_double + i));
     }
 
     // ---- output: drop text (and reference) tokens, AdaLayerNormContinuous, proj_out (:316-324, :444-452)
@@ -1307,6 +1325,52 @@ extern "C" int flux2mi_dit_forward(flux2mi_dit* m, const float* latents, int s_i
                "dit_forward: s_img %d s_txt %d s_out %d", s_img, s_txt, s_out);
     return dit_forward_impl(m, FWD_PLAIN, nullptr, latents, s_img, nullptr, 0, txt_emb, s_txt, timestep, guidance, img_ids,
                             txt_ids, nullptr, out, s_out);
+}
+
+// One block of a plain forward on a caller-supplied residual stream (teacher-forced per-block parity: tests feed the ORACLE's block
+// input, so a block's own error is seen without what the blocks before it accumulated).  `layer`: double blocks 0..n_double-1, then
+// the single blocks.  hs_in / hs_out f32 [s_txt + s_img, d] device, text rows first (Flux2TransformerBlock.swift:80-168 keeps the two
+// streams apart, Flux2SingleBlock.swift:59-98 concatenates them [text ; image]: the same rows either way).  Everything a block takes
+// from the step (modulation vectors, RoPE tables) is computed from timestep / guidance / ids exactly as flux2mi_dit_forward does.
+// final_out (may be NULL): f32 [s_img, 128], the output layer (AdaLayerNormContinuous + proj_out, Flux2Transformer.swift:316-324) applied
+// to hs_out's image rows — the forward's prediction had this block been its last.
+// hs_in == NULL: OBSERVE — the whole forward runs on `latents` (f32 [s_img, 128], required then) as flux2mi_dit_forward would, the
+// stream behind block `layer` is copied to hs_out, final_out is the forward's prediction.
+extern "C" int flux2mi_dit_forward_block(flux2mi_dit* m, int layer, const float* hs_in, const float* latents, float* hs_out, int s_img,
+                                         const void* txt_emb, int s_txt, float timestep, float guidance, const int32_t* img_ids,
+                                         const int32_t* txt_ids, float* final_out) {
+    F2_REQUIRE(m && hs_out && txt_emb && img_ids && txt_ids && (hs_in || latents), FLUX2MI_ERR_INVALID_ARG, "dit_forward_block: NULL argument");
+    F2_REQUIRE(m->finalized, FLUX2MI_ERR_NOT_LOADED, "dit_forward_block: weights not finalized");
+    F2_REQUIRE(layer >= 0 && layer < m->cfg.n_double + m->cfg.n_single, FLUX2MI_ERR_INVALID_ARG, "dit_forward_block: layer %d of %d", layer,
+               m->cfg.n_double + m->cfg.n_single);
+    F2_REQUIRE(s_img > 0 && s_txt > 0, FLUX2MI_ERR_SHAPE, "dit_forward_block: s_img %d s_txt %d", s_img, s_txt);
+    F2_REQUIRE(!m->step_cache.on, FLUX2MI_ERR_UNSUPPORTED, "dit_forward_block: not inside a generation");
+    F2_CHECK_HIP(hipSetDevice(m->ctx->device));
+    // teacher-forced: the embedders still run (their rows are replaced by hs_in at the block) on zero latents; the prediction goes to
+    // scratch unless asked for
+    F2_TRY(m->ctx->scratch.reserve((size_t)s_img * 128 * 4 * 2));
+    float* lat0 = m->ctx->scratch.as<float>();
+    float* pred = final_out ? final_out : lat0 + (size_t)s_img * 128;
+    if (!latents) F2_CHECK_HIP(hipMemsetAsync(lat0, 0, (size_t)s_img * 128 * 4, m->ctx->stream));
+    m->tap.layer = layer;
+    m->tap.hs_in = hs_in;
+    m->tap.hs_out = hs_out;
+    const int r = dit_forward_impl(m, FWD_PLAIN, nullptr, latents ? latents : lat0, s_img, nullptr, 0, txt_emb, s_txt, timestep, guidance, img_ids,
+                                   txt_ids, nullptr, pred, s_img);
+    m->tap = flux2mi_dit::BlockTap();
+    return r;
+}
+
+// The timestep embedding and the modulation vectors the LAST forward outside a generation computed (Flux2Embeddings.swift:124-142,
+// Flux2Modulation.swift:49-75): f32 [256 + 19 dim] = sinusoid(256) | MLP hidden(dim) | temb(dim) | img(6 dim: shift, scale, gate x 2) |
+// txt(6 dim) | single(3 dim) | final(2 dim: shift, scale), copied to `out` (device or host) in stream order.  Parity tests only.
+extern "C" int flux2mi_dit_last_modulation(flux2mi_dit* m, float* out, int64_t n_floats) {
+    F2_REQUIRE(m && out, FLUX2MI_ERR_INVALID_ARG, "dit_last_modulation: NULL argument");
+    const int64_t n = 256 + (int64_t)19 * m->cfg.dim;
+    F2_REQUIRE(n_floats >= n && m->mods.ptr, FLUX2MI_ERR_SHAPE, "dit_last_modulation: %lld floats needed (and a forward first)", (long long)n);
+    F2_CHECK_HIP(hipSetDevice(m->ctx->device));
+    F2_CHECK_HIP(hipMemcpyAsync(out, m->mods.ptr, (size_t)n * 4, hipMemcpyDefault, m->ctx->stream));
+    return FLUX2MI_OK;
 }
 
 // Which softmax form the attention of each block runs.  The fixed zero offset (attention64b.hip, DOFF = false) needs the block's

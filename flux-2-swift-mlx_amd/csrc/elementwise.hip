@@ -79,13 +79,16 @@ __global__ __launch_bounds__(256) void gemv_multi_kernel(const uint16_t* __restr
     }
 }
 
-// ---- sinusoidal embedding: [cos(v f_i) | sin(v f_i)], f_i = exp(-ln(1e4) i/128), i < 128
+// ---- sinusoidal embedding: [cos(v f_i) | sin(v f_i)], f_i = exp(-ln(1e4) i/128), i < 128 (Flux2Embeddings.swift:29-40).
+// Evaluated in f64 and rounded once: the argument reaches 1000 rad, where an f32 evaluation carries ~4e-5 of argument error (one ulp of
+// f_i times the timestep) whatever the libm — the exact value is what every f32 evaluation, the reference's included, approximates, and
+// a timestep MLP amplifies the difference (synthetic weights: 3e-3 of the output).  128 threads, once per step: no cost.
 __global__ void sinusoid_kernel(float value, float* __restrict__ emb) {
     const int i = threadIdx.x;  // 128 threads
-    const float f = expf(-9.210340371976184f * (float)i / 128.0f);
-    const float a = value * f;
-    emb[i] = cosf(a);
-    emb[128 + i] = sinf(a);
+    const double f = exp(-9.210340371976184 * (double)i / 128.0);
+    const double a = (double)value * f;
+    emb[i] = (float)cos(a);
+    emb[128 + i] = (float)sin(a);
 }
 
 __global__ void silu_inplace_kernel(float* x, int n) {

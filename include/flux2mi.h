@@ -307,6 +307,20 @@ int64_t flux2mi_dit_param_bytes(const flux2mi_dit* dit);
 int flux2mi_dit_forward(flux2mi_dit* dit, const float* latents, int s_img, const void* txt_emb, int s_txt,
                         float timestep, float guidance, const int32_t* img_ids, const int32_t* txt_ids,
                         float* out, int s_out);
+/* ONE block of that forward on a caller-supplied residual stream — Flux2TransformerBlock.callAsFunction
+ * (Transformer/Flux2TransformerBlock.swift:80-168) for layer < n_double, Flux2SingleTransformerBlock.callAsFunction
+ * (Transformer/Flux2SingleBlock.swift:59-98) after that; async.  hs_in / hs_out f32 [s_txt + s_img, dim] device, text rows first;
+ * modulation vectors and RoPE tables from timestep / guidance / ids as in flux2mi_dit_forward.  final_out (may be NULL): f32
+ * [s_img,128] = the output layer (:316-324) applied to hs_out.  hs_in == NULL: OBSERVE — the whole forward runs on `latents`
+ * (f32 [s_img,128]; otherwise unused, may be NULL), the stream behind block `layer` goes to hs_out and final_out is the forward's
+ * prediction.  For teacher-forced per-block parity tests: a host never needs it. */
+int flux2mi_dit_forward_block(flux2mi_dit* dit, int layer, const float* hs_in, const float* latents, float* hs_out, int s_img,
+                              const void* txt_emb, int s_txt, float timestep, float guidance, const int32_t* img_ids,
+                              const int32_t* txt_ids, float* final_out);
+/* The timestep embedding and modulation vectors of the last forward outside a generation — TimestepEmbedding + Modulation
+ * (Transformer/Flux2Embeddings.swift:124-142, Flux2Modulation.swift:49-75): f32 [256 + 19 dim] = sinusoid | MLP hidden | temb |
+ * img (shift, scale, gate) x 2 | txt x 2 | single (shift, scale, gate) | final (shift, scale).  Parity tests only; async. */
+int flux2mi_dit_last_modulation(flux2mi_dit* dit, float* out, int64_t n_floats);
 
 /* ---- KV-cached reference conditioning (Transformer/TransformerKVCache.swift,
  * Flux2Transformer.swift:330-546; model variant klein-9b-kv) -------------------------------------- */

@@ -281,6 +281,12 @@ def apply_rope(x: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
 def sinusoid_embedding(t: Tensor, num_channels: int = 256) -> Tensor:
     """Timesteps(flipSinToCos: true, downscaleFreqShift: 0): [cos | sin]."""
     half = num_channels // 2
+    if _DEV_ROUND:
+        # the HIP path evaluates the embedding in f64 and rounds once (elementwise.hip, sinusoid_kernel): at arguments up to 1000 rad
+        # an f32 evaluation carries ~4e-5 of argument error that a timestep MLP amplifies; the store-point emulation follows the device
+        e64 = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float64) / float(half))
+        a64 = t.to(torch.float32).double().unsqueeze(-1) * e64.unsqueeze(0)
+        return torch.cat([torch.cos(a64), torch.sin(a64)], dim=-1).float()
     exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / float(half)
     emb = torch.exp(exponent)
     arg = t.to(torch.float32).unsqueeze(-1) * emb.unsqueeze(0)
@@ -303,16 +309,49 @@ _FP8_ACT_BLOCKS = False
 E4M3_MAX = 448.0
 
 
-class fp8_block_gemms:
-    """Context manager: block GEMMs (qkv/proj/mlp/linear1/linear2) run on fake-quantised operands."""
+# ---- emulation of the MI355X path's bf16 STORE POINTS — NOT a restatement of the reference, which keeps f32
+# activations.  Off: the oracle is the f32 restatement every tolerance is stated against.  On: every tensor the HIP path
+# keeps in bf16 between kernels is rounded to bf16 at the same place — the packed latents in front of img_in, `xn` (LayerNorm +
+# modulate output), q (with the score scale log2(e)/sqrt(128) folded in, as the epilogue stores it), k, v, the softmax numerators P
+# in front of P V (denominator = the sum of the ROUNDED numerators: the kernel sums them on the matrix pipe), the attention output
+# and the SwiGLU hidden (`comb`; in fp8 mode these two are quantised to e4m3 blocks straight from f32 instead).  What is left between
+# the two sides is f32 summation order and the hardware's exp2 / sin / cos / rsqrt — small against ONE e4m3 step, which is what
+# makes the fp8 model-level comparison sharp (an e4m3 rounding flips wherever the two sides differ by more than that).
+_DEV_ROUND = False
+
+
+def _r16(x: Tensor) -> Tensor:
+    return x.to(torch.bfloat16).float() if _DEV_ROUND else x
+
+
+class device_roundings:
+    """Context manager: round to bf16 where the HIP path stores bf16 (see above)."""
 
     def __enter__(self):
-        global _FP8_BLOCK_GEMMS
-        self._old, _FP8_BLOCK_GEMMS = _FP8_BLOCK_GEMMS, True
+        global _DEV_ROUND
+        self._old, _DEV_ROUND = _DEV_ROUND, True
 
     def __exit__(self, *exc):
-        global _FP8_BLOCK_GEMMS
+        global _DEV_ROUND
+        _DEV_ROUND = self._old
+
+
+class fp8_block_gemms:
+    """Context manager: block GEMMs (qkv/proj/mlp/linear1/linear2) run on fake-quantised operands.  `device_roundings=True` adds the
+    bf16 store points of the HIP path on top (class device_roundings)."""
+
+    def __init__(self, device_roundings: bool = False):
+        self._dev = device_roundings
+
+    def __enter__(self):
+        global _FP8_BLOCK_GEMMS, _DEV_ROUND
+        self._old, _FP8_BLOCK_GEMMS = _FP8_BLOCK_GEMMS, True
+        self._old_dev, _DEV_ROUND = _DEV_ROUND, _DEV_ROUND or self._dev
+
+    def __exit__(self, *exc):
+        global _FP8_BLOCK_GEMMS, _DEV_ROUND
         _FP8_BLOCK_GEMMS = self._old
+        _DEV_ROUND = self._old_dev
 
 
 def fake_quant_e4m3_rows(x: Tensor) -> Tensor:
@@ -354,6 +393,9 @@ def fp8_qk(q: Tensor, k: Tensor, wq_max: float, wk_max: float) -> Tuple[Tensor, 
     reference): q carries the score scale log2(e)/sqrt(128); q 2^qe and k 2^ke are rounded to e4m3 with the largest powers of two that
     keep the RMSNorm-bounded elements (|x_d| <= sqrt(128) max|w|) inside 448; returns the de-quantised q (score scale removed again), k."""
     if not _FP8_BLOCK_GEMMS:
+        if _DEV_ROUND:      # the bf16 path stores q with the score scale folded in (gemm256s.hip, QK epilogue), and k
+            c = math.log2(math.e) / math.sqrt(128.0)
+            return _r16(q * c) / c, _r16(k)
         return q, k
     c = math.log2(math.e) / math.sqrt(128.0)
     r128 = math.sqrt(128.0)
@@ -427,10 +469,27 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor] = None) -> Tens
     """softmax(QK^T/sqrt(D) [+mask]) V, explicit form (MLXFast.scaledDotProductAttention,
     Flux2Attention.swift:168-174)."""
     scale = 1.0 / math.sqrt(q.shape[-1])
+    if _DEV_ROUND and mask is None:
+        # attention64b.hip: scores in the log2 domain, P = exp2(score - offset) rounded to bf16 for the P V MFMA, row sums of the ROUNDED
+        # P.  The kernel's offset is 0 (fixed-offset form); an integer offset is the same bf16 rounding (a power-of-two factor) without
+        # the overflow of f32 exp2 on the host.  Per head, to bound the memory of the S x S intermediates.
+        out = torch.empty_like(q)
+        v16 = _r16(v)
+        for h in range(q.shape[1]):
+            s2 = torch.matmul(q[:, h] * (scale * math.log2(math.e)), k[:, h].transpose(-1, -2))
+            pb = _r16(torch.exp2(s2 - torch.floor(s2.amax(dim=-1, keepdim=True))))
+            out[:, h] = torch.matmul(pb, v16[:, h]) / pb.sum(dim=-1, keepdim=True)
+        return out
     s = torch.matmul(q, k.transpose(-1, -2)) * scale
     if mask is not None:
         s = s + mask
     return torch.matmul(torch.softmax(s, dim=-1), v)
+
+
+def _store16(x: Tensor) -> Tensor:
+    """attention output / SwiGLU hidden (`comb`): bf16 in the bf16 path; in fp8 mode the consuming block_linear quantises them itself
+    (e4m3 blocks straight from f32, or rows from the bf16 copy)."""
+    return x if _FP8_BLOCK_GEMMS else _r16(x)
 
 
 def _heads(x: Tensor, H: int) -> Tensor:
@@ -447,7 +506,7 @@ def swiglu_ff(x: Tensor, w_in: Tensor, w_out: Tensor) -> Tensor:
     """a15 — Flux2FeedForward.swift:42-109: gate = first half, value = second half."""
     p = block_linear(x, w_in)
     gate, value = p.chunk(2, dim=-1)
-    return block_linear(F.silu(gate) * value, w_out, blocks=True, mag=gate * value)
+    return block_linear(_store16(F.silu(gate) * value), w_out, blocks=True, mag=gate * value)
 
 
 def double_block(P: Dict[str, Tensor], i: int, img: Tensor, txt: Tensor, H: int,
@@ -455,8 +514,8 @@ def double_block(P: Dict[str, Tensor], i: int, img: Tensor, txt: Tensor, H: int,
     """a14-a16 — Flux2TransformerBlock.swift:80-168 + Flux2Attention.swift:103-193."""
     pre = f"double_blocks.{i}."
     S_txt = txt.shape[1]
-    img_n = apply_modulation(layer_norm_noaffine(img), img_mod[0][0], img_mod[0][1])
-    txt_n = apply_modulation(layer_norm_noaffine(txt), txt_mod[0][0], txt_mod[0][1])
+    img_n = _r16(apply_modulation(layer_norm_noaffine(img), img_mod[0][0], img_mod[0][1]))
+    txt_n = _r16(apply_modulation(layer_norm_noaffine(txt), txt_mod[0][0], txt_mod[0][1]))
 
     def qkv(x, name):
         p = block_linear(x, P[pre + name + ".qkv.weight"])
@@ -475,14 +534,14 @@ def double_block(P: Dict[str, Tensor], i: int, img: Tensor, txt: Tensor, H: int,
     v = torch.cat([v_t, v_i], dim=2)
     wmax = lambda s_: max(float(P[pre + "img_attn.norm." + s_].float().abs().max()), float(P[pre + "txt_attn.norm." + s_].float().abs().max()))
     q, k = fp8_qk(q, k, wmax("query_norm.scale"), wmax("key_norm.scale"))
-    o = _unheads(sdpa(q, k, v))
+    o = _store16(_unheads(sdpa(q, k, v)))
     txt_attn = block_linear(o[:, :S_txt], P[pre + "txt_attn.proj.weight"], blocks=True)
     img_attn = block_linear(o[:, S_txt:], P[pre + "img_attn.proj.weight"], blocks=True)
     img = img + img_attn * img_mod[0][2].unsqueeze(1)
     txt = txt + txt_attn * txt_mod[0][2].unsqueeze(1)
 
-    img_n2 = apply_modulation(layer_norm_noaffine(img), img_mod[1][0], img_mod[1][1])
-    txt_n2 = apply_modulation(layer_norm_noaffine(txt), txt_mod[1][0], txt_mod[1][1])
+    img_n2 = _r16(apply_modulation(layer_norm_noaffine(img), img_mod[1][0], img_mod[1][1]))
+    txt_n2 = _r16(apply_modulation(layer_norm_noaffine(txt), txt_mod[1][0], txt_mod[1][1]))
     img = img + swiglu_ff(img_n2, P[pre + "img_mlp.0.weight"], P[pre + "img_mlp.2.weight"]) * img_mod[1][2].unsqueeze(1)
     txt = txt + swiglu_ff(txt_n2, P[pre + "txt_mlp.0.weight"], P[pre + "txt_mlp.2.weight"]) * txt_mod[1][2].unsqueeze(1)
     return txt, img
@@ -492,7 +551,7 @@ def single_block(P: Dict[str, Tensor], i: int, hs: Tensor, H: int, cos: Tensor, 
     """a17 — Flux2SingleBlock.swift:59-98 + Flux2ParallelAttention.swift:72-123."""
     pre = f"single_blocks.{i}."
     d = hs.shape[-1]
-    x = apply_modulation(layer_norm_noaffine(hs), mod[0][0], mod[0][1])
+    x = _r16(apply_modulation(layer_norm_noaffine(hs), mod[0][0], mod[0][1]))
     p = block_linear(x, P[pre + "linear1.weight"])      # [q | k | v | gate | up]
     q, k, v = p[..., :d], p[..., d:2 * d], p[..., 2 * d:3 * d]
     mlp_hidden = (p.shape[-1] - 3 * d) // 2
@@ -502,7 +561,7 @@ def single_block(P: Dict[str, Tensor], i: int, hs: Tensor, H: int, cos: Tensor, 
     k = apply_rope(rms_norm(k, P[pre + "norm.key_norm.scale"]), cos, sin)
     q, k = fp8_qk(q, k, float(P[pre + "norm.query_norm.scale"].float().abs().max()), float(P[pre + "norm.key_norm.scale"].float().abs().max()))
     attn = _unheads(sdpa(q, k, v))
-    out = block_linear(torch.cat([attn, F.silu(gate) * up], dim=-1), P[pre + "linear2.weight"], blocks=True, mag=torch.cat([attn, gate * up], dim=-1))
+    out = block_linear(_store16(torch.cat([attn, F.silu(gate) * up], dim=-1)), P[pre + "linear2.weight"], blocks=True, mag=torch.cat([attn, gate * up], dim=-1))
     return hs + out * mod[0][2].unsqueeze(1)
 
 
@@ -515,8 +574,8 @@ def dit_forward(P: Dict[str, Tensor], cfg: dict, lat: Tensor, txt_emb: Tensor, t
     H = cfg["heads"]
     global _FP8_ACT_BLOCKS
     _FP8_ACT_BLOCKS = _FP8_BLOCK_GEMMS and txt_emb.shape[1] % 64 == 0 and cfg["dim"] % 128 == 0
-    img = linear(lat.float(), P["img_in.weight"])
-    txt = linear(txt_emb.float(), P["txt_in.weight"])
+    img = linear(_r16(lat.float()), P["img_in.weight"])
+    txt = linear(_r16(txt_emb.float()), P["txt_in.weight"])
     temb = time_guidance_embed(P, t.float() * 1000.0, None if g is None else g.float() * 1000.0)
     cos, sin = rope_tables(torch.cat([txt_ids, img_ids], dim=0))
     img_mod = modulation(temb, P["double_stream_modulation_img.lin.weight"], 2)
@@ -542,7 +601,7 @@ def dit_forward(P: Dict[str, Tensor], cfg: dict, lat: Tensor, txt_emb: Tensor, t
     d = img.shape[-1]
     p = linear(F.silu(temb), P["final_layer.adaLN_modulation.1.weight"])
     shift, scale = p[:, :d], p[:, d:]
-    img = apply_modulation(layer_norm_noaffine(img), shift, scale)
+    img = _r16(apply_modulation(layer_norm_noaffine(img), shift, scale))
     return linear(img, P["final_layer.linear.weight"])
 
 
@@ -575,8 +634,8 @@ def dit_forward_kv(P: Dict[str, Tensor], cfg: dict, lat: Tensor, txt_emb: Tensor
     _FP8_ACT_BLOCKS = False     # the KV passes keep the row-wise activations (dit.cpp: bsa needs a plain forward)
     H, d = cfg["heads"], cfg["dim"]
     S_txt, S_out = txt_emb.shape[1], lat.shape[1]
-    img = linear(lat.float(), P["img_in.weight"])
-    txt = linear(txt_emb.float(), P["txt_in.weight"])
+    img = linear(_r16(lat.float()), P["img_in.weight"])
+    txt = linear(_r16(txt_emb.float()), P["txt_in.weight"])
     if extract:
         S_ref = ref_lat.shape[1]
         img = torch.cat([linear(ref_lat.float(), P["img_in.weight"]), img], dim=1)     # [ref | out]

@@ -21,7 +21,7 @@ import pytest
 import torch
 
 from oracle import flux2_ref as R
-from tests.util import rel_l2
+from tests.util import oracle_cached, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -81,14 +81,18 @@ def test_dev_width_fp8_blocks(flux2mi, ctx):
     del P
     args = (Pc, cfg, lat, inp["txt"].float(), torch.tensor([0.6]), torch.tensor([4.0]), ii, ti)
     ref32 = R.dit_forward(*args)[0]
-    with R.fp8_block_gemms():
+    with R.fp8_block_gemms(device_roundings=True):
         ref8 = R.dit_forward(*args)[0]
     q, e8 = rel_l2(ref8, ref32), rel_l2(out8, ref8)
-    print(f"Dev width fp8: q {q:.3e}, HIP vs emulation {e8:.3e}, HIP vs f32 oracle {rel_l2(out8, ref32):.3e}")
+    print(f"Dev width fp8: q {q:.3e}, HIP vs emulation (bf16 store points emulated) {e8:.3e} = {e8 / q:.2f} q, HIP vs f32 oracle {rel_l2(out8, ref32):.3e}")
     assert torch.isfinite(out8).all()
-    # e4m3 noise at this width (K 6144 ... 24576, synthetic weights): q = 9.3e-2; the HIP path sits 7.1e-2 from the emulation, the same
-    # ~3/4 of q as at the narrower widths
-    assert e8 < 0.8 * q and e8 < 8e-2, (e8, q)
+    # the emulation rounds to bf16 where the HIP path stores bf16 (oracle: device_roundings) and takes the same f64 sinusoid: every op
+    # then agrees with its emulation to ~5e-5 on the emulation's own input (profiles/r04_d_store_point_probe.txt) — and the blocks still
+    # sit 0.59 q apart (0.76 q against the f32-activation emulation), because roundings CASCADE: a 1e-7 perturbation of a block's input
+    # moves its output by 2e-4 whatever its size (same file: each rounding stage turns a difference d into ~sqrt(d x ulp)), so two
+    # correct implementations that differ in f32 summation order de-correlate within a block.  Sharp statements: per op
+    # (tests/test_gpu_ops.py) and per teacher-forced block (tests/test_gpu_full_depth.py).
+    assert e8 < 0.75 * q, (e8, q)
     assert 0.5 * q < rel_l2(out8, ref32) < 1.5 * q
 
 
@@ -113,19 +117,27 @@ def test_config_d_klein9b_width_fp8(flux2mi, ctx):
     del P
     args = (Pc, cfg, lat, inp["txt"].float(), torch.tensor([0.6]), None, ii, ti)
     ref32 = R.dit_forward(*args)[0]
-    with R.fp8_block_gemms():
+    with R.device_roundings():
+        ref16 = R.dit_forward(*args)[0]
+    with R.fp8_block_gemms(device_roundings=True):
         ref8 = R.dit_forward(*args)[0]
     assert torch.isfinite(outs["fp8"]).all()
     assert rel_l2(outs["bf16"], ref32) < 2e-2
-    # e4m3 noise at this width (K 4096 ... 16384): q = rel-L2(emulating oracle, f32 oracle) = 6.4e-2, the HIP path sits
-    # 4.3e-2 from the emulation — the same 2/3 of q as at Klein-4B width (test_production_width_fused_paths_bf16_and_fp8:
-    # 2.5e-2 of 3.9e-2): roundings flipped by bf16-level differences de-correlate part of the noise (test_tiny_forward_fp8)
+    # the bf16 path against the oracle with the SAME bf16 store points: what is left is f32 summation order and hardware exp2 / sin / cos
+    e16 = rel_l2(outs["bf16"], ref16)
     q = rel_l2(ref8, ref32)
     e8 = rel_l2(outs["fp8"], ref8)
-    assert e8 < 0.8 * q and e8 < 5e-2, (e8, q)
+    print(f"Klein-9B width: bf16 vs store-point oracle {e16:.3e} (vs f32 oracle {rel_l2(outs['bf16'], ref32):.3e}); fp8: q {q:.3e}, "
+          f"HIP vs emulation {e8:.3e} = {e8 / q:.2f} q")
+    # 3.1e-3 measured (4.0e-3 against the f32 oracle): six bf16 store points in sequence per double block de-correlate two correct
+    # implementations to the level of the bf16 rounding noise itself (the cascade of test_dev_width_fp8_blocks' comment); the output layer
+    # of these synthetic weights amplifies the stream's 5e-4 five-fold
+    assert e16 < 5e-3, e16
+    # e4m3 noise at this width (K 4096 ... 16384): q = 6.4e-2; HIP vs the store-point emulation 0.53 q (0.67 q against the f32-activation one)
+    assert e8 < 0.7 * q, (e8, q)
     assert 0.5 * q < rel_l2(outs["fp8"], ref32) < 1.5 * q
-    d_hip, d_ref = (outs["fp8"] - outs["bf16"]).flatten(), (ref8 - ref32).flatten()
-    assert torch.dot(d_hip, d_ref) / (d_hip.norm() * d_ref.norm()) > 0.7     # the quantisation effect points the same way
+    d_hip, d_ref = (outs["fp8"] - outs["bf16"]).flatten(), (ref8 - ref16).flatten()
+    assert torch.dot(d_hip, d_ref) / (d_hip.norm() * d_ref.norm()) > 0.7     # the quantisation effect, same direction
 
 
 # ------------------------------------------------------------------------------------------------ E
@@ -195,31 +207,6 @@ def test_config_e_sequence_8704(flux2mi, ctx):
 
 
 # ------------------------------------------------------------------------------------------------ A
-def test_config_a_klein4b_256_4steps(flux2mi, ctx):
-    """BASELINE config A end to end: Klein-4B (5 + 20 blocks), 256 x 256, 4 steps, standard VAE decode, u8 image.
-    Per-step latent rel-L2 <= 3e-2, image mean |diff| <= 2 levels (measured values: DESIGN.md §1c)."""
-    from flux2mi import synthetic as syn
-    from flux2mi.pipeline import Flux2Pipeline
-    cfg, vcfg = syn.DIT_PRESETS["klein-4b"], syn.VAE_PRESETS["standard"]
-    P = syn.make_dit_weights(cfg, device="cuda")
-    VP = syn.make_vae_weights(vcfg, encoder=False)
-    pipe = Flux2Pipeline(model="klein-4b", vae_variant="standard").load_models(P, VP)
-    Pc = _cpu(P)
-    del P
-    inp = syn.make_inputs(cfg, 256, 256, s_txt=512)
-    traj = []
-    res = pipe.generate_text_to_image(height=256, width=256, steps=4, precomputed_embeddings=inp["txt"], noise=inp["noise"],
-                                      on_step=lambda c, x: traj.append(x.detach().clone().cpu()) or x)
-    ref = R.generate(Pc, cfg, VP, vcfg, inp["txt"].float(), inp["noise"], 256, 256, 4)
-    errs = [rel_l2(traj[k], ref["latents"][k]) for k in range(4)]
-    mean, mx, gt2, gt8 = _u8_stats(res.image, ref["image"])
-    print(f"config A: per-step latent rel-L2 {['%.2e' % e for e in errs]}; u8 |diff| mean {mean:.3f} max {mx:.0f} "
-          f">2: {100 * gt2:.2f}% >8: {100 * gt8:.3f}%")
-    assert max(errs) < 3e-2, errs
-    assert mean < 2.0 and gt8 < 0.01
-    pipe.clearAll()
-
-
 # ------------------------------------------------------------------------------------------------ B
 @pytest.fixture(scope="module")
 def klein4b_pipe(flux2mi, ctx):
@@ -233,6 +220,30 @@ def klein4b_pipe(flux2mi, ctx):
     pipe.clearAll()
 
 
+def test_config_a_klein4b_256_4steps(klein4b_pipe):
+    """BASELINE config A end to end: Klein-4B (5 + 20 blocks), 256 x 256, 4 steps, standard VAE decode, u8 image.
+    Per-step latent rel-L2 <= 3e-2, image mean |diff| <= 2 levels (measured values: DESIGN.md §1c)."""
+    from flux2mi import synthetic as syn
+    k = klein4b_pipe
+    cfg, vcfg, pipe, P = k["cfg"], k["vcfg"], k["pipe"], k["P"]
+    inp = syn.make_inputs(cfg, 256, 256, s_txt=512)
+    traj = []
+    res = pipe.generate_text_to_image(height=256, width=256, steps=4, precomputed_embeddings=inp["txt"], noise=inp["noise"],
+                                      on_step=lambda c, x: traj.append(x.detach().clone().cpu()) or x)
+
+    def oracle():
+        ref = R.generate(_cpu(P), cfg, k["VP"], vcfg, inp["txt"].float(), inp["noise"], 256, 256, 4)
+        return {"latents": torch.stack([x.reshape(traj[0].shape) for x in ref["latents"]]), "image": torch.as_tensor(ref["image"])}
+    got, cached = oracle_cached("config_a_256_4steps", [P["img_in.weight"], P["single_blocks.19.linear2.weight"][:64], P["double_blocks.2.img_mlp.0.weight"][:64],
+                                                        k["VP"]["decoder.conv_in.weight"], inp["noise"], inp["txt"]], oracle)
+    errs = [rel_l2(traj[j], got["latents"][j]) for j in range(4)]
+    mean, mx, gt2, gt8 = _u8_stats(res.image, got["image"])
+    print(f"config A: per-step latent rel-L2 {['%.2e' % e for e in errs]}; u8 |diff| mean {mean:.3f} max {mx:.0f} "
+          f">2: {100 * gt2:.2f}% >8: {100 * gt8:.3f}% (oracle {'from the committed fixture' if cached else 'run live'})")
+    assert max(errs) < 3e-2, errs
+    assert mean < 2.0 and gt8 < 0.01
+
+
 def test_config_b_klein4b_full_depth_forward_1024(klein4b_pipe):
     """BASELINE config B geometry: Klein-4B full depth at 1024 x 1024 (S = 4608), ONE forward vs the oracle
     (34.8 TFLOP of f32 on the host cores)."""
@@ -243,11 +254,15 @@ def test_config_b_klein4b_full_depth_forward_1024(klein4b_pipe):
     lat = R.pack_patchified_to_sequence(inp["noise"])
     ii, ti = R.image_position_ids(1024, 1024), R.text_position_ids(512)
     out = k["pipe"].transformer.forward(lat.cuda(), inp["txt"].cuda(), 0.877, 0.0, ii.cuda(), ti.cuda()).cpu()
-    Pc = _cpu(k["P"])
-    with torch.no_grad():
-        ref = R.dit_forward(Pc, cfg, lat, inp["txt"].float(), torch.tensor([0.877]), None, ii, ti)[0]
-    e = rel_l2(out, ref)
-    print(f"config B forward: rel-L2 {e:.3e}")
+    def oracle():
+        with torch.no_grad():
+            return {"ref": R.dit_forward(_cpu(k["P"]), cfg, lat, inp["txt"].float(), torch.tensor([0.877]), None, ii, ti)[0]}
+    # (seeded case: the 57 s oracle forward is a committed fixture, used while the inputs' fingerprint matches — tests/util.py)
+    P = k["P"]
+    got, cached = oracle_cached("config_b_forward_1024", [P["img_in.weight"], P["single_blocks.19.linear2.weight"][:64], P["double_blocks.2.img_mlp.0.weight"][:64],
+                                                          inp["noise"], inp["txt"]], oracle)
+    e = rel_l2(out, got["ref"])
+    print(f"config B forward: rel-L2 {e:.3e} (oracle {'from the committed fixture' if cached else 'run live'})")
     assert torch.isfinite(out).all()
     assert e < 3e-2
 

@@ -551,7 +551,7 @@ def test_memory_stats_and_trim(flux2mi, ctx):
     # a hook that calls clearCache() mid-generation: nothing is released, the result equals the undisturbed run
     vcfg = syn.VAE_PRESETS["tiny"]
     pipe = Flux2Pipeline(model=cfg, vae_variant=vcfg).load_models(P, syn.make_vae_weights(vcfg))
-    kw = dict(height=64, width=64, steps=3, precomputed_embeddings=inp["txt"], noise=inp["noise"])
+    kw = dict(height=64, width=64, steps=3, precomputed_embeddings=inp["txt"], noise=inp["noise"], return_latents=True)
     ref = pipe.generate_with_result("textToImage", **kw)
     freed_in_hook = []
 
