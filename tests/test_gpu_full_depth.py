@@ -215,10 +215,13 @@ def test_klein9b_full_depth_forward_bf16_and_fp8_vs_oracles(klein9b_fp8, flux2mi
     de-correlate — the free-running statement stays relative to q (< 0.9 q, effect reproduced in size and direction).
 
     The SHARP statement is TEACHER-FORCED: every one of the 32 blocks is fed the emulation's own block input through
-    flux2mi_dit_forward_block and must reproduce the emulation's block output to <= 1e-2 and its INCREMENT (output - input: what the
-    block computes) to within 0.6 of that block's own quantisation effect q_b (the emulation's increment against the f32 oracle's on
-    the same input).  Anything wrong between the ops of a block — a scale applied twice, halves swapped, a stale buffer — is an O(1)
-    increment error; it cannot hide behind 32 blocks of accumulated noise."""
+    flux2mi_dit_forward_block and must reproduce the emulation's block output to <= 3e-3 and its INCREMENT (output - input: what the
+    block computes) to within 0.3 of that block's own quantisation effect q_b = 6.6e-2 (the emulation's increment against the f32
+    oracle's on the same input) — single blocks, one quantisation stage deep, to within 0.06 q_b.  Measured
+    (profiles/r04_e_parity_tests.log): double blocks 1.1e-2 ... 1.4e-2 = 0.17 ... 0.21 q_b (the MLP half re-quantises what the
+    attention half changed: two stages in sequence), single blocks 1.3e-3 ... 2.2e-3 = 0.02 ... 0.034 q_b; outputs <= 1.6e-3.
+    Anything wrong between the ops of a block — a scale applied twice, halves swapped, a stale buffer — is an O(1) increment error; it
+    cannot hide behind 32 blocks of accumulated noise."""
     from flux2mi import synthetic as syn
     from flux2mi.api import DiT
     k = klein9b_fp8
@@ -258,15 +261,17 @@ def test_klein9b_full_depth_forward_bf16_and_fp8_vs_oracles(klein9b_fp8, flux2mi
         rows.append((layer, rel_l2(y, y_ref), rel_l2(y - x_in, y_ref - x_in), q_b))
     print("teacher-forced blocks (layer: rel-L2 of the output / of the increment / the block's own quantisation effect q_b): "
           + ", ".join(f"{l}: {a:.1e} / {b:.1e} / {c:.1e}" for l, a, b, c in rows))
-    assert max(r[1] for r in rows) < 1e-2, rows
-    assert all(r[2] < 0.6 * r[3] for r in rows), rows
+    assert max(r[1] for r in rows) < 3e-3, rows
+    assert all(r[2] < 0.3 * r[3] for r in rows), rows
+    assert all(r[2] < 0.06 * r[3] for r in rows[nd:]), rows[nd:]
 
 
 def test_klein9b_bf16_teacher_forced_blocks_vs_store_point_oracle(klein9b_fp8, flux2mi, ctx):
     """The bf16 model, every block teacher-forced against the oracle with the HIP path's bf16 store points (`device_roundings`): the
-    increment of each of the 32 blocks within 3e-3 of the emulation's (measured 2e-4 ... 1.5e-3: six bf16 store points in sequence per
-    double block, three per single block), its output within 5e-4.  Against the plain f32 oracle the same increments sit ~4e-3 away
-    (the bf16 storage itself), which is why a sharp bf16 check needs the store-point emulation."""
+    increment of each of the 32 blocks within 2e-3 of the emulation's (double blocks, six bf16 store points in sequence: measured
+    9.5e-4 ... 1.1e-3) and within 5e-4 (single blocks, three: 1.8e-4 ... 2.4e-4), its output within 3e-4 (<= 1.3e-4).  Against the
+    plain f32 oracle the same increments sit ~4e-3 away (the bf16 storage itself), which is why a sharp bf16 check needs the
+    store-point emulation (profiles/r04_e_parity_tests.log)."""
     from flux2mi import synthetic as syn
     from flux2mi.api import DiT
     k = klein9b_fp8
@@ -287,8 +292,9 @@ def test_klein9b_bf16_teacher_forced_blocks_vs_store_point_oracle(klein9b_fp8, f
         rows.append((layer, rel_l2(y, y_ref), rel_l2(y - x_in, y_ref - x_in)))
     dit16.close()
     print("bf16 teacher-forced blocks (layer: output / increment): " + ", ".join(f"{l}: {a:.1e} / {b:.1e}" for l, a, b in rows))
-    assert max(r[1] for r in rows) < 5e-4, rows
-    assert max(r[2] for r in rows) < 3e-3, rows
+    assert max(r[1] for r in rows) < 3e-4, rows
+    assert max(r[2] for r in rows) < 2e-3, rows
+    assert max(r[2] for r in rows[nd:]) < 5e-4, rows[nd:]
 
 
 def test_config_d_klein9b_fp8_1024_28_steps_properties(klein9b_fp8):
