@@ -407,6 +407,8 @@ def main():
         "dit_step_tflops": round(step_flops / (step_ms * 1e-3) / 1e12, 2) if step_ms > 0 else None,
         "dit_step_mfma_frac": round(step_flops / (step_ms * 1e-3) / 1e12 / peak, 4) if step_ms > 0 else None,
         "attention_softmax": None if dry else pipe.transformer.attention_softmax_paths(),
+        # KV pieces per (head, query block) item of the attention's partial last round on this GPU (1 = whole items only)
+        "attention_kv_split_pieces": None if dry else pipe.ctx.op_attention_split_info(S_all, cfg["heads"])[0],
         "output_check": {"latents_finite": True, "image_crc32": checksum, "u8_histogram": hist},
         "model_load_s": round(t_load, 2),
         "roofline": roofline,

@@ -157,6 +157,7 @@ PROTOTYPES = {
     "flux2mi_dit_forward": (_I, [_P, _P, _I, _P, _I, _F, _F, _P, _P, _P, _I]),
     "flux2mi_dit_forward_block": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _F, _F, _P, _P, _P]),
     "flux2mi_dit_last_modulation": (_I, [_P, _P, _I64]),
+    "flux2mi_op_attention_split_info": (_I, [_P, _I, _I, _PI, _PI]),
     "flux2mi_dit_set_attention_softmax": (_I, [_P, _I]),
     "flux2mi_dit_attention_softmax_info": (_I, [_P, _PI, _PI]),
     "flux2mi_kv_cache_create": (_I, [_P, _I, _I, C.POINTER(_P)]),

@@ -440,6 +440,12 @@ class Context:
         self._exit()
         return out
 
+    def op_attention_split_info(self, S: int, heads: int):
+        """(KV pieces per item of the partial last round — 1 = whole items only —, compute units) of the blocks' attention on this GPU."""
+        f, n = C.c_int(0), C.c_int(0)
+        check(lib().flux2mi_op_attention_split_info(self.handle, S, heads, C.byref(f), C.byref(n)))
+        return int(f.value), int(n.value)
+
     def op_attention_qk8(self, q8: torch.Tensor, k8: torch.Tensor, v: torch.Tensor, heads: int, q_exp: int, k_exp: int, score_bound_log2: float) -> torch.Tensor:
         """q8 / k8: e4m3 bytes (torch.float8_e4m3fn or uint8) [S, heads*128], q8 = q 2^q_exp with q pre-scaled by log2(e)/sqrt(128),
         k8 = k 2^k_exp; v bf16 [S, heads*128]: the fp8 models' attention."""

@@ -342,104 +342,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
                                 blockIdx.y, blockIdx.x * (NW * 32), 0, 1 << 30, nullptr);
 }
 
-#ifdef FLUX2MI_DEV   // KV-split of the partial last round: correct and bit-reproducible, but NO faster ("tried and dropped")
-// ---- wave quantisation: (q-blocks x heads) items rarely fill the chip's workgroup slots a whole number of times
-// (S 4608 x 24 heads: 432 items of 256 rows on 256 CUs = 1.69 rounds, i.e. 84 % of the chip for two rounds).  The items of
-// the last, partial round (the "tail") are therefore cut along the KEYS into `n_pieces` equal runs of KV tiles, one
-// workgroup each (a piece covers at most two items since tail < slots): workgroups [0, n_full) of the grid run whole
-// items exactly as attn_fwd_kernel does, workgroups [n_full, n_full + n_pieces) run pieces and leave un-normalised
-// partial states, which attn_combine_kernel adds up in a FIXED order (bit-reproducible) — with the fixed-offset softmax
-// a plain sum, with the running maximum a rescaled one.
-struct AttnSplit {
-    int n_full;        // whole items (item = head * qblocks + qb, the order of attn_fwd_kernel's grid), workgroups [0, n_full)
-    int n_tail;        // items n_full .. n_full + n_tail - 1 are split
-    int n_pieces;      // workgroups that share the tail's n_tail * nt KV tiles
-    int nt;            // KV tiles per item
-    int qblocks;
-    float* ws;         // [2 * n_pieces] partial slots of (66 * NW*64) floats
-};
-__device__ __forceinline__ long split_bound(const AttnSplit& sp, int p) { return (long)p * sp.n_tail * sp.nt / sp.n_pieces; }
-
-template <int NW, int FIXM>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_split_kernel(const uint16_t* __restrict__ q,
-                                                          const uint16_t* __restrict__ k, int ldqk,
-                                                          const uint16_t* __restrict__ vt, int s_pad,
-                                                          uint16_t* __restrict__ out, int ldo, int Sq, int S,
-                                                          float scale_log2e, float fixed_m, AttnSplit sp) {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE_BYTES];
-    constexpr int BQ = NW * 32;
-    const int bid = blockIdx.x;
-    if (bid < sp.n_full) {
-        attn_item<false, NW, FIXM>(smem, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, scale_log2e, S, 1, fixed_m, 0, bid / sp.qblocks,
-                                   (bid % sp.qblocks) * BQ, 0, 1 << 30, nullptr);
-        return;
-    }
-    const int p = bid - sp.n_full;
-    const long t0 = split_bound(sp, p), t1 = split_bound(sp, p + 1);
-    int j = 0;
-    for (long tt = t0; tt < t1; ++j) {
-        const int it = (int)(tt / sp.nt), k0 = (int)(tt - (long)it * sp.nt);
-        const int k1 = (int)min((long)sp.nt, t1 - (long)it * sp.nt);
-        const int item = sp.n_full + it;
-        const bool whole = k0 == 0 && k1 == sp.nt;
-        if (j > 0) __syncthreads();   // the previous segment's last LDS reads are done before this one restages
-        attn_item<false, NW, FIXM>(smem, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, scale_log2e, S, 1, fixed_m, 0, item / sp.qblocks,
-                                   (item % sp.qblocks) * BQ, k0, k1, whole ? nullptr : sp.ws + (size_t)(2 * p + j) * (66 * NW * 64));
-        tt = (long)it * sp.nt + k1;
-    }
-}
-
-// One workgroup per split item, thread mapping = the attention's: sums the item's pieces in piece order.
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn_combine_kernel(uint16_t* __restrict__ out, int ldo, int Sq, AttnSplit sp) {
-    constexpr int NT = NW * 64, BQ = NW * 32;
-    const int it = blockIdx.x, item = sp.n_full + it;
-    const int t = threadIdx.x, lane = t & 63, wid = t >> 6, l31 = lane & 31, hi = lane >> 5;
-    const long lo = (long)it * sp.nt, hi_t = lo + sp.nt;
-    // pieces p with [bound(p), bound(p+1)) intersecting [lo, hi_t)
-    int p0 = (int)(lo * sp.n_pieces / ((long)sp.n_tail * sp.nt));
-    while (p0 > 0 && split_bound(sp, p0) > lo) --p0;
-    while (split_bound(sp, p0 + 1) <= lo) ++p0;
-    float m_max = -INFINITY;
-    int np = 0;
-    for (int p = p0; p < sp.n_pieces && split_bound(sp, p) < hi_t; ++p, ++np) {
-        const int j = split_bound(sp, p) < lo ? 1 : 0;   // the piece's second item when it started in the previous one
-        m_max = fmaxf(m_max, sp.ws[(size_t)(2 * p + j) * (66 * NT) + (size_t)65 * NT + t]);
-    }
-    if (np == 1 && split_bound(sp, p0) <= lo && split_bound(sp, p0 + 1) >= hi_t) return;   // written whole by its piece
-    float acc[64], l = 0.f;
-#pragma unroll
-    for (int i = 0; i < 64; ++i) acc[i] = 0.f;
-    for (int p = p0; p < sp.n_pieces && split_bound(sp, p) < hi_t; ++p) {
-        const int j = split_bound(sp, p) < lo ? 1 : 0;
-        const float* ws = sp.ws + (size_t)(2 * p + j) * (66 * NT);
-        const float f = __builtin_amdgcn_exp2f(ws[(size_t)65 * NT + t] - m_max);   // 1 for the fixed-offset softmax
-        l += ws[(size_t)64 * NT + t] * f;
-#pragma unroll
-        for (int i = 0; i < 64; ++i) acc[i] += ws[(size_t)i * NT + t] * f;
-    }
-    const float inv = 1.0f / xhalf_sum(l);
-    const int qrow = (item % sp.qblocks) * BQ + wid * 32 + l31;
-    if (qrow < Sq) {
-        uint16_t* op = out + (size_t)qrow * ldo + (item / sp.qblocks) * HD + hi * 4;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 v;
-                v.x = pack_bf16x2(acc[db * 16 + g * 4 + 0] * inv, acc[db * 16 + g * 4 + 1] * inv);
-                v.y = pack_bf16x2(acc[db * 16 + g * 4 + 2] * inv, acc[db * 16 + g * 4 + 3] * inv);
-                *reinterpret_cast<uint2*>(op + db * 32 + g * 8) = v;
-            }
-    }
-}
-
-#endif
 
 }  // namespace
 
 int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
-                        int ldo, int Sq, int S, int heads, bool data_offset);  // attention64b.hip (MFMA 16x16x32)
+                        int ldo, int Sq, int S, int heads, bool data_offset, int n_cu, float* split_ws);  // attention64b.hip (MFMA 16x16x32)
 
 // Offset = the bound (scores not pre-scaled): p in [2^(-2 bound), 1], bound <= 40 keeps 2^-80 far inside the f32 / bf16 exponent range.
 // Offset = 0 on pre-scaled q (the model's form): p in [2^-bound, 2^bound]; with bound <= 80 a row sum stays below 2^80 S and an
@@ -451,9 +358,6 @@ bool attention_uses_fixed_offset(float score_bound_log2, bool q_prescaled) {
     }();
     return fixm_on && score_bound_log2 > 0.f && score_bound_log2 <= (q_prescaled ? 80.f : 40.f);
 }
-
-// 2 partial slots per piece; <= n_cu pieces of 66 x 512 floats (8-wave workgroups) or <= 2 n_cu pieces of 66 x 256 (4-wave)
-size_t attention_split_ws_bytes(int n_cu) { return (size_t)n_cu * 2 * (66 * 512) * 4; }
 
 int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
                      int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads, float score_bound_log2, bool q_prescaled,
@@ -470,46 +374,13 @@ int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, i
     const bool fixm = attention_uses_fixed_offset(score_bound_log2, q_prescaled);
     const int fx = fixm ? (q_prescaled ? 2 : 1) : 0;
     const int qblocks = (Sq + nw * 32 - 1) / (nw * 32);
-#ifdef FLUX2MI_DEV
-    // ---- KV-split of the partial last round (see AttnSplit): development library only, FLUX2MI_ATTN_SPLIT=1.  Measured on
-    // S 4608 x 24 / 32 / 48 heads: the same time as whole items (the chip clocks higher while the partial round leaves CUs
-    // idle, which already gives back most of the quantisation loss), and slower on small grids (profiles/r02_attn_kv_split_vs_whole.log).
-    static const int split_on = [] {
-        const char* e = F2_DEV_ENV("FLUX2MI_ATTN_SPLIT");
-        return e ? atoi(e) : 0;
-    }();
-    if (split_on && split_ws != nullptr && n_cu > 0) {
-        const int slots = n_cu * (nw == 4 ? 2 : 1);
-        const int items = qblocks * heads, nt = (S + BKV - 1) / BKV;
-        AttnSplit sp;
-        sp.n_tail = items % slots;
-        sp.n_full = items - sp.n_tail;
-        sp.nt = nt;
-        sp.qblocks = qblocks;
-        sp.ws = split_ws;
-        // pieces of >= 3 KV tiles, at least one per tail item (a piece then spans at most two items), at most one per slot
-        sp.n_pieces = (int)std::min<long>(slots, (long)sp.n_tail * nt / 3);
-        // the tail costs n_tail / n_pieces of an item's time instead of 1, plus ~0.1 for prologues, partial states and the combine
-        if (sp.n_tail > 0 && sp.n_pieces >= sp.n_tail && (double)sp.n_tail / sp.n_pieces + 0.12 < 1.0) {
-            const dim3 grid(sp.n_full + sp.n_pieces), block(nw * 64);
-#define ATTN_SPLIT_GO(NW_, FX_) hipLaunchKernelGGL((attn_split_kernel<NW_, FX_>), grid, block, 0, stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, scale_log2e, score_bound_log2, sp)
-            if (nw == 8) { if (fx == 2) ATTN_SPLIT_GO(8, 2); else if (fx) ATTN_SPLIT_GO(8, 1); else ATTN_SPLIT_GO(8, 0); }
-            else { if (fx == 2) ATTN_SPLIT_GO(4, 2); else if (fx) ATTN_SPLIT_GO(4, 1); else ATTN_SPLIT_GO(4, 0); }
-#undef ATTN_SPLIT_GO
-            if (nw == 8) hipLaunchKernelGGL((attn_combine_kernel<8>), dim3(sp.n_tail), block, 0, stream, out, ldo, Sq, sp);
-            else hipLaunchKernelGGL((attn_combine_kernel<4>), dim3(sp.n_tail), block, 0, stream, out, ldo, Sq, sp);
-            return hipGetLastError() == hipSuccess ? 0 : 2;
-        }
-    }
-#endif
-    (void)split_ws; (void)n_cu;
     // pre-scaled Q (the model's form): the one-wave-per-SIMD kernel (attention64b.hip), with the fixed zero offset when the score
     // bound allows it and with its per-query data offset otherwise (the "online" count of flux2mi_dit_attention_softmax_info).
     // FLUX2MI_ATTN64=0 with the dev library keeps the kernel below (A/B runs)
     if (q_prescaled && fx != 1 && !nw_env) {
         static const int a64 = [] { const char* e = F2_DEV_ENV("FLUX2MI_ATTN64"); return e ? atoi(e) : 2; }();   // dev: 0 = the kernel below
         if (a64 != 0) {
-            const int r64 = launch_attention64b(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads, fx != 2);
+            const int r64 = launch_attention64b(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads, fx != 2, n_cu, split_ws);
             if (r64 != 1) return r64;
         }
     }

@@ -35,6 +35,14 @@ constexpr int HD = 128, BKV = 64;
 // QK8: the output as block-scaled e4m3 instead of bf16 (the A operand of the fp8 models' proj / linear2): bytes q8[row * ld + head * 128 + d],
 // scale bytes bs[head * bs_ld + row / 16] (one per 16 queries x this head's 128 columns); q8 = nullptr: the bf16 output
 struct AttnBlocksOut { uint8_t* q8; int ld; uint8_t* bs; int bs_ld; };
+// KV-split of the partial last round (fixed-offset softmax only: partial O and row sums of disjoint key ranges just add).  The
+// (head, query block) items rarely fill the CUs a whole number of times — Klein-9B 32 heads x 18 = 576 items on 256 CUs = 2.25 rounds
+// paid as 3, Dev 864 = 3.375 paid as 4.  With f > 1 the launch is 1-D: workgroups [0, n_whole) run whole items exactly as before,
+// workgroup n_whole + r runs KV tiles [part nt / f, (part + 1) nt / f) of item n_whole + r / f, part = r % f, and leaves its raw
+// accumulators in ws[r] (SPLIT_PIECE_FLOATS floats); attn64b_combine_kernel adds an item's f pieces in part order (bit-reproducible) and
+// stores through the same epilogue.  f = 1: the plain 2-D launch, nothing else changes.
+struct AttnSplit { int n_whole; int f; int qblocks; float* ws; };
+constexpr int SPLIT_PIECE_FLOATS = 33 * 256 * 4;   // 32 accumulator quads + the four row sums, per lane
 constexpr int KT = BKV * HD * 2;     // 16 KB
 constexpr int VT = HD * BKV * 2;     // 16 KB
 constexpr int VRING = 3 * KT;        // LDS: K ring (3 slots), then V ring (3 slots) = 96 KB
@@ -80,7 +88,8 @@ static_assert(x1_gap(31) == T + 24 && c1_gap(15) == T + 31 && vr_gap(15) == 135 
 template <bool DOFF, bool QK8 = false>
 __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, int ldqk,
                                                          const uint16_t* __restrict__ vt, int s_pad, uint16_t* __restrict__ out,
-                                                         int ldo, int Sq, int S, unsigned long long* trace, int qk8_exps, AttnBlocksOut bo) {
+                                                         int ldo, int Sq, int S_total, unsigned long long* trace, int qk8_exps, AttnBlocksOut bo,
+                                                         AttnSplit sp) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[3 * KT + 3 * VT];
     __shared__ unsigned bo_max[4][4];     // AttnBlocksOut: block maxima [wave][query block], as float bits
     __shared__ int s_again;               // DOFF: some wave of the workgroup asks for another pass
@@ -90,10 +99,27 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
     // multiple of 8, XCD x takes heads x, x + 8, ... and runs the query blocks of one head back to back, so that the workgroups of a head
     // stream its K / V^T through ONE L2 instead of eight.
     int head = blockIdx.y, qblk = blockIdx.x;
-    if ((gridDim.y & 7) == 0) {
-        const int id = blockIdx.y * gridDim.x + blockIdx.x, xcd = id & 7, k = id >> 3;
-        head = (k / (int)gridDim.x) * 8 + xcd;
-        qblk = k % (int)gridDim.x;
+    int S = S_total, kv_tile0 = 0;          // this workgroup's keys: [kv_tile0 * 64, kv_tile0 * 64 + S)
+    float* piece_ws = nullptr;              // a piece of a KV-split item: raw accumulators go here
+    if (sp.f <= 1) {
+        if ((gridDim.y & 7) == 0) {
+            const int id = blockIdx.y * gridDim.x + blockIdx.x, xcd = id & 7, k = id >> 3;
+            head = (k / (int)gridDim.x) * 8 + xcd;
+            qblk = k % (int)gridDim.x;
+        }
+    } else {   // 1-D launch (the launcher guarantees heads % 8 == 0 and !DOFF): items in the same XCD-aware order, then the pieces
+        int item = blockIdx.x;
+        if (item >= sp.n_whole) {
+            const int r = item - sp.n_whole, part = r % sp.f, ntf = (S_total + BKV - 1) / BKV;
+            item = sp.n_whole + r / sp.f;
+            kv_tile0 = part * ntf / sp.f;
+            const int kv_tile1 = (part + 1) * ntf / sp.f;
+            S = min(S_total, kv_tile1 * BKV) - kv_tile0 * BKV;
+            piece_ws = sp.ws + (size_t)r * SPLIT_PIECE_FLOATS;
+        }
+        const int xcd = item & 7, k = item >> 3;
+        head = (k / sp.qblocks) * 8 + xcd;
+        qblk = k % sp.qblocks;
     }
     const int q0 = qblk * 256 + wid * 64;
     const int nt = (S + BKV - 1) / BKV;   // the last tile may be partial: its missing keys score against key S - 1 again (clamped rows: finite
@@ -153,9 +179,9 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
             voffV[j] = (uint32_t)vrow * (uint32_t)s_pad * 2u + (uint32_t)(((lane & 7) ^ ((vrow >> 1) & 7)) << 4);
         }
     }
-    const uint8_t* kb8 = QK8 ? reinterpret_cast<const uint8_t*>(k) + head * HD : reinterpret_cast<const uint8_t*>(k + head * HD);
-    const uint8_t* vb8 = reinterpret_cast<const uint8_t*>(vt + (size_t)head * HD * s_pad);
     const uint32_t k_tile_bytes = (uint32_t)BKV * (uint32_t)ldqk * (QK8 ? 1u : 2u);
+    const uint8_t* kb8 = (QK8 ? reinterpret_cast<const uint8_t*>(k) + head * HD : reinterpret_cast<const uint8_t*>(k + head * HD)) + (size_t)kv_tile0 * k_tile_bytes;
+    const uint8_t* vb8 = reinterpret_cast<const uint8_t*>(vt + (size_t)head * HD * s_pad) + (size_t)kv_tile0 * (BKV * 2);
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
     const uint32_t m0_wave = __builtin_amdgcn_readfirstlane(lds_base + wid * 1024);
 
@@ -512,6 +538,16 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
         }
     }
 
+    // ---- a piece of a KV-split item: the raw accumulators, [quad index][thread] as 16-byte stores (4 KB per instruction), for the combine kernel
+    if (!DOFF && piece_ws != nullptr) {
+        f32x4* w4 = reinterpret_cast<f32x4*>(piece_ws) + t;
+#pragma unroll
+        for (int db = 0; db < 8; ++db)
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb) w4[(db * 4 + qb) * 256] = o[db][qb];
+        w4[32 * 256] = f32x4{lacc[0][0], lacc[1][0], lacc[2][0], lacc[3][0]};
+        return;
+    }
     // ---- normalise and store.  o[db][qb][r]: d = db*16 + 4 g4 + r, query = q0 + qb*16 + c16; lacc[qb][*] = the row sum of that query
     if (QK8 && bo.q8 != nullptr) {
         // fp8 models: O as block-scaled e4m3 (kernels.h, GemmProblem::a_bscale) — the 16 queries of a query block x this head's 128
@@ -564,6 +600,77 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
     }
 }
 
+// One workgroup per split item, thread mapping = the attention's (lane (c16, g4) of wave wid): adds the item's f pieces in part order,
+// then the attention kernel's own epilogue (bf16, or the block-scaled e4m3 of the fp8 models).
+template <bool QK8>
+__global__ __launch_bounds__(256) void attn64b_combine_kernel(uint16_t* __restrict__ out, int ldo, int Sq, AttnBlocksOut bo, AttnSplit sp) {
+    __shared__ unsigned bo_max[4][4];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6, c16 = lane & 15, g4 = lane >> 4;
+    const int it = blockIdx.x, item = sp.n_whole + it;
+    const int xcd = item & 7, kk = item >> 3;
+    const int head = (kk / sp.qblocks) * 8 + xcd, qblk = kk % sp.qblocks;
+    const int q0 = qblk * 256 + wid * 64;
+    f32x4 o[8][4], l4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int db = 0; db < 8; ++db)
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int part = 0; part < sp.f; ++part) {
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(sp.ws + (size_t)(it * sp.f + part) * SPLIT_PIECE_FLOATS) + t;
+#pragma unroll
+        for (int db = 0; db < 8; ++db)
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb) o[db][qb] += w4[(db * 4 + qb) * 256];
+        l4 += w4[32 * 256];
+    }
+    if (QK8 && bo.q8 != nullptr) {
+        if (lane < 4) bo_max[wid][lane] = 0u;
+        float inv4[4];
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            inv4[qb] = 1.0f / l4[qb];
+            float mx = 0.f;
+#pragma unroll
+            for (int db = 0; db < 8; ++db)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(o[db][qb][r] * inv4[qb]));
+            mx = row16_max_nonneg(mx);
+            if ((lane & 15) == 15) atomicMax(&bo_max[wid][qb], __float_as_uint(mx));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            const int e = fp8_block_exp(__uint_as_float(bo_max[wid][qb]));
+            const float mult = ldexpf(1.0f, e) * inv4[qb];
+            const int qrow = q0 + qb * 16 + c16;
+            if (lane == 0 && q0 + qb * 16 < Sq) bo.bs[(size_t)head * bo.bs_ld + ((q0 + qb * 16) >> 4)] = (uint8_t)(127 - e);
+            if (qrow < Sq) {
+                uint8_t* op = bo.q8 + (size_t)qrow * bo.ld + head * HD + g4 * 4;
+#pragma unroll
+                for (int db = 0; db < 8; ++db)
+                    *reinterpret_cast<uint32_t*>(op + db * 16) =
+                        pack_fp8x4_inrange(o[db][qb][0] * mult, o[db][qb][1] * mult, o[db][qb][2] * mult, o[db][qb][3] * mult);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+        const float inv = 1.0f / l4[qb];
+        const int qrow = q0 + qb * 16 + c16;
+        if (qrow < Sq) {
+            uint16_t* op = out + (size_t)qrow * ldo + head * HD + g4 * 4;
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                uint2 v;
+                v.x = pack_bf16x2(o[db][qb][0] * inv, o[db][qb][1] * inv);
+                v.y = pack_bf16x2(o[db][qb][2] * inv, o[db][qb][3] * inv);
+                *reinterpret_cast<uint2*>(op + db * 16) = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // 0 launched / 1 not this kernel's case (the caller falls back) / 2 launch error.
@@ -582,27 +689,51 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
 #define A64B_CAT(a, b, c) A64B_CAT2(a, b, c)
 #define A64B_VARIANT A64B_CAT(launch_attention64b_v, ATTN64B_DOFF, ATTN64B_QK8)
 // q, k: bf16 rows of ldqk elements, or (QK8) e4m3 rows of ldqk bytes with qk8_exps = (127 - qe) | (127 - ke) << 8 (q8 = q 2^qe, k8 = k 2^ke)
-int launch_attention64b_v00(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int, uint8_t*, int, uint8_t*, int);
-int launch_attention64b_v10(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int, uint8_t*, int, uint8_t*, int);
-int launch_attention64b_v01(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int, uint8_t*, int, uint8_t*, int);
-int launch_attention64b_v11(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int, uint8_t*, int, uint8_t*, int);
+int attention64b_split_factor(int Sq, int S, int heads, int n_cu);
+int launch_attention64b_v00(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int, uint8_t*, int, uint8_t*, int, int, float*);
+int launch_attention64b_v10(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int, uint8_t*, int, uint8_t*, int, int, float*);
+int launch_attention64b_v01(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int, uint8_t*, int, uint8_t*, int, int, float*);
+int launch_attention64b_v11(hipStream_t, const void*, const void*, int, const uint16_t*, int, uint16_t*, int, int, int, int, int, uint8_t*, int, uint8_t*, int, int, float*);
 
 int A64B_VARIANT(hipStream_t stream, const void* q, const void* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out, int ldo, int Sq, int S,
-                 int heads, int qk8_exps, uint8_t* out8, int ld8o, uint8_t* bs, int bs_ld) {
+                 int heads, int qk8_exps, uint8_t* out8, int ld8o, uint8_t* bs, int bs_ld, int n_cu, float* split_ws) {
     if (out8 && (!ATTN64B_QK8 || !bs || (ld8o & 3) || (reinterpret_cast<uintptr_t>(out8) & 3) || bs_ld < (Sq + 15) / 16)) return 1;
     const AttnBlocksOut bo{out8, ld8o, bs, bs_ld};
     if (S < 1 || Sq <= 0 || s_pad < ((S + BKV - 1) / BKV) * BKV) return 1;
     const unsigned long long esz = ATTN64B_QK8 ? 1 : 2;
     if ((unsigned long long)S * (unsigned long long)ldqk * esz >= (1ull << 31) || (unsigned long long)HD * (unsigned long long)s_pad * 2 >= (1ull << 31)) return 1;
     if (ATTN64B_QK8 && ((ldqk & 15) || (reinterpret_cast<uintptr_t>(q) & 15) || (reinterpret_cast<uintptr_t>(k) & 15))) return 1;
-    const dim3 grid((Sq + 255) / 256, heads), block(256);
+    dim3 grid((Sq + 255) / 256, heads);
+    const dim3 block(256);
+    // KV-split of the partial last round (AttnSplit): only the fixed-offset form, heads % 8 == 0 (the 1-D launch keeps the XCD-aware item
+    // order), a tail of at most half the CUs (each tail item then splits into f >= 2 equal pieces that still fit ONE round) and pieces of
+    // at least 8 KV tiles (shorter ones are all prologue).  split_ws: attention64b_split_ws_bytes(n_cu) bytes, or nullptr = never split.
+    AttnSplit sp{0, 1, (int)grid.x, nullptr};
+    static const bool split_on = [] {
+        const char* e = F2_DEV_ENV("FLUX2MI_ATTN_SPLIT");
+        return e ? atoi(e) != 0 : true;
+    }();
+    if (!ATTN64B_DOFF && split_on && split_ws != nullptr) {
+        const int f = attention64b_split_factor(Sq, S, heads, n_cu);
+        if (f >= 2) {
+            const int items = (int)grid.x * heads, tail = items % n_cu;
+            sp.n_whole = items - tail;
+            sp.f = f;
+            sp.ws = split_ws;
+            grid = dim3(sp.n_whole + tail * f, 1);
+        }
+    }
     unsigned long long* trace = nullptr;
     static const char* trace_env = F2_DEV_ENV("FLUX2MI_ATTN_TRACE");
     static int seen = 0;
     const size_t tn = (size_t)grid.x * grid.y * 4 * 2;
     if (trace_env && ++seen % 8 == 0 && hipMalloc((void**)&trace, tn * 8) != hipSuccess) trace = nullptr;
     hipLaunchKernelGGL((attn64b_kernel<(ATTN64B_DOFF != 0), (ATTN64B_QK8 != 0)>), grid, block, 0, stream, reinterpret_cast<const uint16_t*>(q),
-                       reinterpret_cast<const uint16_t*>(k), ldqk, vt, s_pad, out, ldo, Sq, S, trace, qk8_exps, bo);
+                       reinterpret_cast<const uint16_t*>(k), ldqk, vt, s_pad, out, ldo, Sq, S, trace, qk8_exps, bo, sp);
+    if (sp.f > 1) {
+        const int tail = ((int)grid.x - sp.n_whole) / sp.f;
+        hipLaunchKernelGGL((attn64b_combine_kernel<(ATTN64B_QK8 != 0)>), dim3(tail), block, 0, stream, out, ldo, Sq, bo, sp);
+    }
     if (trace) {
         std::vector<unsigned long long> h(tn);
         (void)hipStreamSynchronize(stream);
@@ -618,16 +749,31 @@ int A64B_VARIANT(hipStream_t stream, const void* q, const void* k, int ldqk, con
 }
 
 #if !ATTN64B_DOFF && !ATTN64B_QK8
+size_t attention64b_split_ws_bytes(int n_cu) { return (size_t)(n_cu > 0 ? n_cu : 0) * SPLIT_PIECE_FLOATS * 4; }
+// Pieces per tail item the launcher cuts (1 = no split): heads % 8 == 0 (the 1-D launch keeps the XCD-aware item order), more than one
+// round of items, a tail of at most half the CUs (f = n_cu / tail >= 2 pieces per item still fit ONE round), pieces of >= 8 KV tiles
+// (shorter ones are all prologue), at most 8 per item.
+int attention64b_split_factor(int Sq, int S, int heads, int n_cu) {
+    if (n_cu < 16 || (heads & 7) != 0 || Sq <= 0 || S <= 0) return 1;
+    const int items = ((Sq + 255) / 256) * heads, tail = items % n_cu, nt = (S + BKV - 1) / BKV;
+    if (items <= n_cu || tail == 0) return 1;
+    int f = n_cu / tail;
+    if (f > nt / 8) f = nt / 8;
+    if (f > 8) f = 8;
+    return f >= 2 ? f : 1;
+}
+
 int launch_attention64b(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt, int s_pad, uint16_t* out,
-                        int ldo, int Sq, int S, int heads, bool data_offset) {
-    return data_offset ? launch_attention64b_v10(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads, 0, nullptr, 0, nullptr, 0)
-                       : launch_attention64b_v00(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads, 0, nullptr, 0, nullptr, 0);
+                        int ldo, int Sq, int S, int heads, bool data_offset, int n_cu, float* split_ws) {
+    return data_offset ? launch_attention64b_v10(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads, 0, nullptr, 0, nullptr, 0, n_cu, split_ws)
+                       : launch_attention64b_v00(stream, q, k, ldqk, vt, s_pad, out, ldo, Sq, S, heads, 0, nullptr, 0, nullptr, 0, n_cu, split_ws);
 }
 int launch_attention64b_qk8(hipStream_t stream, const uint8_t* q8, const uint8_t* k8, int ld8, int q_exp, int k_exp, const uint16_t* vt, int s_pad,
-                            uint16_t* out, int ldo, int Sq, int S, int heads, bool data_offset, uint8_t* out8, int ld8o, uint8_t* bs, int bs_ld) {
+                            uint16_t* out, int ldo, int Sq, int S, int heads, bool data_offset, uint8_t* out8, int ld8o, uint8_t* bs, int bs_ld,
+                            int n_cu, float* split_ws) {
     if (q_exp < -60 || q_exp > 60 || k_exp < -60 || k_exp > 60) return 1;   // negative: operands larger than e4m3's 448 were scaled DOWN
     const int exps = (127 - q_exp) | ((127 - k_exp) << 8);
-    return data_offset ? launch_attention64b_v11(stream, q8, k8, ld8, vt, s_pad, out, ldo, Sq, S, heads, exps, out8, ld8o, bs, bs_ld)
-                       : launch_attention64b_v01(stream, q8, k8, ld8, vt, s_pad, out, ldo, Sq, S, heads, exps, out8, ld8o, bs, bs_ld);
+    return data_offset ? launch_attention64b_v11(stream, q8, k8, ld8, vt, s_pad, out, ldo, Sq, S, heads, exps, out8, ld8o, bs, bs_ld, n_cu, split_ws)
+                       : launch_attention64b_v01(stream, q8, k8, ld8, vt, s_pad, out, ldo, Sq, S, heads, exps, out8, ld8o, bs, bs_ld, n_cu, split_ws);
 }
 #endif

@@ -766,9 +766,7 @@ int ensure_workspace(flux2mi_dit* m, int S, int s_img) {
         F2_CHECK_HIP(hipMemsetAsync(m->vt.ptr, 0, m->vt.bytes, m->ctx->stream));
     }
     F2_TRY(m->comb.reserve(Sz * 4 * d * 2));
-#ifdef FLUX2MI_DEV
-    if (m->ctx->n_cu > 0) F2_TRY(m->ctx->attn_ws.reserve(attention_split_ws_bytes(m->ctx->n_cu)));
-#endif
+    if (m->ctx->n_cu > 0) F2_TRY(m->ctx->attn_ws.reserve(attention64b_split_ws_bytes(m->ctx->n_cu)));   // KV-split pieces (attention64b.hip)
     F2_TRY(m->mods.reserve((size_t)(256 + 2 * d + 6 * d + 6 * d + 3 * d + 2 * d) * 4));
     F2_TRY(m->rope.reserve(Sz * 128 * 4 * 2 + Sz * 4 * 4));   // cos, sin f32 [S,128] + positions f32 [S,4]
     F2_TRY(m->lat_bf16.reserve((size_t)s_img * 128 * 2));
@@ -1053,7 +1051,8 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
             prof_before(m->ctx, PROF_ATTENTION);
             // (bsa: the output straight into proj's / linear2's block-scaled operand, row pitch ldo bytes, K-tiles 0 .. d / 128 - 1)
             const int ar = launch_attention64b_qk8(st, qk8_buf, qk8_buf + d, 2 * d, q8_exp, k8_exp, vt, s_pad, o_buf, ldo, S, S, H,
-                                                   !attention_uses_fixed_offset(score_bound, true), attn_blocks ? xq2 : nullptr, ldo, xbs, bs_ld);
+                                                   !attention_uses_fixed_offset(score_bound, true), attn_blocks ? xq2 : nullptr, ldo, xbs, bs_ld,
+                                                   m->ctx->n_cu, m->ctx->attn_ws.as<float>());
             prof_after(m->ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
             F2_LAUNCH(ar, "attention(e4m3 QK)");
             return FLUX2MI_OK;
@@ -1079,7 +1078,7 @@ int dit_forward_impl(flux2mi_dit* m, int mode, flux2mi_kv_cache* cache, const fl
             prof_before(m->ctx, PROF_ATTENTION);
             const int ar = launch_attention(st, qkv + (size_t)rg[i].q0 * 3 * d, qkv + d, 3 * d, vt, s_pad,
                                             o_buf + (size_t)rg[i].q0 * ldo, ldo, rg[i].nq, rg[i].nk, H, score_bound, q_pre,
-                                            m->ctx->attn_ws.as<float>(), m->ctx->n_cu);
+                                            mode == FWD_PLAIN ? m->ctx->attn_ws.as<float>() : nullptr, m->ctx->n_cu);   // KV-split: plain forwards only
             prof_after(m->ctx, PROF_ATTENTION, 4.0 * (double)rg[i].nq * rg[i].nk * d);
             F2_LAUNCH(ar, "attention");
         }
@@ -1571,11 +1570,8 @@ extern "C" int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv_in, void* 
               "v_transpose");
     const uint16_t* q = reinterpret_cast<const uint16_t*>(qkv_in);
     prof_before(ctx, PROF_ATTENTION);
-#ifdef FLUX2MI_DEV
-    if (ctx->n_cu > 0) F2_TRY(ctx->attn_ws.reserve(attention_split_ws_bytes(ctx->n_cu)));
-#endif
     const int r = launch_attention(ctx->stream, q, q + d, 3 * d, vt, s_pad, reinterpret_cast<uint16_t*>(out), d, S, S, heads, 0.f, false,
-                                   ctx->attn_ws.as<float>(), ctx->n_cu);
+                                   nullptr, 0);   // (not pre-scaled: the 8-wave kernels, no KV-split)
     prof_after(ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
     F2_LAUNCH(r, "op_attention");
     return FLUX2MI_OK;
@@ -1592,11 +1588,21 @@ extern "C" int flux2mi_op_attention_prescaled(flux2mi_ctx* ctx, const void* qkv_
     F2_CHECK_HIP(hipMemsetAsync(vt, 0, (size_t)heads * 128 * s_pad * 2, ctx->stream));
     F2_LAUNCH(launch_v_transpose_only(ctx->stream, reinterpret_cast<const uint16_t*>(qkv_in), 3 * d, S, heads, vt, s_pad), "v_transpose");
     const uint16_t* q = reinterpret_cast<const uint16_t*>(qkv_in);
+    if (ctx->n_cu > 0) F2_TRY(ctx->attn_ws.reserve(attention64b_split_ws_bytes(ctx->n_cu)));   // the blocks' form incl. the KV-split of a partial last round
     prof_before(ctx, PROF_ATTENTION);
     const int r = launch_attention(ctx->stream, q, q + d, 3 * d, vt, s_pad, reinterpret_cast<uint16_t*>(out), d, S, S, heads, score_bound_log2, true,
-                                   nullptr, 0);
+                                   ctx->attn_ws.as<float>(), ctx->n_cu);
     prof_after(ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
     F2_LAUNCH(r, "op_attention_prescaled");
+    return FLUX2MI_OK;
+}
+
+// How the blocks' attention cuts the (head, 256-query block) items of [S queries x S keys] on this context's GPU: *pieces = the
+// KV pieces per item of the partial last round (1 = whole items only), *n_cu = the compute units it plans for (tests, bench reports).
+extern "C" int flux2mi_op_attention_split_info(flux2mi_ctx* ctx, int S, int heads, int* pieces, int* n_cu) {
+    F2_REQUIRE(ctx && S > 0 && heads > 0, FLUX2MI_ERR_INVALID_ARG, "op_attention_split_info: bad argument");
+    if (pieces) *pieces = attention64b_split_factor(S, S, heads, ctx->n_cu);
+    if (n_cu) *n_cu = ctx->n_cu;
     return FLUX2MI_OK;
 }
 
@@ -1619,9 +1625,10 @@ extern "C" int flux2mi_op_attention_qk8_blocks(flux2mi_ctx* ctx, const void* q8,
     F2_CHECK_HIP(hipMemsetAsync(vt, 0, (size_t)heads * 128 * s_pad * 2, ctx->stream));
     // a V matrix of its own ([S, d], first V column 0), not the fused [q | k | v] row
     F2_LAUNCH(launch_v_transpose_only(ctx->stream, reinterpret_cast<const uint16_t*>(v), d, S, heads, vt, s_pad, /*v_col0=*/0), "v_transpose");
+    if (ctx->n_cu > 0) F2_TRY(ctx->attn_ws.reserve(attention64b_split_ws_bytes(ctx->n_cu)));
     const int r = launch_attention64b_qk8(ctx->stream, reinterpret_cast<const uint8_t*>(q8), reinterpret_cast<const uint8_t*>(k8), d, q_exp, k_exp, vt, s_pad,
                                           reinterpret_cast<uint16_t*>(out), d, S, S, heads, !attention_uses_fixed_offset(score_bound_log2, true),
-                                          reinterpret_cast<uint8_t*>(out8), d, reinterpret_cast<uint8_t*>(bs), bs_ld);
+                                          reinterpret_cast<uint8_t*>(out8), d, reinterpret_cast<uint8_t*>(bs), bs_ld, ctx->n_cu, ctx->attn_ws.as<float>());
     F2_LAUNCH(r, "op_attention_qk8");
     return FLUX2MI_OK;
 }

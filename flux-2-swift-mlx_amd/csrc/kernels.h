@@ -130,9 +130,11 @@ size_t gemm_splitk_ws_bytes(int M, int N, int K);
 // needs no multiply-add at all (p in [2^-80, 2^80]: inside f32 / bf16 range with room for the sums, any offset cancels in O / l).
 // true when launch_attention takes the fixed-offset softmax for this score bound (log2 domain; 0 = no bound known)
 bool attention_uses_fixed_offset(float score_bound_log2, bool q_prescaled = true);
-// split_ws (optional, attention_split_ws_bytes(n_cu) bytes, n_cu = the device's CU count): lets the launcher cut the items of
-// a partial last round along the keys into equal pieces, one per free workgroup slot (attention.hip, AttnSplit).
-size_t attention_split_ws_bytes(int n_cu);
+// split_ws (optional, attention64b_split_ws_bytes(n_cu) bytes, n_cu = the device's CU count): lets the one-wave-per-SIMD kernel cut the
+// items of a partial last round along the keys into f equal pieces each (attention64b.hip, AttnSplit: fixed-offset softmax, heads % 8
+// == 0, a tail of at most half the CUs — Klein-9B's 576 items and Dev's 864 on 256 CUs, not Klein-4B's 432); nullptr = never.
+size_t attention64b_split_ws_bytes(int n_cu);
+int attention64b_split_factor(int Sq, int S, int heads, int n_cu);   // pieces per tail item (1 = whole items)
 int launch_attention(hipStream_t stream, const uint16_t* q, const uint16_t* k, int ldqk, const uint16_t* vt,
                      int s_pad, uint16_t* out, int ldo, int Sq, int S, int heads, float score_bound_log2 = 0.f, bool q_prescaled = false,
                      float* split_ws = nullptr, int n_cu = 0);
@@ -145,7 +147,7 @@ static inline int attn_s_pad(int S) { return ((S + 63) / 64) * 64; }
 // out8[row * ld8o + head * 128 + d], scale bytes bs[head * bs_ld + row / 16] (16 queries x one head's 128 columns per block); `out` unused.
 int launch_attention64b_qk8(hipStream_t stream, const uint8_t* q8, const uint8_t* k8, int ld8, int q_exp, int k_exp, const uint16_t* vt, int s_pad,
                             uint16_t* out, int ldo, int Sq, int S, int heads, bool data_offset, uint8_t* out8 = nullptr, int ld8o = 0,
-                            uint8_t* bs = nullptr, int bs_ld = 0);
+                            uint8_t* bs = nullptr, int bs_ld = 0, int n_cu = 0, float* split_ws = nullptr);
 
 // ---------------------------------------------------------------- norms / rope (norm.hip)
 // y bf16[row,:] = LN(x f32[row,:]) * (1 + scale) + shift ; rows < split use (shift0, scale0),

@@ -537,6 +537,10 @@ int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv, void* out, int S, in
    fixed zero offset when 0 < bound <= 80 (Flux2Attention.swift:168-174 after the QK RMSNorm bounds the scores); bound <= 0
    (unknown) or > 80: a per-query offset taken from the data, exact for any scores (attention64b.hip, DOFF) */
 int flux2mi_op_attention_prescaled(flux2mi_ctx* ctx, const void* qkv, void* out, int S, int heads, float score_bound_log2);
+/* The launch plan of that attention on this GPU (Flux2Attention.swift:168-174 has no counterpart: MLX's SDPA is one call): *pieces = into
+ * how many equal key ranges the (head, 256-query block) items of the partial last round are cut (1 = whole items only; fixed-offset
+ * softmax, partial sums added in a fixed order), *n_cu = compute units.  Either pointer may be NULL. */
+int flux2mi_op_attention_split_info(flux2mi_ctx* ctx, int S, int heads, int* pieces, int* n_cu);
 /* the fp8 models' form (weight_format 1, plain forwards; q_exp, k_exp in [-60, 60], negative = operands scaled down into e4m3's range):
    Q K^T on e4m3 copies q8 = q 2^q_exp, k8 = k 2^k_exp (device bytes
    [S, heads*128] each, q pre-scaled as above; the powers of two are undone by the scale operands of the block-scaled MFMA), V bf16

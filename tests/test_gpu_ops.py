@@ -760,3 +760,60 @@ def test_attention_e4m3_qk_negative_exponent(ctx):
     ref = R.sdpa(hv(q8.float() / 2.0 ** qe / c), hv(k8.float() / 2.0 ** ke), hv(v.float())).permute(0, 2, 1, 3).reshape(S, d)
     assert torch.isfinite(out).all()
     assert rel_l2(out, ref) < 1e-2, rel_l2(out, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,heads,qk8,blocks", [(4608, 32, False, False), (4608, 48, False, False), (4600, 32, False, False), (8500, 8, False, False),
+                                                (4608, 32, True, False), (4600, 32, True, True), (4608, 24, False, False), (4608, 24, True, False)])
+def test_attention_kv_split_of_the_partial_round(ctx, S, heads, qk8, blocks):
+    """attention64b.hip, AttnSplit: when the (head, 256-query block) items leave a partial last round of at most half the CUs — Klein-9B's
+    32 heads x 18 = 576 items on 256 CUs (2.25 rounds paid as 3), Dev's 864 — every item of that round is cut into f equal key ranges, the
+    pieces leave raw O / row sums and a combine kernel adds them in part order and stores through the attention's own epilogue (bf16, or the
+    block-scaled e4m3 of the fp8 models).  With the fixed zero softmax offset the partial sums of disjoint key ranges just add: the result
+    against the oracle like every other attention (<= 1e-2), against the oracle with the kernel's own bf16 P (device_roundings) to 2e-4
+    (measured 1.1e-4, split or not; the e4m3 Q K^T form 8.7e-4, split or not: the block-scaled MFMA sums its 128 products to ~1e-4
+    relative, not to an f32 ulp, which moves p = 2^s by that much at |s| ~ 10), bit-reproducible; ragged last tile inside the last piece (S 4600), f = 8 (S 8500 x 8 heads), and Klein-4B's 432 items (tail 176 > half
+    the CUs: NOT split, same checks).  flux2mi_op_attention_split_info reports the plan."""
+    import math
+    f, n_cu = ctx.op_attention_split_info(S, heads)
+    items = ((S + 255) // 256) * heads
+    if n_cu == 256:
+        assert f == {(4608, 32): 4, (4608, 48): 2, (4600, 32): 4, (8500, 8): 8, (4608, 24): 1}[(S, heads)], (f, items)
+    g = torch.Generator().manual_seed(S * 7 + heads)
+    d = heads * 128
+    c = math.log2(math.e) / math.sqrt(128.0)
+    x = torch.randn((S, 3 * d), generator=g)
+    q = x[:, :d].view(S, heads, 128); k = x[:, d:2 * d].view(S, heads, 128)
+    q = q / q.pow(2).mean(-1, keepdim=True).sqrt(); k = k / k.pow(2).mean(-1, keepdim=True).sqrt()
+    v = (x[:, 2 * d:] * (1.0 + torch.arange(S).float().unsqueeze(1) / S)).to(torch.bfloat16)     # values that depend on the key index: a mis-placed piece shows
+    hv = lambda t: t.reshape(1, S, heads, 128).permute(0, 2, 1, 3)
+    bound = 1.5 * 128.0 * c
+    if qk8:
+        q8 = ((q * c).reshape(S, d) * 2.0 ** 7).clamp(-448, 448).to(torch.float8_e4m3fn)
+        k8 = (k.reshape(S, d) * 2.0 ** 4).clamp(-448, 448).to(torch.float8_e4m3fn)
+        qd, kd = hv(q8.float() / 2.0 ** 7 / c), hv(k8.float() / 2.0 ** 4)
+        run = lambda: ctx.op_attention_qk8(q8.cuda(), k8.cuda(), v.cuda(), heads, 7, 4, bound).float().cpu()
+    else:
+        qkv = torch.cat([(q * c).reshape(S, d), k.reshape(S, d), v.float()], dim=1).to(torch.bfloat16)
+        qs, ks, _ = qkv.float().split(d, dim=1)
+        qd, kd = hv(qs / c), hv(ks)
+        run = lambda: ctx.op_attention_prescaled(qkv.cuda(), heads, bound).float().cpu()
+    out = run()
+    with R.device_roundings():
+        ref16 = R.sdpa(qd, kd, hv(v.float())).permute(0, 2, 1, 3).reshape(S, d)
+    ref32 = torch.empty_like(ref16)
+    for h in range(heads):       # per head: the S x S f32 intermediates of 32 ... 48 heads at once do not fit comfortably
+        ref32[:, h * 128:(h + 1) * 128] = R.sdpa(qd[:, h:h + 1], kd[:, h:h + 1], hv(v.float())[:, h:h + 1])[0, 0]
+    assert torch.isfinite(out).all()
+    e32, e16 = rel_l2(out, ref32), rel_l2(out, ref16.to(torch.bfloat16).float())
+    print(f"attention S {S} x {heads} heads ({items} items on {n_cu} CUs, {f} pieces per tail item{', e4m3 QK' if qk8 else ''}): vs f32 oracle {e32:.2e}, vs bf16-P oracle {e16:.2e}")
+    assert e32 < 1e-2, e32
+    assert e16 < (2e-3 if qk8 else 2e-4), e16
+    assert torch.equal(out, run())
+    if blocks:
+        out8, bs = ctx.op_attention_qk8_blocks(q8.cuda(), k8.cuda(), v.cuda(), heads, 7, 4, bound)
+        scale = torch.exp2(bs.cpu().float() - 127.0)
+        deq = out8.cpu().view(torch.float8_e4m3fn).float().view(S, heads, 128) * scale.t().repeat_interleave(16, 0)[:S].unsqueeze(-1)
+        assert rel_l2(deq.reshape(S, d), out) < 3e-2
+        o2, b2 = ctx.op_attention_qk8_blocks(q8.cuda(), k8.cuda(), v.cuda(), heads, 7, 4, bound)
+        assert torch.equal(o2.cpu(), out8.cpu()) and torch.equal(b2.cpu(), bs.cpu())
