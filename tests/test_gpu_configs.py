@@ -21,7 +21,7 @@ import pytest
 import torch
 
 from oracle import flux2_ref as R
-from tests.util import oracle_cached, rel_l2
+from tests.util import oracle_cached, rel_l2, tapped_stream
 
 pytestmark = pytest.mark.gpu
 
@@ -265,6 +265,33 @@ def test_config_b_klein4b_full_depth_forward_1024(klein4b_pipe):
     print(f"config B forward: rel-L2 {e:.3e} (oracle {'from the committed fixture' if cached else 'run live'})")
     assert torch.isfinite(out).all()
     assert e < 3e-2
+
+
+def test_klein4b_bf16_teacher_forced_blocks_vs_store_point_oracle(klein4b_pipe):
+    """The headline model block by block (Klein-4B, 5 + 20 blocks, S 768): each block is fed the input the oracle's store-point emulation
+    (`device_roundings`: bf16 where the HIP path stores bf16) gave it, through flux2mi_dit_forward_block, and must reproduce the
+    emulation's increment (output - input) to 2e-3 (double blocks: six bf16 store points in sequence) / 5e-4 (single blocks: three) and its
+    output to 3e-4.  Free-running forwards cannot be held to that: roundings cascade."""
+    from flux2mi import synthetic as syn
+    k = klein4b_pipe
+    cfg, P = k["cfg"], k["P"]
+    inp = syn.make_inputs(cfg, 256, 256, s_txt=512)
+    lat = R.pack_patchified_to_sequence(inp["noise"])
+    ii, ti = R.image_position_ids(256, 256), R.text_position_ids(512)
+    taps = {}
+    with torch.no_grad(), R.device_roundings():
+        R.dit_forward(_cpu(P), cfg, lat, inp["txt"].float(), torch.tensor([0.6]), None, ii, ti, taps=taps)
+    nd, ns = cfg["n_double"], cfg["n_single"]
+    dit = k["pipe"].transformer
+    rows = []
+    for layer in range(nd + ns):
+        x_in, y_ref = tapped_stream(taps, layer - 1, nd), tapped_stream(taps, layer, nd)
+        y = dit.forward_block(layer, x_in.cuda(), inp["txt"].cuda(), 0.6, 0.0, ii.cuda(), ti.cuda()).cpu()
+        rows.append((layer, rel_l2(y, y_ref), rel_l2(y - x_in, y_ref - x_in)))
+    print("Klein-4B bf16 teacher-forced blocks (layer: output / increment): " + ", ".join(f"{l}: {a:.1e} / {b:.1e}" for l, a, b in rows))
+    assert max(r[1] for r in rows) < 3e-4, rows
+    assert max(r[2] for r in rows) < 2e-3, rows
+    assert max(r[2] for r in rows[nd:]) < 5e-4, rows[nd:]
 
 
 def test_config_b_28_steps_properties(klein4b_pipe):

@@ -21,7 +21,7 @@ import pytest
 import torch
 
 from oracle import flux2_ref as R
-from tests.util import oracle_cached, rel_l2
+from tests.util import oracle_cached, rel_l2, tapped_stream
 
 pytestmark = pytest.mark.gpu
 
@@ -197,15 +197,6 @@ def _oracle_block(P, cfg, layer, x, taps, s_txt):
     return R.single_block(P, layer - nd, x.unsqueeze(0), H, cos, sin, smod)[0]
 
 
-def _stream(t, layer, nd):
-    """residual stream [S, d] (text rows first) BEHIND block `layer` of a tapped oracle forward (-1: behind the embedders)"""
-    if layer < 0:
-        return torch.cat([t["txt_in"][0], t["img_in"][0]], 0)
-    if layer < nd:
-        return torch.cat([t[f"double{layer}.txt"][0], t[f"double{layer}.img"][0]], 0)
-    return t[f"single{layer - nd}"][0]
-
-
 def test_klein9b_full_depth_forward_bf16_and_fp8_vs_oracles(klein9b_fp8, flux2mi, ctx):
     """Klein-9B at full depth (8 + 24 blocks), one forward at 256 x 256.  bf16 weights against the fp32 oracle (3e-2, like the other
     full-depth forwards): the clean check of the 32-block structure.  e4m3 block GEMMs against the oracle running the same e4m3
@@ -253,7 +244,7 @@ def test_klein9b_full_depth_forward_bf16_and_fp8_vs_oracles(klein9b_fp8, flux2mi
     dit8 = k["pipe"].transformer
     rows = []
     for layer in range(nd + ns):
-        x_in, y_ref = _stream(taps8, layer - 1, nd), _stream(taps8, layer, nd)
+        x_in, y_ref = tapped_stream(taps8, layer - 1, nd), tapped_stream(taps8, layer, nd)
         y = dit8.forward_block(layer, x_in.cuda(), inp["txt"].cuda(), 0.6, 0.0, ii.cuda(), ti.cuda()).cpu()
         with torch.no_grad():
             y32 = _oracle_block(Pc, cfg, layer, x_in, taps8, 512)                     # the un-quantised block on the same input
@@ -287,7 +278,7 @@ def test_klein9b_bf16_teacher_forced_blocks_vs_store_point_oracle(klein9b_fp8, f
     nd, ns = cfg["n_double"], cfg["n_single"]
     rows = []
     for layer in range(nd + ns):
-        x_in, y_ref = _stream(taps, layer - 1, nd), _stream(taps, layer, nd)
+        x_in, y_ref = tapped_stream(taps, layer - 1, nd), tapped_stream(taps, layer, nd)
         y = dit16.forward_block(layer, x_in.cuda(), inp["txt"].cuda(), 0.6, 0.0, ii.cuda(), ti.cuda()).cpu()
         rows.append((layer, rel_l2(y, y_ref), rel_l2(y - x_in, y_ref - x_in)))
     dit16.close()

@@ -36,3 +36,13 @@ def oracle_cached(name: str, fingerprint_tensors, compute):
         os.makedirs(wdir, exist_ok=True)
         np.savez_compressed(os.path.join(wdir, f"oracle_cache_{name}.npz"), fingerprint=np.int64(crc), **{k: v.detach().cpu().numpy() for k, v in out.items()})
     return out, False
+
+
+def tapped_stream(taps: dict, layer: int, n_double: int) -> torch.Tensor:
+    """Residual stream [S, d] (text rows first) BEHIND block `layer` of an oracle forward run with `taps=` (-1: behind the embedders);
+    layers count the double blocks first, then the single blocks (the order of flux2mi_dit_forward_block)."""
+    if layer < 0:
+        return torch.cat([taps["txt_in"][0], taps["img_in"][0]], 0)
+    if layer < n_double:
+        return torch.cat([taps[f"double{layer}.txt"][0], taps[f"double{layer}.img"][0]], 0)
+    return taps[f"single{layer - n_double}"][0]

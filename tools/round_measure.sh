@@ -10,7 +10,10 @@ python bench.py --steps 3 --warmup 1 --no-cpu-baseline --weights fp8 > $O/bench_
 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --attn-softmax online > $O/bench_online_softmax.json.log 2>>$O/bench.err || exit 1
 python tools/run_configs.py A D D8 C E K T > $O/configs.jsonl 2>>$O/bench.err || exit 1
 tail -8 $O/configs.jsonl | cut -c1-200
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-mfma-stream > $O/prof.log 2>&1 || exit 1
+# the BASELINE.json configurations D and E through bench.py's own contract (one GPU here; `--gpus 8 --config D` / `--gpus 4 --config E` on a node)
+python bench.py --config D --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_config_d.json.log 2>>$O/bench.err || exit 1
+python bench.py --config E --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_config_e.json.log 2>>$O/bench.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-mfma-stream --no-secondary > $O/prof.log 2>&1 || exit 1
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv
 python3 tools/linear1_from_trace.py $O/prof $O/linear1_rocprof.json
 grep '^{"metric' $O/prof.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('bench roofline.avg_launch_ms (HIP events) of the same run:', d['roofline']['avg_launch_ms'], 'over', d['roofline']['launches'], 'launches')" | tee $O/linear1_bench_events.txt
