@@ -98,6 +98,9 @@ struct flux2mi_ctx {
     int n_cu = 0;    // compute units of the device (workgroup slots for the attention's KV-split)
     DevBuf attn_ws;  // partial states of KV-split attention items (attention_split_ws_bytes)
     flux2mi_dp* dp = nullptr;   // flux2mi_dp_init
+    // flux2mi_generate's own buffers (packed latents, prediction(s), position ids, VAE input, image bytes): grow-only workspaces of the
+    // context like every other — no hipMalloc / hipFree (a device-wide synchronisation) per image
+    struct GenScratch { DevBuf packed, lat_in, v, v2, ids_txt, ids_neg, ids_img, z, img_u8; } gen;
 };
 
 // profiling helpers: bracket a launch of class `cls` with events when active.

@@ -18,14 +18,6 @@
 
 namespace {
 
-struct GenScratch {
-    DevBuf packed, lat_in, v, v2, ids_txt, ids_neg, ids_img, z, img_u8;
-    ~GenScratch() {
-        DevBuf* b[] = {&packed, &lat_in, &v, &v2, &ids_txt, &ids_neg, &ids_img, &z, &img_u8};
-        for (DevBuf* x : b) x->release();
-    }
-};
-
 // events + KV cache of one generation: released on every exit path
 struct GenGuard {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
@@ -90,7 +82,7 @@ extern "C" int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae*
     const int n_steps = n_sig - 1;
     p->effective_steps = n_steps;
 
-    GenScratch g;
+    flux2mi_ctx::GenScratch& g = ctx->gen;
     F2_TRY(g.packed.reserve((size_t)n_lat * 4));
     F2_TRY(g.v.reserve((size_t)n_lat * 4));
     if (use_cfg) F2_TRY(g.v2.reserve((size_t)n_lat * 4));
