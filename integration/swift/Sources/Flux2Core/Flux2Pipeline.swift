@@ -583,6 +583,10 @@ public final class Flux2Pipeline: @unchecked Sendable {
         } else {
             try run()
         }
+        // the two device phases under the reference's names (Flux2Pipeline.swift:1933-2052 "5. Denoising Loop", :2058-2098 "6. VAE Decoding"):
+        // HIP-event milliseconds of the generating stream, reported by the library
+        Flux2Profiler.shared.record("5. Denoising Loop", seconds: Double(p.ms_denoise) / 1000)
+        Flux2Profiler.shared.record("6. VAE Decoding", seconds: Double(p.ms_decode) / 1000)
         guard let cg = image.withUnsafeBufferPointer({ makeCGImage(rgb: $0.baseAddress!, width: Int(vw), height: Int(vh)) }) else {
             throw Flux2Error.imageProcessingFailed("Failed to create CGImage")            // postprocessVAEOutput, :2450-2467
         }

@@ -14,6 +14,11 @@ import CFlux2MI
 import Foundation
 import MLX
 
+/// Flux2Core.swift:9-11 (`Flux2CLI.swift:25, 851` print it)
+public enum Flux2Core {
+    public static let version = "2.4.0"
+}
+
 public enum Flux2Error: Error, LocalizedError {
     case modelNotLoaded(String)
     case invalidConfiguration(String)
@@ -102,6 +107,18 @@ public struct LoRAConfig: Sendable, Codable {
     public var schedulerOverrides: SchedulerOverrides?
     public var name: String { URL(fileURLWithPath: filePath).deletingPathExtension().lastPathComponent }
     public var effectiveScale: Float { scale ?? 1.0 }
+    public init(filePath: String, scale: Float? = 1.0, activationKeyword: String? = nil, schedulerOverrides: SchedulerOverrides? = nil) {
+        self.filePath = filePath; self.scale = scale; self.activationKeyword = activationKeyword; self.schedulerOverrides = schedulerOverrides
+    }
+    /// JSON sidecar of a LoRA (`Flux2CLI.swift:169, 500`): the Codable form of this struct
+    public static func load(from path: String) throws -> LoRAConfig {
+        try JSONDecoder().decode(LoRAConfig.self, from: Data(contentsOf: URL(fileURLWithPath: path)))
+    }
+    public func save(to path: String) throws {
+        let enc = JSONEncoder()
+        enc.outputFormatting = [.prettyPrinted, .sortedKeys]
+        try enc.encode(self).write(to: URL(fileURLWithPath: path))
+    }
 }
 public struct LoRAInfo: Sendable {
     public let numLayers: Int

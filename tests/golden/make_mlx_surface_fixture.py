@@ -56,13 +56,45 @@ def files():
     return out
 
 
+def flux2core_types_used():
+    """Public types declared in the Flux2Core files that import an MLX module (the files the shim replaces: the MLX-free ones stay in the
+    reference's tree), as far as the in-scope callers name them: {type: {"declared_in", "kind", "members": [statically accessed
+    `Type.member` / `Type.shared.member` / `.case` names], "used_in": [files]}}.  Interface data: names only."""
+    from tests.swift_mlx_usage import strip
+    decl = {}
+    for f in sorted(glob.glob(os.path.join(REF, "Flux2Core", "**", "*.swift"), recursive=True)):
+        src = strip(open(f).read())
+        if not re.search(r"^\s*(?:@\w+\s+)*import\s+MLX", src, re.M):
+            continue
+        for m in re.finditer(r"public\s+(?:final\s+)?(class|struct|enum|protocol|typealias|actor)\s+(\w+)", src):
+            decl.setdefault(m.group(2), (os.path.relpath(f, REF), m.group(1)))
+    out = {}
+    for f in files():
+        src = strip(open(f).read())
+        src = re.sub(r"^\s*(?:@\w+\s+)*import\s+\w+.*$", "", src, flags=re.M)
+        for t, (where, kind) in decl.items():
+            if not re.search(r"\b" + t + r"\b", src):
+                continue
+            e = out.setdefault(t, {"declared_in": where, "kind": kind, "members": set(), "used_in": set()})
+            e["used_in"].add(os.path.relpath(f, REF))
+            for m in re.finditer(r"\b" + t + r"\.(\w+)(?:\.(\w+))?", src):
+                e["members"].add(m.group(1))
+                if m.group(1) == "shared" and m.group(2):
+                    e["members"].add(m.group(2))
+            if t == "Flux2Profiler":      # `let profiler = Flux2Profiler.shared` ... `profiler.start(..)`
+                for m in re.finditer(r"\bprofiler\.(\w+)", src):
+                    e["members"].add(m.group(1))
+    return {t: {"declared_in": e["declared_in"], "kind": e["kind"], "members": sorted(e["members"]), "used_in": sorted(e["used_in"])}
+            for t, e in sorted(out.items())}
+
+
 def build():
     rets, aliases, members = typing_context()
     uses = []
     for f in files():
         uses += used_surface(os.path.relpath(f, REF), open(f).read(), rets, aliases, members)
     return {"files": [os.path.relpath(f, REF) for f in files()], "excluded_cli_files": EXCLUDED,
-            "uses": uses, "summary": [list(t) for t in summarize(uses)]}
+            "uses": uses, "summary": [list(t) for t in summarize(uses)], "flux2core_types": flux2core_types_used()}
 
 
 if __name__ == "__main__":

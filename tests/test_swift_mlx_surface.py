@@ -149,3 +149,49 @@ def test_the_memory_facade_is_backed_by_the_c_abi():
 def test_mlxrandom_module_reexports_mlx():
     assert re.search(r"@_exported\s+import\s+MLX\b", _module_src("MLXRandom"))
     assert re.search(r"public\s+enum\s+MLXRandom\b", _module_src("MLX"))
+
+
+def _flux2core_shim_src():
+    return _module_src("Flux2Core")
+
+
+@pytest.mark.parametrize("type_name", sorted(json.load(open(FIXTURE))["flux2core_types"]))
+def test_flux2core_types_the_callers_name_are_declared(type_name):
+    """Every public type of the Flux2Core files the shim REPLACES (the ones that import an MLX module; the MLX-free files stay in the
+    reference's tree) that the chains or the t2i / i2i / inpaint / outpaint commands name must exist in the shim's `Flux2Core` module, with
+    the statically accessed members (`Flux2Core.version`, `Flux2Profiler.shared.enable()`, `LoRAConfig.load(from:)`, enum cases, ...) —
+    except members the callers add themselves in extensions (`TransformerQuantization.parseCLI`: Flux2CLI/QuantizationParsing.swift)."""
+    fx = _fixture()["flux2core_types"][type_name]
+    src = _flux2core_shim_src()
+    assert re.search(r"public\s+(?:final\s+)?(?:class|struct|enum|protocol|typealias|actor)\s+" + type_name + r"\b", src), f"{type_name} ({fx['declared_in']}) is not declared"
+    caller_side = set()
+    if os.path.isdir("/root/reference/Sources"):
+        for f in _fixture()["files"]:
+            text = strip(open(os.path.join("/root/reference/Sources", f)).read())
+            for m in re.finditer(r"extension\s+" + type_name + r"\b[^{]*\{", text):
+                depth, i = 1, m.end()
+                while depth:
+                    depth += {"{": 1, "}": -1}.get(text[i], 0)
+                    i += 1
+                caller_side |= set(re.findall(r"func\s+(\w+)", text[m.end():i]))
+    else:
+        caller_side = {"parseCLI"}
+    m = re.search(r"public\s+(?:final\s+)?(?:class|struct|enum)\s+" + type_name + r"\b[^{]*\{", src)
+    body = ""
+    if m:
+        depth, i = 1, m.end()
+        while depth:
+            depth += {"{": 1, "}": -1}.get(src[i], 0)
+            i += 1
+        body = src[m.end():i]
+        for mm in re.finditer(r"extension\s+" + type_name + r"\b[^{]*\{", src):
+            depth, i = 1, mm.end()
+            while depth:
+                depth += {"{": 1, "}": -1}.get(src[i], 0)
+                i += 1
+            body += src[mm.end():i]
+    for member in fx["members"]:
+        if member in caller_side:
+            continue
+        assert re.search(r"(?:public\s+(?:static\s+)?(?:func|var|let)\s+|case\s+(?:\w+\s*(?:\([^)]*\))?\s*,\s*)*)" + member + r"\b", body), \
+            f"{type_name}.{member} (used in {fx['used_in']}) has no public declaration in the shim"
