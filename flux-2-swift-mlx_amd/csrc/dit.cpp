@@ -1626,9 +1626,11 @@ extern "C" int flux2mi_op_attention_qk8_blocks(flux2mi_ctx* ctx, const void* q8,
     // a V matrix of its own ([S, d], first V column 0), not the fused [q | k | v] row
     F2_LAUNCH(launch_v_transpose_only(ctx->stream, reinterpret_cast<const uint16_t*>(v), d, S, heads, vt, s_pad, /*v_col0=*/0), "v_transpose");
     if (ctx->n_cu > 0) F2_TRY(ctx->attn_ws.reserve(attention64b_split_ws_bytes(ctx->n_cu)));
+    prof_before(ctx, PROF_ATTENTION);
     const int r = launch_attention64b_qk8(ctx->stream, reinterpret_cast<const uint8_t*>(q8), reinterpret_cast<const uint8_t*>(k8), d, q_exp, k_exp, vt, s_pad,
                                           reinterpret_cast<uint16_t*>(out), d, S, S, heads, !attention_uses_fixed_offset(score_bound_log2, true),
                                           reinterpret_cast<uint8_t*>(out8), d, reinterpret_cast<uint8_t*>(bs), bs_ld, ctx->n_cu, ctx->attn_ws.as<float>());
+    prof_after(ctx, PROF_ATTENTION, 4.0 * (double)S * S * d);
     F2_LAUNCH(r, "op_attention_qk8");
     return FLUX2MI_OK;
 }
