@@ -600,56 +600,61 @@ __global__ __launch_bounds__(256, 1) void attn64b_kernel(const uint16_t* __restr
     }
 }
 
-// One workgroup per split item, thread mapping = the attention's (lane (c16, g4) of wave wid): adds the item's f pieces in part order,
-// then the attention kernel's own epilogue (bf16, or the block-scaled e4m3 of the fp8 models).
+// One 256-thread workgroup per (split item, wave of the attention's workgroup); its four waves take two of the eight d blocks each, so a
+// lane adds 8 accumulator quads + the row sums over the item's f pieces (in part order: bit-reproducible) — sixteen times the waves of one
+// workgroup per item, which read 64 items' 35 MB of partials from a quarter of the chip, one dependent accumulation chain per lane
+// (20 us per launch measured, 1.9 % of a Klein-9B fp8 step).  Lane (c16, g4) = the attention's; then the attention kernel's own epilogue:
+// bf16, or the block-scaled e4m3 of the fp8 models (a block = 16 queries x the head's 128 columns: maximum over the four waves through LDS).
 template <bool QK8>
 __global__ __launch_bounds__(256) void attn64b_combine_kernel(uint16_t* __restrict__ out, int ldo, int Sq, AttnBlocksOut bo, AttnSplit sp) {
-    __shared__ unsigned bo_max[4][4];
-    const int t = threadIdx.x, lane = t & 63, wid = t >> 6, c16 = lane & 15, g4 = lane >> 4;
-    const int it = blockIdx.x, item = sp.n_whole + it;
+    __shared__ unsigned bo_max[4];        // per query block of this (item, wave)
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6, c16 = lane & 15, g4 = lane >> 4;
+    const int wid = blockIdx.x & 3, t = wid * 64 + lane;       // wave / thread of the attention's workgroup whose accumulators these are
+    const int it = blockIdx.x >> 2, item = sp.n_whole + it;
     const int xcd = item & 7, kk = item >> 3;
     const int head = (kk / sp.qblocks) * 8 + xcd, qblk = kk % sp.qblocks;
     const int q0 = qblk * 256 + wid * 64;
-    f32x4 o[8][4], l4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 o[2][4], l4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int db = 0; db < 8; ++db)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int qb = 0; qb < 4; ++qb) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qb = 0; qb < 4; ++qb) o[j][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int part = 0; part < sp.f; ++part) {
         const f32x4* w4 = reinterpret_cast<const f32x4*>(sp.ws + (size_t)(it * sp.f + part) * SPLIT_PIECE_FLOATS) + t;
 #pragma unroll
-        for (int db = 0; db < 8; ++db)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int qb = 0; qb < 4; ++qb) o[db][qb] += w4[(db * 4 + qb) * 256];
+            for (int qb = 0; qb < 4; ++qb) o[j][qb] += w4[((2 * sub + j) * 4 + qb) * 256];
         l4 += w4[32 * 256];
     }
     if (QK8 && bo.q8 != nullptr) {
-        if (lane < 4) bo_max[wid][lane] = 0u;
+        if (threadIdx.x < 4) bo_max[threadIdx.x] = 0u;
+        __syncthreads();
         float inv4[4];
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
             inv4[qb] = 1.0f / l4[qb];
             float mx = 0.f;
 #pragma unroll
-            for (int db = 0; db < 8; ++db)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(o[db][qb][r] * inv4[qb]));
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(o[j][qb][r] * inv4[qb]));
             mx = row16_max_nonneg(mx);
-            if ((lane & 15) == 15) atomicMax(&bo_max[wid][qb], __float_as_uint(mx));
+            if ((lane & 15) == 15) atomicMax(&bo_max[qb], __float_as_uint(mx));
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
-            const int e = fp8_block_exp(__uint_as_float(bo_max[wid][qb]));
+            const int e = fp8_block_exp(__uint_as_float(bo_max[qb]));
             const float mult = ldexpf(1.0f, e) * inv4[qb];
             const int qrow = q0 + qb * 16 + c16;
-            if (lane == 0 && q0 + qb * 16 < Sq) bo.bs[(size_t)head * bo.bs_ld + ((q0 + qb * 16) >> 4)] = (uint8_t)(127 - e);
+            if (threadIdx.x == 0 && q0 + qb * 16 < Sq) bo.bs[(size_t)head * bo.bs_ld + ((q0 + qb * 16) >> 4)] = (uint8_t)(127 - e);
             if (qrow < Sq) {
                 uint8_t* op = bo.q8 + (size_t)qrow * bo.ld + head * HD + g4 * 4;
 #pragma unroll
-                for (int db = 0; db < 8; ++db)
-                    *reinterpret_cast<uint32_t*>(op + db * 16) =
-                        pack_fp8x4_inrange(o[db][qb][0] * mult, o[db][qb][1] * mult, o[db][qb][2] * mult, o[db][qb][3] * mult);
+                for (int j = 0; j < 2; ++j)
+                    *reinterpret_cast<uint32_t*>(op + (2 * sub + j) * 16) =
+                        pack_fp8x4_inrange(o[j][qb][0] * mult, o[j][qb][1] * mult, o[j][qb][2] * mult, o[j][qb][3] * mult);
             }
         }
         return;
@@ -661,11 +666,11 @@ __global__ __launch_bounds__(256) void attn64b_combine_kernel(uint16_t* __restri
         if (qrow < Sq) {
             uint16_t* op = out + (size_t)qrow * ldo + head * HD + g4 * 4;
 #pragma unroll
-            for (int db = 0; db < 8; ++db) {
+            for (int j = 0; j < 2; ++j) {
                 uint2 v;
-                v.x = pack_bf16x2(o[db][qb][0] * inv, o[db][qb][1] * inv);
-                v.y = pack_bf16x2(o[db][qb][2] * inv, o[db][qb][3] * inv);
-                *reinterpret_cast<uint2*>(op + db * 16) = v;
+                v.x = pack_bf16x2(o[j][qb][0] * inv, o[j][qb][1] * inv);
+                v.y = pack_bf16x2(o[j][qb][2] * inv, o[j][qb][3] * inv);
+                *reinterpret_cast<uint2*>(op + (2 * sub + j) * 16) = v;
             }
         }
     }
@@ -732,7 +737,7 @@ int A64B_VARIANT(hipStream_t stream, const void* q, const void* k, int ldqk, con
                        reinterpret_cast<const uint16_t*>(k), ldqk, vt, s_pad, out, ldo, Sq, S, trace, qk8_exps, bo, sp);
     if (sp.f > 1) {
         const int tail = ((int)grid.x - sp.n_whole) / sp.f;
-        hipLaunchKernelGGL((attn64b_combine_kernel<(ATTN64B_QK8 != 0)>), dim3(tail), block, 0, stream, out, ldo, Sq, bo, sp);
+        hipLaunchKernelGGL((attn64b_combine_kernel<(ATTN64B_QK8 != 0)>), dim3(tail * 4), dim3(256), 0, stream, out, ldo, Sq, bo, sp);
     }
     if (trace) {
         std::vector<unsigned long long> h(tn);
