@@ -79,7 +79,7 @@ else:
     def tick(c, x):
         print(f"oracle step at {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
         return x
-    with torch.no_grad(), (R.fp8_block_gemms() if fp8 else contextlib.nullcontext()):
+    with torch.no_grad(), (R.fp8_block_gemms(device_roundings=True) if fp8 else contextlib.nullcontext()):   # the emulation with the HIP path's bf16 store points
         ref = R.generate(P, cfg, VP, vcfg, inp["txt"].float(), inp["noise"], H, W, steps, on_step=tick)
     ref32 = None
     if fp8:   # the unquantised oracle as well: how large the quantisation effect itself is on this trajectory
