@@ -350,7 +350,12 @@ def main():
     # the two VAE classes.  MFMA-bound classes against the dense peak, HBM-bound classes (work = algorithmic bytes) against 8 TB/s.
     roofline_secondary = roofline_hbm = None
     if not dry and not args.no_secondary:
-        roofline_secondary, roofline_hbm = secondary_rooflines(pipe, torch, dev, H, W, peak, stream_tf, lambda n: pipe.generate_with_result(
+        sec_traffic = None
+        spath = os.path.join(ROOT, "profiles", "secondary_traffic.json")     # committed PMC passes (tools/secondary_traffic.py), Klein-4B 1024^2 bf16 only
+        if args.model == "klein-4b" and (H, W) == (1024, 1024) and args.weights == "bf16" and not args.reference and os.path.exists(spath):
+            with open(spath) as f:
+                sec_traffic = {int(k): v["traffic_bytes_per_launch"] for k, v in json.load(f)["kernels"].items()}
+        roofline_secondary, roofline_hbm = secondary_rooflines(pipe, torch, dev, H, W, peak, stream_tf, sec_traffic, lambda n: pipe.generate_with_result(
             "imageToImage" if ref_lat is not None else "textToImage", height=H, width=W, steps=n, guidance=guidance,
             precomputed_embeddings=emb_all[0], noise=noise, skip_decode=True, reference_latents=ref_lat, reference_ids=ref_ids))
 
@@ -423,7 +428,7 @@ def main():
     par.finalize()
 
 
-def secondary_rooflines(pipe, torch, dev, H, W, peak, stream_tf, short_generation, steps=4):
+def secondary_rooflines(pipe, torch, dev, H, W, peak, stream_tf, traffic, short_generation, steps=4):
     """[MFMA-bound entries], [HBM-bound entries]: achieved = work of the class's launches / their summed HIP-event time."""
     ctx = pipe.ctx
     where = f"one extra {steps}-step generation after the timed region (same model and inputs; HIP events around every launch of the class)"
@@ -432,7 +437,7 @@ def secondary_rooflines(pipe, torch, dev, H, W, peak, stream_tf, short_generatio
         ach = work / max(ms * 1e-3, 1e-12) / (1e12 if unit == "TFLOP/s" else 1e9)
         e = {"kernel": ctx.prof_kernel_name(cls), "bound": "mfma" if unit == "TFLOP/s" else "hbm", "achieved": round(ach, 2), "peak": pk,
              "unit": unit, "frac": round(ach / pk, 4), "launches": n, "avg_launch_ms": round(ms / max(n, 1), 4),
-             "work_per_launch": work / max(n, 1), "measured": where}
+             "work_per_launch": work / max(n, 1), "traffic": (traffic or {}).get(cls), "measured": where}
         if unit == "TFLOP/s" and stream_tf:
             e["frac_of_mfma_stream"] = round(ach / stream_tf, 4)
         e.update(extra or {})

@@ -195,3 +195,29 @@ def test_flux2core_types_the_callers_name_are_declared(type_name):
             continue
         assert re.search(r"(?:public\s+(?:static\s+)?(?:func|var|let)\s+|case\s+(?:\w+\s*(?:\([^)]*\))?\s*,\s*)*)" + member + r"\b", body), \
             f"{type_name}.{member} (used in {fx['used_in']}) has no public declaration in the shim"
+
+
+def test_swift_sources_are_well_formed_as_far_as_text_can_tell():
+    """No Swift toolchain here: at least every shim source has balanced (), [], {} outside comments and strings, every `import` names a
+    target of the package, the system library target, or an Apple / Foundation framework, and every target directory of Package.swift exists."""
+    pkg = open(os.path.join(PKG, "Package.swift")).read()
+    targets = set(re.findall(r'\.(?:target|systemLibrary)\(\s*name:\s*"(\w+)"', pkg))
+    assert {"CFlux2MI", "MLX", "MLXRandom", "Flux2Core"} <= targets
+    allowed = targets | {"Foundation", "CoreGraphics", "ImageIO", "PackageDescription"}
+    for t in targets:
+        assert os.path.isdir(os.path.join(PKG, "Sources", t)), t
+    for mod in sorted(os.listdir(os.path.join(PKG, "Sources"))):
+        for f in sorted(os.listdir(os.path.join(PKG, "Sources", mod))):
+            if not f.endswith(".swift"):
+                continue
+            text = strip(open(os.path.join(PKG, "Sources", mod, f)).read())
+            stack = []
+            for i, c in enumerate(text):
+                if c in "([{":
+                    stack.append(c)
+                elif c in ")]}":
+                    assert stack and stack[-1] == {")": "(", "]": "[", "}": "{"}[c], f"{mod}/{f}: unbalanced '{c}' near line {text.count(chr(10), 0, i) + 1}"
+                    stack.pop()
+            assert not stack, f"{mod}/{f}: {len(stack)} unclosed bracket(s)"
+            for m in re.finditer(r"^\s*(?:@\w+\s+)*import\s+(\w+)", text, flags=re.M):
+                assert m.group(1) in allowed, f"{mod}/{f}: import {m.group(1)} is neither a target of the package nor a system framework"

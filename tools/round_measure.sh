@@ -22,6 +22,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- pyt
 python3 tools/pmc_summary.py $O/fetch > $O/pmc_fetch_size.txt
 python3 tools/pmc_summary.py $O/write > $O/pmc_write_size.txt
 python3 tools/linear1_traffic.py $O/fetch $O/write $O/linear1_traffic.json | tail -5
+python3 tools/secondary_traffic.py $O/pmc_fetch_size.txt $O/pmc_write_size.txt $O/secondary_traffic.json | tail -3
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/sq1 -- python3 tools/one_forward.py klein-4b 2 > $O/sq1.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/sq2 -- python3 tools/one_forward.py klein-4b 2 > $O/sq2.log 2>&1 || exit 1
 python3 tools/pmc_sq.py $O/sq1 $O/sq2 > $O/pmc_sq.txt
