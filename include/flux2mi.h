@@ -287,6 +287,8 @@ int flux2mi_dit_merge_lora_checked(flux2mi_dit* dit, const char* name, int dtype
                                    int dtype_b, const void* B, int64_t b_rows, int64_t b_cols, float scale);
 int flux2mi_dit_merge_lora(flux2mi_dit* dit, const char* name, int dtype, const void* A, const void* B, int rank,
                            float scale);
+/* [out, in] of the weight a checkpoint key addresses (what `WeightLoader.mergeLoRAWeights` reads off `module.weight.shape`, :760-790);
+ * FLUX2MI_ERR_UNKNOWN_KEY when the model has no tensor of that name */
 int flux2mi_dit_slot_shape(flux2mi_dit* dit, const char* name, int64_t* rows, int64_t* cols);
 /* `loadLoRA(LoRAConfig)`, weights side (Flux2Pipeline.swift:618-663, LoRA/LoRALoader.swift:132-140, WeightLoader.swift:736-856):
  * every `<layer>.lora_A.weight` / `.lora_B.weight` pair of the file (each factor in its own float dtype), prefixes
