@@ -96,7 +96,7 @@ struct flux2mi_ctx {
     ProfState prof;
     DevBuf scratch;  // small misc scratch
     int n_cu = 0;    // compute units of the device (workgroup slots for the attention's KV-split)
-    DevBuf attn_ws;  // partial states of KV-split attention items (attention_split_ws_bytes)
+    DevBuf attn_ws;  // raw accumulators of the attention's KV-split pieces (attention64b_split_ws_bytes: n_cu x 135 KB)
     flux2mi_dp* dp = nullptr;   // flux2mi_dp_init
     // flux2mi_generate's own buffers (packed latents, prediction(s), position ids, VAE input, image bytes): grow-only workspaces of the
     // context like every other — no hipMalloc / hipFree (a device-wide synchronisation) per image

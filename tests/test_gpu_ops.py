@@ -392,7 +392,7 @@ def test_attention_growing_maxima(ctx, S, heads):
     """8-wave workgroups (S >= 1024) on grids that leave a partial last round (36 / 54 / 200 / 90 items on 256 CUs).  The keys
     grow in norm along the sequence, so the online softmax rescales in almost every tile and one dominant key sits in the
     middle of every head (guide rule 26: force the rare branch).  Full-tensor check against the oracle's softmax, rel-L2
-    <= 1e-2.  (With the development library's FLUX2MI_ATTN_SPLIT=1 the same test exercises the KV-split pieces + combine.)"""
+    <= 1e-2.  (op_attention is the un-prescaled 8-wave form; the KV-split of the one-wave-per-SIMD kernel has its own test below.)"""
     g = torch.Generator().manual_seed(S * 3 + heads)
     d = heads * 128
     qkv = torch.randn((S, 3 * d), generator=g) * 0.6

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Attention microbenchmark on the DiT's shapes: time per call and TFLOP/s (4 S^2 d), online-softmax op entry.  Dev tool.
-With FLUX2MI_LIB=libflux2mi_dev.so, FLUX2MI_ATTN_SPLIT=0 times the un-split launch for comparison."""
+(The blocks' pre-scaled form with and without the KV-split of the partial round: tools/attn_split_bench.py.)"""
 import os
 import sys
 
