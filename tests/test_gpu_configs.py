@@ -343,3 +343,45 @@ def test_vae_standard_large_latents(flux2mi, ctx, hw):
     assert e < 3e-2
     assert mean < 2.0 and gt8 < 0.01
     assert torch.equal(ou, R.postprocess_vae_output(of))
+
+
+# ------------------------------------------------------------------------------------------------ D at its real sequence length
+def test_config_d_klein9b_width_1024_attention_kv_split_in_the_model(flux2mi, ctx):
+    """Klein-9B width at config D's REAL sequence length (1024 x 1024: S 4608, 32 heads x 18 query blocks = 576 attention items): on a
+    256-CU card the attention's partial last round is KV-split (4 pieces per tail item + the combine kernel; attention64b.hip, AttnSplit) —
+    the one + one block forward with that launch plan active against the oracle, bf16 (<= 2e-2, and <= 5e-3 against the store-point
+    emulation) and e4m3 (block-scaled e4m3 output written by the combine kernel for the tail items: within 0.75 q of the emulating
+    oracle, 0.5 q ... 1.5 q of the f32 one), bit-reproducible."""
+    from flux2mi import synthetic as syn
+    from flux2mi.api import DiT
+    cfg = K9B_W
+    f, n_cu = ctx.op_attention_split_info(4608, cfg["heads"])
+    if n_cu == 256:
+        assert f == 4
+    P = syn.make_dit_weights(cfg, seed=78, device="cuda")
+    inp = syn.make_inputs(cfg, 1024, 1024, s_txt=512)
+    lat = R.pack_patchified_to_sequence(inp["noise"])
+    ii, ti = R.image_position_ids(1024, 1024), R.text_position_ids(512)
+    outs = {}
+    for wf in ("bf16", "fp8"):
+        dit = DiT(ctx, cfg, weights=wf).load(P).finalize()
+        outs[wf] = dit.forward(lat.cuda(), inp["txt"].cuda(), 0.55, 0.0, ii.cuda(), ti.cuda()).cpu()
+        again = dit.forward(lat.cuda(), inp["txt"].cuda(), 0.55, 0.0, ii.cuda(), ti.cuda()).cpu()
+        assert torch.equal(outs[wf], again), wf
+        dit.close()
+    Pc = _cpu(P)
+    del P
+    args = (Pc, cfg, lat, inp["txt"].float(), torch.tensor([0.55]), None, ii, ti)
+    with torch.no_grad():
+        ref32 = R.dit_forward(*args)[0]
+        with R.device_roundings():
+            ref16 = R.dit_forward(*args)[0]
+        with R.fp8_block_gemms(device_roundings=True):
+            ref8 = R.dit_forward(*args)[0]
+    e32, e16 = rel_l2(outs["bf16"], ref32), rel_l2(outs["bf16"], ref16)
+    q, e8 = rel_l2(ref8, ref32), rel_l2(outs["fp8"], ref8)
+    print(f"Klein-9B width, S 4608 ({f} KV pieces per tail item on {n_cu} CUs): bf16 vs f32 oracle {e32:.3e}, vs store-point oracle {e16:.3e}; "
+          f"fp8: q {q:.3e}, HIP vs emulation {e8:.3e} = {e8 / q:.2f} q")
+    assert torch.isfinite(outs["fp8"]).all()
+    assert e32 < 2e-2 and e16 < 5e-3, (e32, e16)
+    assert e8 < 0.75 * q and 0.5 * q < rel_l2(outs["fp8"], ref32) < 1.5 * q, (e8, q)
