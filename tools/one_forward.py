@@ -12,10 +12,11 @@ from flux2mi.api import Context, DiT
 
 model = sys.argv[1] if len(sys.argv) > 1 else "klein-4b"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+weights = sys.argv[3] if len(sys.argv) > 3 else "bf16"     # "fp8": weight_format 1
 dev = torch.device("cuda", 0)
 cfg = syn.DIT_PRESETS[model]
 ctx = Context(0)
-dit = DiT(ctx, model).load(syn.make_dit_weights(cfg, device=dev)).finalize()
+dit = DiT(ctx, model, weights=weights).load(syn.make_dit_weights(cfg, device=dev)).finalize()
 inp = syn.make_inputs(cfg, 1024, 1024, device=dev)
 lat = torch.randn((4096, 128), device=dev)
 img_ids = torch.from_numpy(api.image_position_ids(1024, 1024)).to(dev)
