@@ -1085,7 +1085,7 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
     const size_t tn = (size_t)grid.x * 16;
     if (trace_env && ++seen % 16 == 0 && hipMalloc((void**)&b.trace, tn * 8) != hipSuccess) b.trace = nullptr;
     struct TraceOut {
-        GemmBatch& b; hipStream_t stream; size_t tn; const GemmProblem* probs;
+        GemmBatch& b; hipStream_t stream; size_t tn; const GemmProblem* probs; int ni; int nprob;
         ~TraceOut() {
             if (!b.trace) return;
             std::vector<unsigned long long> h(tn);
@@ -1094,10 +1094,12 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
             (void)hipFree(b.trace);
             double cyc = 0, rt = 0, kt = 0;
             for (size_t w = 0; w < tn / 4; ++w) { cyc += (double)h[w * 4]; rt += (double)h[w * 4 + 1]; kt += (double)h[w * 4 + 2] + 1.5; }   // + prologue ~1.5 K-tiles
-            fprintf(stderr, "[gemm256s trace] M %d N %d K %d%s: %.0f shader cycles per K-tile (2048 = MFMA issue alone; prologue counted as 1.5), clock %.0f MHz, %.3f us per K-tile\n",
-                    probs[0].M, probs[0].N, probs[0].K, probs[0].fp8 ? " fp8" : "", cyc / kt, cyc / rt * 100.0, rt / kt * 0.01);
+            // a K-tile is 16 NI MFMAs of 16 cycles (bf16, 64 deep) or 8 NI of 32 (e4m3, 128 deep): 256 NI cycles of MFMA issue either way
+            fprintf(stderr, "[gemm256s trace] M %d N %d K %d%s%s, %d-row tiles: %.0f shader cycles per K-tile (%d = MFMA issue alone; prologue counted as 1.5), clock %.0f MHz, %.3f us per K-tile\n",
+                    probs[0].M, probs[0].N, probs[0].K, probs[0].fp8 ? " fp8" : "", nprob > 1 ? " (+ a second problem)" : "", 32 * ni, cyc / kt, 256 * ni,
+                    cyc / rt * 100.0, rt / kt * 0.01);
         }
-    } trace_out{b, stream, tn, probs};
+    } trace_out{b, stream, tn, probs, ni, nprob};
     if (probs[0].epi == EPI_CONV) {
         for (int i = 0; i < nprob; ++i) {
             const GemmProblem& q = probs[i];
