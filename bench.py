@@ -182,7 +182,9 @@ def main():
         # per-tensor seeds, generated on the GPU one tensor at a time (Dev is 64 GB: no second copy of the model anywhere)
         # the CPU-oracle leg needs the tensors themselves: Klein-4B only (a Dev forward is minutes of host time and 64 GB of host memory)
         need_host_copy = rank == 0 and not args.no_cpu_baseline and world == 1 and args.model == "klein-4b"
-        P = syn.make_dit_weights(cfg, seed=1234, device=dev) if need_host_copy else syn.LazyDitWeights(cfg, seed=1234, device=dev)
+        # ONE weight recipe in every mode (default run, --no-cpu-baseline, other models, multi-GPU): output_check.image_crc32 of a
+        # configuration is the same number whichever way it was run; the oracle leg draws the same tensors again (to the host)
+        P = syn.LazyDitWeights(cfg, seed=1234, device=dev)
         VP = syn.make_vae_weights(vcfg, seed=4321, device=dev)
         pipe.load_models(P, VP)
         if world > 1:
@@ -414,7 +416,8 @@ def main():
         "attention_softmax": None if dry else pipe.transformer.attention_softmax_paths(),
         # KV pieces per (head, query block) item of the attention's partial last round on this GPU (1 = whole items only)
         "attention_kv_split_pieces": None if dry else pipe.ctx.op_attention_split_info(S_all, cfg["heads"])[0],
-        "output_check": {"latents_finite": True, "image_crc32": checksum, "u8_histogram": hist},
+        "output_check": {"latents_finite": True, "image_crc32": checksum, "u8_histogram": hist,
+                         "weights": "synthetic.LazyDitWeights(seed 1234) + make_vae_weights(seed 4321)"},
         "model_load_s": round(t_load, 2),
         "roofline": roofline,
         "roofline_secondary": roofline_secondary,

@@ -87,6 +87,7 @@ PROTOTYPES = {
     "flux2mi_buffer_free": (_I, [_P, _P]),
     "flux2mi_buffer_upload": (_I, [_P, _P, _P, C.c_size_t]),
     "flux2mi_buffer_download": (_I, [_P, _P, _P, C.c_size_t]),
+    "flux2mi_dp_rccl_library": (C.c_char_p, []),
     "flux2mi_dp_unique_id": (_I, [_P]),
     "flux2mi_dp_init": (_I, [_P, _I, _I, _P]),
     "flux2mi_dp_finalize": (_I, [_P]),

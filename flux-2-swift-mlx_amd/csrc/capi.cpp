@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <condition_variable>
 #include <mutex>
 #include <unordered_map>
 #include <unordered_set>
@@ -35,8 +36,12 @@ struct MemTable {
     std::unordered_map<void*, Rec> live;
     std::unordered_set<DevBuf*> bufs;
     size_t active[FLUX2MI_MAX_DEVICES] = {0}, workspace[FLUX2MI_MAX_DEVICES] = {0}, peak[FLUX2MI_MAX_DEVICES] = {0};
-    int generating = 0;
+    // per device: open WorkspaceUse count, and whether a trim is releasing right now (uses and DevBuf destructors wait on cv)
+    int users[FLUX2MI_MAX_DEVICES] = {0};
+    bool trimming[FLUX2MI_MAX_DEVICES] = {false};
+    std::condition_variable cv;
 };
+int dev_slot(int device) { return device >= 0 && device < FLUX2MI_MAX_DEVICES ? device : 0; }
 MemTable& mem() {
     static MemTable* t = new MemTable();   // never destroyed: DevBufs of static objects may outlive any static table
     return *t;
@@ -70,14 +75,28 @@ void f2_free(void* p) {
     }
     (void)hipFree(p);
 }
-GenerationInFlight::GenerationInFlight() { std::lock_guard<std::mutex> g(mem().mu); ++mem().generating; }
-GenerationInFlight::~GenerationInFlight() { std::lock_guard<std::mutex> g(mem().mu); --mem().generating; }
+WorkspaceUse::WorkspaceUse(int dev) : device(dev_slot(dev)) {
+    MemTable& t = mem();
+    std::unique_lock<std::mutex> g(t.mu);
+    // a nested use (users > 0) never waits: a trim only starts with no use open
+    t.cv.wait(g, [&] { return t.users[device] > 0 || !t.trimming[device]; });
+    ++t.users[device];
+}
+WorkspaceUse::~WorkspaceUse() {
+    MemTable& t = mem();
+    std::lock_guard<std::mutex> g(t.mu);
+    --t.users[device];
+}
 
 DevBuf::DevBuf() { std::lock_guard<std::mutex> g(mem().mu); mem().bufs.insert(this); }
 DevBuf::~DevBuf() {
+    {   // leave the table first (a trim collects its victims from it), and never under a trim that may hold this buffer as a victim
+        MemTable& t = mem();
+        std::unique_lock<std::mutex> g(t.mu);
+        t.cv.wait(g, [&] { return device < 0 || !t.trimming[dev_slot(device)]; });
+        t.bufs.erase(this);
+    }
     release();
-    std::lock_guard<std::mutex> g(mem().mu);
-    mem().bufs.erase(this);
 }
 int DevBuf::reserve(size_t n) {
     if (n <= bytes) return FLUX2MI_OK;
@@ -122,20 +141,31 @@ extern "C" int flux2mi_ctx_trim(flux2mi_ctx* ctx, size_t* freed_bytes) {
     if (freed_bytes) *freed_bytes = 0;
     F2_CHECK_HIP(hipSetDevice(ctx->device));
     std::vector<DevBuf*> victims;
+    MemTable& t = mem();
+    const int d = dev_slot(ctx->device);
     {
-        MemTable& t = mem();
         std::lock_guard<std::mutex> g(t.mu);
-        if (t.generating > 0) return FLUX2MI_OK;   // the workspaces are in use (a hook called us): nothing to give back now
+        // a call that uses the workspaces is running on this device (another thread's forward / decode / merge, or the generation whose
+        // hook called us), or another trim is: nothing to give back now
+        if (t.users[d] > 0 || t.trimming[d]) return FLUX2MI_OK;
         for (DevBuf* b : t.bufs)
             if (b->ptr && !b->keep && b->device == ctx->device) victims.push_back(b);
+        if (victims.empty()) return FLUX2MI_OK;
+        t.trimming[d] = true;   // from here to the end: no new use starts on the device, no victim is destroyed
     }
-    if (victims.empty()) return FLUX2MI_OK;
-    F2_CHECK_HIP(hipDeviceSynchronize());   // work queued on any context of this device may still use them
+    const hipError_t se = hipDeviceSynchronize();   // work queued on any context of this device may still use them
     size_t freed = 0;
-    for (DevBuf* b : victims) {
-        freed += b->bytes;
-        b->release();
+    if (se == hipSuccess)
+        for (DevBuf* b : victims) {
+            freed += b->bytes;
+            b->release();
+        }
+    {
+        std::lock_guard<std::mutex> g(t.mu);
+        t.trimming[d] = false;
     }
+    t.cv.notify_all();
+    F2_CHECK_HIP(se);
     if (freed_bytes) *freed_bytes = freed;
     return FLUX2MI_OK;
 }
@@ -168,6 +198,7 @@ extern "C" int flux2mi_ctx_create(int device, void* hip_stream, flux2mi_ctx** ou
 
 extern "C" int flux2mi_ctx_destroy(flux2mi_ctx* ctx) {
     if (!ctx) return FLUX2MI_OK;
+    F2_WORKSPACE_USE(ctx->device);   // explicit releases below: not beside a trim
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)flux2mi_dp_finalize(ctx);
@@ -246,6 +277,7 @@ void prof_after(flux2mi_ctx* ctx, int cls_mask, double flops) {
 
 extern "C" int flux2mi_debug_mfma_stream(flux2mi_ctx* ctx, int fp8, double seconds, double* tflops) {
     F2_REQUIRE(ctx && tflops && seconds > 0.0 && seconds <= 10.0 && (fp8 == 0 || fp8 == 1), FLUX2MI_ERR_INVALID_ARG, "debug_mfma_stream: bad args");
+    F2_WORKSPACE_USE(ctx->device);
     int n_cu = ctx->n_cu;
     if (n_cu <= 0) {
         hipDeviceProp_t pr;

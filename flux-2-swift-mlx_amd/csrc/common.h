@@ -52,11 +52,22 @@ enum { PROF_LINEAR1 = 1 << 0, PROF_DIT_GEMM = 1 << 1, PROF_ATTENTION = 1 << 2, P
 #define FLUX2MI_MAX_DEVICES 16
 hipError_t f2_malloc(void** p, size_t bytes, bool workspace = false);
 void f2_free(void* p);
-// RAII mark of a running flux2mi_generate: flux2mi_ctx_trim leaves the workspaces alone while one is in flight.
-struct GenerationInFlight { GenerationInFlight(); ~GenerationInFlight(); };
+// Threading contract of the workspaces (MLX.Memory.clearCache is callable from any thread, and so is flux2mi_ctx_trim): every entry
+// point that reserves or hands out DevBuf memory holds a WorkspaceUse of its device for the duration of the call (nestable: generate ->
+// forward).  flux2mi_ctx_trim gives nothing back while a use is open on the device (also: called from a hook of a running
+// generation), keeps new uses and DevBuf destructors waiting while it releases, and drains the device's queued work first.
+struct WorkspaceUse {
+    int device;
+    explicit WorkspaceUse(int device);
+    ~WorkspaceUse();
+    WorkspaceUse(const WorkspaceUse&) = delete;
+    WorkspaceUse& operator=(const WorkspaceUse&) = delete;
+};
+#define F2_WORKSPACE_USE(dev) WorkspaceUse _f2_ws_use(dev)
 
 // Grow-only device buffer (no allocation inside the steady-state loop).  Registered process-wide so that flux2mi_ctx_trim can
 // release the ones of its device; `keep` marks buffers whose contents are built once (derived weights) and must survive a trim.
+// reserve() is only called under a WorkspaceUse of the buffer's device; the destructor waits for a running trim.
 struct DevBuf {
     void* ptr = nullptr;
     size_t bytes = 0;

@@ -331,6 +331,7 @@ extern "C" int flux2mi_dit_create(flux2mi_ctx* ctx, const flux2mi_dit_config* cf
 
 extern "C" int flux2mi_dit_destroy(flux2mi_dit* m) {
     if (!m) return FLUX2MI_OK;
+    F2_WORKSPACE_USE(m->ctx->device);   // explicit releases below: not beside a trim
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     for (Buf& b : m->bufs) {
@@ -350,6 +351,7 @@ extern "C" int64_t flux2mi_dit_param_bytes(const flux2mi_dit* m) { return m ? m-
 extern "C" int flux2mi_dit_set_tensor(flux2mi_dit* m, const char* name, int dtype, const int64_t* shape, int ndim,
                                       const void* data) {
     F2_REQUIRE(m && name && shape && data, FLUX2MI_ERR_INVALID_ARG, "dit_set_tensor: NULL argument");
+    F2_WORKSPACE_USE(m->ctx->device);
     F2_REQUIRE(dtype == FLUX2MI_F32 || dtype == FLUX2MI_BF16 || dtype == FLUX2MI_F16, FLUX2MI_ERR_INVALID_ARG,
                "dit_set_tensor(%s): unsupported dtype %d", name, dtype);
     auto it = m->slots.find(name);
@@ -401,6 +403,7 @@ GemmProblem mk(const uint16_t* A, int lda, const uint16_t* W, int ldw, void* C, 
 extern "C" int flux2mi_dit_set_tensor_q8(flux2mi_dit* m, const char* name, const int8_t* data, const float* scale,
                                          int64_t rows, int64_t cols) {
     F2_REQUIRE(m && name && data && scale && rows > 0 && cols > 0, FLUX2MI_ERR_INVALID_ARG, "dit_set_tensor_q8: bad argument");
+    F2_WORKSPACE_USE(m->ctx->device);
     F2_CHECK_HIP(hipSetDevice(m->ctx->device));
     hipStream_t st = m->ctx->stream;
     const size_t n = (size_t)rows * cols;
@@ -426,6 +429,7 @@ extern "C" int flux2mi_dit_set_tensor_q8(flux2mi_dit* m, const char* name, const
 extern "C" int flux2mi_dit_merge_lora_checked(flux2mi_dit* m, const char* name, int dtype_a, const void* A, int64_t a_rows, int64_t a_cols,
                                               int dtype_b, const void* B, int64_t b_rows, int64_t b_cols, float scale) {
     F2_REQUIRE(m && name && A && B && a_rows > 0 && a_rows <= INT32_MAX, FLUX2MI_ERR_INVALID_ARG, "dit_merge_lora: bad argument");
+    F2_WORKSPACE_USE(m->ctx->device);
     for (int dtype : {dtype_a, dtype_b})
         F2_REQUIRE(dtype == FLUX2MI_F32 || dtype == FLUX2MI_BF16 || dtype == FLUX2MI_F16, FLUX2MI_ERR_INVALID_ARG,
                    "dit_merge_lora(%s): unsupported dtype %d", name, dtype);
@@ -504,6 +508,7 @@ extern "C" int flux2mi_dit_slot_shape(flux2mi_dit* m, const char* name, int64_t*
 
 extern "C" int flux2mi_dit_finalize(flux2mi_dit* m) {
     F2_REQUIRE(m, FLUX2MI_ERR_INVALID_ARG, "dit_finalize: NULL");
+    F2_WORKSPACE_USE(m->ctx->device);
     for (const Buf& b : m->bufs) {
         if (b.got_rows() < b.rows) {
             flux2mi_set_error("dit_finalize: tensor '%s' missing (%d of %d rows loaded)", b.label.c_str(), b.got_rows(),
@@ -638,6 +643,7 @@ std::vector<PreqEntry> preq_entries(const flux2mi_dit* m) {
 
 extern "C" int flux2mi_dit_export_prequantized(flux2mi_dit* m, const char* path, const char* source_fingerprint) {
     F2_REQUIRE(m && path && *path, FLUX2MI_ERR_INVALID_ARG, "dit_export_prequantized: bad argument");
+    F2_WORKSPACE_USE(m->ctx->device);
     F2_REQUIRE(m->finalized, FLUX2MI_ERR_NOT_LOADED, "dit_export_prequantized: weights not finalized");
     F2_CHECK_HIP(hipSetDevice(m->ctx->device));
     F2_CHECK_HIP(hipStreamSynchronize(m->ctx->stream));
@@ -696,6 +702,7 @@ extern "C" int flux2mi_dit_export_prequantized(flux2mi_dit* m, const char* path,
 
 extern "C" int flux2mi_dit_load_prequantized(flux2mi_dit* m, const char* path, const char* expected_fingerprint, int* lora_baked) {
     F2_REQUIRE(m && path, FLUX2MI_ERR_INVALID_ARG, "dit_load_prequantized: bad argument");
+    F2_WORKSPACE_USE(m->ctx->device);
     MappedFile f;
     std::map<std::string, TensorInfo> ts;
     std::map<std::string, std::string> md;
@@ -1319,6 +1326,7 @@ extern "C" int flux2mi_dit_forward(flux2mi_dit* m, const float* latents, int s_i
                                    float timestep, float guidance, const int32_t* img_ids, const int32_t* txt_ids,
                                    float* out, int s_out) {
     F2_REQUIRE(m && latents && txt_emb && img_ids && txt_ids && out, FLUX2MI_ERR_INVALID_ARG, "dit_forward: NULL argument");
+    F2_WORKSPACE_USE(m->ctx->device);
     F2_REQUIRE(m->finalized, FLUX2MI_ERR_NOT_LOADED, "dit_forward: weights not finalized");
     F2_REQUIRE(s_img > 0 && s_txt > 0 && s_out > 0 && s_out <= s_img, FLUX2MI_ERR_SHAPE,
                "dit_forward: s_img %d s_txt %d s_out %d", s_img, s_txt, s_out);
@@ -1339,6 +1347,7 @@ extern "C" int flux2mi_dit_forward_block(flux2mi_dit* m, int layer, const float*
                                          const void* txt_emb, int s_txt, float timestep, float guidance, const int32_t* img_ids,
                                          const int32_t* txt_ids, float* final_out) {
     F2_REQUIRE(m && hs_out && txt_emb && img_ids && txt_ids && (hs_in || latents), FLUX2MI_ERR_INVALID_ARG, "dit_forward_block: NULL argument");
+    F2_WORKSPACE_USE(m->ctx->device);
     F2_REQUIRE(m->finalized, FLUX2MI_ERR_NOT_LOADED, "dit_forward_block: weights not finalized");
     F2_REQUIRE(layer >= 0 && layer < m->cfg.n_double + m->cfg.n_single, FLUX2MI_ERR_INVALID_ARG, "dit_forward_block: layer %d of %d", layer,
                m->cfg.n_double + m->cfg.n_single);
@@ -1365,6 +1374,7 @@ extern "C" int flux2mi_dit_forward_block(flux2mi_dit* m, int layer, const float*
 // txt(6 dim) | single(3 dim) | final(2 dim: shift, scale), copied to `out` (device or host) in stream order.  Parity tests only.
 extern "C" int flux2mi_dit_last_modulation(flux2mi_dit* m, float* out, int64_t n_floats) {
     F2_REQUIRE(m && out, FLUX2MI_ERR_INVALID_ARG, "dit_last_modulation: NULL argument");
+    F2_WORKSPACE_USE(m->ctx->device);
     const int64_t n = 256 + (int64_t)19 * m->cfg.dim;
     F2_REQUIRE(n_floats >= n && m->mods.ptr, FLUX2MI_ERR_SHAPE, "dit_last_modulation: %lld floats needed (and a forward first)", (long long)n);
     F2_CHECK_HIP(hipSetDevice(m->ctx->device));
@@ -1397,6 +1407,7 @@ extern "C" int flux2mi_dit_attention_softmax_info(const flux2mi_dit* m, int* n_f
 // ------------------------------------------------------------------ KV-cached reference conditioning
 extern "C" int flux2mi_kv_cache_create(flux2mi_dit* m, int s_txt, int s_ref, flux2mi_kv_cache** out) {
     F2_REQUIRE(m && out && s_txt > 0 && s_ref > 0, FLUX2MI_ERR_INVALID_ARG, "kv_cache_create: bad argument");
+    F2_WORKSPACE_USE(m->ctx->device);
     F2_CHECK_HIP(hipSetDevice(m->ctx->device));
     flux2mi_kv_cache* c = new flux2mi_kv_cache();
     c->dit = m;
@@ -1442,6 +1453,7 @@ extern "C" int flux2mi_dit_forward_kv_extract(flux2mi_dit* m, flux2mi_kv_cache* 
                                               const int32_t* txt_ids, const int32_t* ref_ids, float* out) {
     F2_REQUIRE(m && cache && latents && ref_latents && txt_emb && img_ids && txt_ids && ref_ids && out, FLUX2MI_ERR_INVALID_ARG,
                "dit_forward_kv_extract: NULL argument");
+    F2_WORKSPACE_USE(m->ctx->device);
     F2_REQUIRE(m->finalized, FLUX2MI_ERR_NOT_LOADED, "dit_forward_kv_extract: weights not finalized");
     F2_REQUIRE(cache->dit == m && cache->s_txt == s_txt && cache->s_ref == s_ref && s_out > 0, FLUX2MI_ERR_SHAPE,
                "dit_forward_kv_extract: cache was created for s_txt %d s_ref %d, call has %d / %d", cache->s_txt,
@@ -1457,6 +1469,7 @@ extern "C" int flux2mi_dit_forward_kv_cached(flux2mi_dit* m, flux2mi_kv_cache* c
                                              const int32_t* img_ids, const int32_t* txt_ids, float* out) {
     F2_REQUIRE(m && cache && latents && txt_emb && img_ids && txt_ids && out, FLUX2MI_ERR_INVALID_ARG,
                "dit_forward_kv_cached: NULL argument");
+    F2_WORKSPACE_USE(m->ctx->device);
     F2_REQUIRE(m->finalized, FLUX2MI_ERR_NOT_LOADED, "dit_forward_kv_cached: weights not finalized");
     // the reference aborts here (fatalError, Flux2Transformer.swift:488); this returns a status
     F2_REQUIRE(cache->filled, FLUX2MI_ERR_NOT_LOADED, "dit_forward_kv_cached: the cache has not been filled by an extraction pass");
@@ -1479,6 +1492,7 @@ static int op_splitk_ws(flux2mi_ctx* ctx, GemmProblem& p) {
 
 extern "C" int flux2mi_op_gemm_bf16(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K) {
     F2_REQUIRE(ctx && A && W && C, FLUX2MI_ERR_INVALID_ARG, "op_gemm: NULL argument");
+    F2_WORKSPACE_USE(ctx->device);
     GemmProblem p = mk(reinterpret_cast<const uint16_t*>(A), K, reinterpret_cast<const uint16_t*>(W), K, C, N, M, N, K, EPI_F32);
     F2_TRY(op_splitk_ws(ctx, p));
     prof_before(ctx, PROF_DIT_GEMM);
@@ -1492,6 +1506,7 @@ extern "C" int flux2mi_op_gemm_bf16(flux2mi_ctx* ctx, const void* A, const void*
 // vendor comparison of tools/gemm_bench.py (hipBLASLt writes bf16 too) and for tests of the EPI_BF16 store path.
 extern "C" int flux2mi_op_gemm_bf16_out_bf16(flux2mi_ctx* ctx, const void* A, const void* W, void* C, int M, int N, int K) {
     F2_REQUIRE(ctx && A && W && C && M > 0 && N > 0 && K > 0, FLUX2MI_ERR_INVALID_ARG, "op_gemm_bf16_out_bf16: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     GemmProblem p = mk(reinterpret_cast<const uint16_t*>(A), K, reinterpret_cast<const uint16_t*>(W), K, C, N, M, N, K, EPI_BF16);
     F2_TRY(op_splitk_ws(ctx, p));
     prof_before(ctx, PROF_DIT_GEMM);
@@ -1506,6 +1521,7 @@ extern "C" int flux2mi_op_gemm_bf16_out_bf16(flux2mi_ctx* ctx, const void* A, co
 extern "C" int flux2mi_op_gemm_gate_resid(flux2mi_ctx* ctx, const void* A, const void* W, const float* gate, float* X,
                                           int M, int N, int K) {
     F2_REQUIRE(ctx && A && W && gate && X && M > 0 && N > 0 && K > 0, FLUX2MI_ERR_INVALID_ARG, "op_gemm_gate_resid: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     GemmProblem p = mk(reinterpret_cast<const uint16_t*>(A), K, reinterpret_cast<const uint16_t*>(W), K, X, N, M, N, K, EPI_GATE_RESID);
     p.vec = gate;
     F2_TRY(op_splitk_ws(ctx, p));
@@ -1518,6 +1534,7 @@ extern "C" int flux2mi_op_gemm_gate_resid(flux2mi_ctx* ctx, const void* A, const
 
 extern "C" int flux2mi_op_gemm_fp8(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K) {
     F2_REQUIRE(ctx && A && W && C && M > 0 && N > 0 && K > 0 && K % 128 == 0, FLUX2MI_ERR_INVALID_ARG, "op_gemm_fp8: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     const size_t need = (size_t)M * K + (size_t)N * K + ((size_t)M + N) * 4 + 1024;
     F2_TRY(ctx->scratch.reserve(need));
     uint8_t* aq = ctx->scratch.as<uint8_t>();
@@ -1539,6 +1556,7 @@ extern "C" int flux2mi_op_gemm_fp8(flux2mi_ctx* ctx, const void* A, const void* 
 // attention epilogues of the fp8 models emit): the block scales ride in the MFMA's scale operand.
 extern "C" int flux2mi_op_gemm_fp8_blocks(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K) {
     F2_REQUIRE(ctx && A && W && C && M > 0 && N > 0 && K > 0 && K % 128 == 0, FLUX2MI_ERR_INVALID_ARG, "op_gemm_fp8_blocks: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     const int lds = (((M + 15) / 16 + 12) + 15) & ~15;
     const size_t need = (size_t)M * K + (size_t)N * K + (size_t)N * 4 + (size_t)(K / 128) * lds + 2048;
     F2_TRY(ctx->scratch.reserve(need));
@@ -1560,6 +1578,7 @@ extern "C" int flux2mi_op_gemm_fp8_blocks(flux2mi_ctx* ctx, const void* A, const
 
 extern "C" int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv_in, void* out, int S, int heads) {
     F2_REQUIRE(ctx && qkv_in && out && S > 0 && heads > 0, FLUX2MI_ERR_INVALID_ARG, "op_attention: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     const int d = heads * 128, s_pad = attn_s_pad(S);
     // scratch: a private copy of qkv is not needed (q,k are used as given); only V^T is built.
     F2_TRY(ctx->scratch.reserve((size_t)heads * 128 * s_pad * 2 + 256 * 4));
@@ -1582,6 +1601,7 @@ extern "C" int flux2mi_op_attention(flux2mi_ctx* ctx, const void* qkv_in, void* 
 // (attention.hip / attention64b.hip).  score_bound_log2 <= 0 or > 80: the per-query data-offset form (exact for any scores).
 extern "C" int flux2mi_op_attention_prescaled(flux2mi_ctx* ctx, const void* qkv_in, void* out, int S, int heads, float score_bound_log2) {
     F2_REQUIRE(ctx && qkv_in && out && S > 0 && heads > 0, FLUX2MI_ERR_INVALID_ARG, "op_attention_prescaled: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     const int d = heads * 128, s_pad = attn_s_pad(S);
     F2_TRY(ctx->scratch.reserve((size_t)heads * 128 * s_pad * 2 + 256 * 4));
     uint16_t* vt = ctx->scratch.as<uint16_t>();
@@ -1619,6 +1639,7 @@ extern "C" int flux2mi_op_attention_qk8(flux2mi_ctx* ctx, const void* q8, const 
 extern "C" int flux2mi_op_attention_qk8_blocks(flux2mi_ctx* ctx, const void* q8, const void* k8, const void* v, void* out, void* out8, void* bs, int bs_ld,
                                                int S, int heads, int q_exp, int k_exp, float score_bound_log2) {
     F2_REQUIRE(ctx && q8 && k8 && v && (out || (out8 && bs)) && S > 0 && heads > 0, FLUX2MI_ERR_INVALID_ARG, "op_attention_qk8: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     const int d = heads * 128, s_pad = attn_s_pad(S);
     F2_TRY(ctx->scratch.reserve((size_t)heads * 128 * s_pad * 2 + 256 * 4));
     uint16_t* vt = ctx->scratch.as<uint16_t>();
@@ -1642,6 +1663,7 @@ extern "C" int flux2mi_op_attention_prescaled_range(flux2mi_ctx* ctx, const void
                                                     int q0, int nq, int nk) {
     F2_REQUIRE(ctx && qkv_in && out && S > 0 && heads > 0 && q0 >= 0 && nq > 0 && q0 + nq <= S && nk > 0 && nk <= S, FLUX2MI_ERR_INVALID_ARG,
                "op_attention_prescaled_range: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     const int d = heads * 128, s_pad = attn_s_pad(S);
     F2_TRY(ctx->scratch.reserve((size_t)heads * 128 * s_pad * 2 + 256 * 4));
     uint16_t* vt = ctx->scratch.as<uint16_t>();
@@ -1664,6 +1686,7 @@ extern "C" int flux2mi_op_layernorm_modulate(flux2mi_ctx* ctx, const float* x, v
                                              const float* shift0, const float* scale0, const float* shift1, const float* scale1) {
     F2_REQUIRE(ctx && x && y && shift0 && scale0 && shift1 && scale1 && rows > 0 && dim > 0, FLUX2MI_ERR_INVALID_ARG,
                "op_layernorm_modulate: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     F2_LAUNCH(launch_layernorm_modulate(ctx->stream, x, reinterpret_cast<uint16_t*>(y), rows, dim, split, shift0, scale0, shift1, scale1),
               "op_layernorm_modulate");
     return FLUX2MI_OK;
@@ -1675,6 +1698,7 @@ extern "C" int flux2mi_op_layernorm_modulate(flux2mi_ctx* ctx, const float* x, v
 extern "C" int flux2mi_op_qk_norm_rope(flux2mi_ctx* ctx, void* qkv, int S, int heads, int split, const void* qw0, const void* kw0,
                                        const void* qw1, const void* kw1, const int32_t* ids, float q_mul) {
     F2_REQUIRE(ctx && qkv && qw0 && kw0 && qw1 && kw1 && ids && S > 0 && heads > 0, FLUX2MI_ERR_INVALID_ARG, "op_qk_norm_rope: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     const int s_pad = attn_s_pad(S);
     const size_t tab = (size_t)S * 128 * 4;
     F2_TRY(ctx->scratch.reserve(2 * tab + (size_t)heads * 128 * s_pad * 2 + 256));
@@ -1695,6 +1719,7 @@ extern "C" int flux2mi_op_qk_proj_norm_rope(flux2mi_ctx* ctx, const void* x, con
                                             const void* kw, const int32_t* ids, float q_mul, void* out) {
     F2_REQUIRE(ctx && x && w && qw && kw && ids && out && S > 0 && dim > 0 && dim % 256 == 0, FLUX2MI_ERR_INVALID_ARG,
                "op_qk_proj_norm_rope: bad argument (dim %% 256 == 0)");
+    F2_WORKSPACE_USE(ctx->device);
     const size_t tab = (size_t)S * 128 * 4;
     F2_TRY(ctx->scratch.reserve(2 * tab + (size_t)S * 16 + 256));
     float* cos_tab = ctx->scratch.as<float>();
@@ -1719,6 +1744,7 @@ extern "C" int flux2mi_op_groupnorm_silu(flux2mi_ctx* ctx, const void* x, void* 
                                          const float* beta, float eps, int silu) {
     F2_REQUIRE(ctx && x && y && gamma && beta && pixels > 0 && C > 0 && groups > 0 && C % groups == 0, FLUX2MI_ERR_INVALID_ARG,
                "op_groupnorm_silu: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     const size_t part = (size_t)groupnorm_partial_floats(pixels, groups) * 4;
     F2_TRY(ctx->scratch.reserve(part + (size_t)2 * C * 4 + 256));
     float* partial = ctx->scratch.as<float>();

@@ -12,6 +12,7 @@
 // ROCm lives elsewhere load libflux2mi.so without it; the dp entry points then return FLUX2MI_ERR_UNSUPPORTED naming what was tried.
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and constants only
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <mutex>
@@ -21,7 +22,7 @@
 namespace {
 struct Rccl {
     void* handle = nullptr;
-    std::string tried;
+    std::string tried, bound;   // files that failed to load / the one that was bound (flux2mi_dp_rccl_library)
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
@@ -34,18 +35,27 @@ Rccl g_rccl;
 std::once_flag g_rccl_once;
 
 void rccl_open() {
-    std::vector<std::string> names;
-    if (const char* e = getenv("FLUX2MI_RCCL_LIB")) names.push_back(e);                 // an explicit file
-    if (const char* e = getenv("ROCM_PATH")) names.push_back(std::string(e) + "/lib/librccl.so.1");
-    names.push_back("/opt/rocm/lib/librccl.so.1");
-    names.push_back("librccl.so.1");                                                   // the loader's search path / an already loaded RCCL
-    names.push_back("librccl.so");
-    for (const std::string& n : names) {
-        g_rccl.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (g_rccl.handle) break;
-        g_rccl.tried += (g_rccl.tried.empty() ? "" : ", ") + n;
+    // Order: an explicit file; then an RCCL the process has ALREADY mapped (a host that runs torch.distributed brought its own
+    // librccl.so.1: binding a second copy by absolute path would mean a second set of proxy threads and possibly another version);
+    // only then the ROCm installation and the loader's search path.
+    std::vector<std::pair<std::string, int>> names;
+    if (const char* e = getenv("FLUX2MI_RCCL_LIB")) names.push_back({e, 0});
+    names.push_back({"librccl.so.1", RTLD_NOLOAD});
+    names.push_back({"librccl.so", RTLD_NOLOAD});
+    if (const char* e = getenv("ROCM_PATH")) names.push_back({std::string(e) + "/lib/librccl.so.1", 0});
+    names.push_back({"/opt/rocm/lib/librccl.so.1", 0});
+    names.push_back({"librccl.so.1", 0});
+    names.push_back({"librccl.so", 0});
+    for (const auto& n : names) {
+        g_rccl.handle = dlopen(n.first.c_str(), RTLD_NOW | RTLD_LOCAL | n.second);
+        if (g_rccl.handle) {
+            g_rccl.bound = n.first + (n.second ? " (already loaded)" : "");
+            break;
+        }
+        if (!n.second) g_rccl.tried += (g_rccl.tried.empty() ? "" : ", ") + n.first;
     }
     if (!g_rccl.handle) return;
+    if (getenv("FLUX2MI_LOG")) fprintf(stderr, "[flux2mi] RCCL bound: %s\n", g_rccl.bound.c_str());
     bool ok = true;
     auto sym = [&](const char* name) { void* p = dlsym(g_rccl.handle, name); if (!p) { ok = false; g_rccl.tried = std::string("symbol ") + name; } return p; };
     g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(sym("ncclGetUniqueId"));
@@ -81,6 +91,11 @@ static_assert(NCCL_UNIQUE_ID_BYTES == FLUX2MI_DP_UNIQUE_ID_BYTES, "unique id siz
             return FLUX2MI_ERR_HIP;                                                                           \
         }                                                                                                     \
     } while (0)
+
+extern "C" const char* flux2mi_dp_rccl_library(void) {
+    std::call_once(g_rccl_once, rccl_open);
+    return g_rccl.handle ? g_rccl.bound.c_str() : nullptr;
+}
 
 extern "C" int flux2mi_dp_unique_id(uint8_t* id) {
     F2_REQUIRE(id, FLUX2MI_ERR_INVALID_ARG, "dp_unique_id: NULL");
@@ -152,6 +167,7 @@ extern "C" int flux2mi_dp_all_gather_images(flux2mi_ctx* ctx, const uint8_t* loc
 // max over the ranks of one f64 (the bench's max-over-ranks step time; also a barrier).  Synchronises the stream.
 extern "C" int flux2mi_dp_all_reduce_max(flux2mi_ctx* ctx, double* value) {
     F2_REQUIRE(ctx && value, FLUX2MI_ERR_INVALID_ARG, "dp_all_reduce_max: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     F2_REQUIRE(ctx->dp, FLUX2MI_ERR_NOT_LOADED, "dp_all_reduce_max: flux2mi_dp_init has not been called on this context");
     F2_CHECK_HIP(hipSetDevice(ctx->device));
     F2_TRY(ctx->scratch.reserve(256));

@@ -269,6 +269,7 @@ extern "C" int flux2mi_image_resample_u8(flux2mi_ctx* ctx, const uint8_t* src, i
                                          uint8_t* dst, int dst_h, int dst_w) {
     F2_REQUIRE(ctx && src && dst && src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0 && channels >= 1 && channels <= 4,
                FLUX2MI_ERR_INVALID_ARG, "image_resample_u8: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     double b[4];
     F2_REQUIRE(valid_box(box, src_h, src_w, b), FLUX2MI_ERR_INVALID_ARG, "image_resample_u8: box outside the image");
     return resample_impl(ctx, src, src_h, src_w, channels, 0, channels, b, dst, dst_h, dst_w);
@@ -278,6 +279,7 @@ extern "C" int flux2mi_mask_inpaint_weights(flux2mi_ctx* ctx, const uint8_t* mas
                                             const float* box, float* weights, int out_h, int out_w) {
     F2_REQUIRE(ctx && mask && weights && mask_h > 0 && mask_w > 0 && out_h > 0 && out_w > 0 && (channels == 1 || channels == 3 || channels == 4),
                FLUX2MI_ERR_INVALID_ARG, "mask_inpaint_weights: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     F2_REQUIRE(convention == FLUX2MI_MASK_GRAYSCALE_WHITE_INPAINT || (convention == FLUX2MI_MASK_ALPHA_TRANSPARENT_INPAINT && channels == 4),
                FLUX2MI_ERR_INVALID_ARG, "mask_inpaint_weights: the alpha convention needs an RGBA mask");
     double b[4];
@@ -304,6 +306,7 @@ extern "C" int flux2mi_mask_inpaint_weights(flux2mi_ctx* ctx, const uint8_t* mas
 extern "C" int flux2mi_mask_bounding_box(flux2mi_ctx* ctx, const uint8_t* mask, int mask_h, int mask_w, int channels, int convention,
                                          int image_width, int image_height, float threshold, int out_rect[4], int* found) {
     F2_REQUIRE(ctx && mask && out_rect && found && image_width > 0 && image_height > 0, FLUX2MI_ERR_INVALID_ARG, "mask_bounding_box: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     *found = 0;
     // :31-33 — scan at <= 512 on the long side
     const double scale = std::min(1.0, 512.0 / (double)std::max(mask_w, mask_h));
@@ -371,6 +374,7 @@ extern "C" int flux2mi_composite_u8(flux2mi_ctx* ctx, uint8_t* base, int full_h,
     F2_REQUIRE(ctx && base && generated && crop_rect && weights && (base_channels == 3 || base_channels == 4) &&
                    (gen_channels == 3 || gen_channels == 4),
                FLUX2MI_ERR_INVALID_ARG, "composite_u8: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     const int cx = crop_rect[0], cy = crop_rect[1], cw = crop_rect[2], ch = crop_rect[3];
     // :124-126 — the reference returns nil for a crop that leaves the image
     F2_REQUIRE(cw > 0 && ch > 0 && cx >= 0 && cy >= 0 && cx + cw <= full_w && cy + ch <= full_h, FLUX2MI_ERR_SHAPE,
@@ -384,6 +388,7 @@ extern "C" int flux2mi_composite_u8(flux2mi_ctx* ctx, uint8_t* base, int full_h,
 extern "C" int flux2mi_preprocess_image_for_vae(flux2mi_ctx* ctx, const uint8_t* image, int height, int width, int channels, float* out) {
     F2_REQUIRE(ctx && image && out && height > 0 && width > 0 && (channels == 3 || channels == 4), FLUX2MI_ERR_INVALID_ARG,
                "preprocess_image_for_vae: bad argument");
+    F2_WORKSPACE_USE(ctx->device);
     const int64_t hw = (int64_t)height * width;
     hipLaunchKernelGGL(image_to_vae_input_kernel, dim3(grid_for(hw)), dim3(256), 0, ctx->stream, image, hw, channels, out);
     F2_CHECK_HIP(hipGetLastError());
@@ -395,6 +400,7 @@ extern "C" int flux2mi_outpaint_canvas(flux2mi_ctx* ctx, const uint8_t* source, 
     F2_REQUIRE(ctx && source && canvas && src_h > 0 && src_w > 0 && (channels == 3 || channels == 4) && canvas_h > 0 && canvas_w > 0 &&
                    offset_x >= 0 && offset_y >= 0 && offset_x + src_w <= canvas_w && offset_y + src_h <= canvas_h,
                FLUX2MI_ERR_INVALID_ARG, "outpaint_canvas: the source does not fit the canvas at the offset");
+    F2_WORKSPACE_USE(ctx->device);
     const uint64_t s0 = noise_seed + 0x9E3779B97F4A7C15ull;  // :345
     hipLaunchKernelGGL(outpaint_canvas_kernel, dim3(grid_for((int64_t)canvas_h * canvas_w)), dim3(256), 0, ctx->stream, source, src_h, src_w,
                        channels, canvas, canvas_h, canvas_w, offset_x, offset_y, s0);
@@ -407,6 +413,7 @@ extern "C" int flux2mi_outpaint_smart_mask(flux2mi_ctx* ctx, uint8_t* mask, int 
     F2_REQUIRE(ctx && mask && canvas_h > 0 && canvas_w > 0 && keep_x >= 0 && keep_y >= 0 && keep_w > 0 && keep_h > 0 &&
                    keep_x + keep_w <= canvas_w && keep_y + keep_h <= canvas_h,
                FLUX2MI_ERR_INVALID_ARG, "outpaint_smart_mask: the keep rectangle leaves the canvas");
+    F2_WORKSPACE_USE(ctx->device);
     hipLaunchKernelGGL(outpaint_mask_kernel, dim3(grid_for((int64_t)canvas_h * canvas_w)), dim3(256), 0, ctx->stream, mask, canvas_h, canvas_w,
                        keep_x, keep_y, keep_w, keep_h, transition_pixels);
     F2_CHECK_HIP(hipGetLastError());

@@ -43,6 +43,7 @@ int upload_ids(hipStream_t st, DevBuf& buf, const std::vector<int32_t>& host) {
 
 extern "C" int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae* vae, flux2mi_generate_params* p) {
     F2_REQUIRE(ctx && dit && p, FLUX2MI_ERR_INVALID_ARG, "generate: NULL argument");
+    F2_WORKSPACE_USE(ctx->device);
     F2_REQUIRE(p->txt_emb && p->s_txt > 0 && p->noise && p->steps > 0, FLUX2MI_ERR_INVALID_ARG,
                "generate: txt_emb/noise/steps missing");
     F2_REQUIRE(p->skip_decode || vae, FLUX2MI_ERR_NOT_LOADED, "generate: VAE required unless skip_decode");
@@ -52,7 +53,6 @@ extern "C" int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae*
                "generate: strength %.3f < 1 requires init_latents", strength);
     F2_CHECK_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    GenerationInFlight in_flight;   // flux2mi_ctx_trim (MLX.Memory.clearCache) from a callback leaves the workspaces alone
 
     int H = 0, W = 0;
     flux2mi_validate_dimensions(p->height, p->width, &H, &W);  // :1191

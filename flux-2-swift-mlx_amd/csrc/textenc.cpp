@@ -145,6 +145,7 @@ extern "C" int flux2mi_textenc_create(flux2mi_ctx* ctx, const flux2mi_textenc_co
 
 extern "C" int flux2mi_textenc_destroy(flux2mi_textenc* m) {
     if (!m) return FLUX2MI_OK;
+    F2_WORKSPACE_USE(m->ctx->device);   // explicit releases below: not beside a trim
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     for (TBuf& b : m->bufs)
@@ -160,6 +161,7 @@ extern "C" int64_t flux2mi_textenc_param_bytes(const flux2mi_textenc* m) { retur
 extern "C" int flux2mi_textenc_set_tensor(flux2mi_textenc* m, const char* name, int dtype, const int64_t* shape, int ndim,
                                           const void* data) {
     F2_REQUIRE(m && name && shape && data, FLUX2MI_ERR_INVALID_ARG, "textenc_set_tensor: NULL argument");
+    F2_WORKSPACE_USE(m->ctx->device);
     F2_REQUIRE(dtype == FLUX2MI_F32 || dtype == FLUX2MI_BF16 || dtype == FLUX2MI_F16, FLUX2MI_ERR_INVALID_ARG,
                "textenc_set_tensor(%s): unsupported dtype %d", name, dtype);
     auto it = m->slots.find(name);
@@ -204,6 +206,7 @@ extern "C" int flux2mi_textenc_set_tensor(flux2mi_textenc* m, const char* name, 
 
 extern "C" int flux2mi_textenc_finalize(flux2mi_textenc* m) {
     F2_REQUIRE(m, FLUX2MI_ERR_INVALID_ARG, "textenc_finalize: NULL");
+    F2_WORKSPACE_USE(m->ctx->device);
     for (const TBuf& b : m->bufs)
         if (b.got < b.rows) {
             flux2mi_set_error("textenc_finalize: tensor '%s' missing (%d of %d rows loaded)", b.label.c_str(), b.got, b.rows);
@@ -224,6 +227,7 @@ extern "C" int flux2mi_textenc_finalize(flux2mi_textenc* m) {
 
 extern "C" int flux2mi_textenc_forward(flux2mi_textenc* m, const int32_t* ids, int S, int pad_left, int valid_len, void* out) {
     F2_REQUIRE(m && ids && out, FLUX2MI_ERR_INVALID_ARG, "textenc_forward: NULL argument");
+    F2_WORKSPACE_USE(m->ctx->device);
     F2_REQUIRE(m->finalized, FLUX2MI_ERR_NOT_LOADED, "textenc_forward: weights not finalized");
     F2_REQUIRE(S > 0 && pad_left >= 0 && valid_len >= 1 && pad_left + valid_len <= S, FLUX2MI_ERR_SHAPE,
                "textenc_forward: S %d pad_left %d valid_len %d", S, pad_left, valid_len);

@@ -232,6 +232,7 @@ extern "C" int flux2mi_vae_create(flux2mi_ctx* ctx, const flux2mi_vae_config* cf
 
 extern "C" int flux2mi_vae_destroy(flux2mi_vae* v) {
     if (!v) return FLUX2MI_OK;
+    F2_WORKSPACE_USE(v->ctx->device);   // explicit releases below: not beside a trim
     (void)hipSetDevice(v->ctx->device);
     (void)hipStreamSynchronize(v->ctx->stream);
     for (Param& p : v->params)
@@ -247,6 +248,7 @@ extern "C" int flux2mi_vae_destroy(flux2mi_vae* v) {
 extern "C" int flux2mi_vae_set_tensor(flux2mi_vae* v, const char* name, int dtype, const int64_t* shape, int ndim,
                                       const void* data) {
     F2_REQUIRE(v && name && shape && data, FLUX2MI_ERR_INVALID_ARG, "vae_set_tensor: NULL argument");
+    F2_WORKSPACE_USE(v->ctx->device);
     if (strstr(name, "num_batches_tracked")) return FLUX2MI_OK;  // bookkeeping tensor of the checkpoint
     auto it = v->index.find(name);
     if (it == v->index.end()) {
@@ -287,6 +289,7 @@ extern "C" int flux2mi_vae_set_tensor(flux2mi_vae* v, const char* name, int dtyp
 
 extern "C" int flux2mi_vae_finalize(flux2mi_vae* v) {
     F2_REQUIRE(v, FLUX2MI_ERR_INVALID_ARG, "vae_finalize: NULL");
+    F2_WORKSPACE_USE(v->ctx->device);
     for (const Param& p : v->params)
         if (!p.got && !p.encoder) {
             flux2mi_set_error("vae_finalize: tensor '%s' missing", p.name.c_str());
@@ -535,6 +538,7 @@ struct Dec {
 
 extern "C" int flux2mi_vae_decode(flux2mi_vae* v, const float* z, int h, int w, float* out_f32, uint8_t* out_u8) {
     F2_REQUIRE(v && z && h > 0 && w > 0, FLUX2MI_ERR_INVALID_ARG, "vae_decode: bad argument");
+    F2_WORKSPACE_USE(v->ctx->device);
     F2_REQUIRE(v->finalized, FLUX2MI_ERR_NOT_LOADED, "vae_decode: weights not finalized");
     F2_REQUIRE(out_f32 || out_u8, FLUX2MI_ERR_INVALID_ARG, "vae_decode: no output requested");
     F2_CHECK_HIP(hipSetDevice(v->ctx->device));
@@ -618,6 +622,7 @@ extern "C" int flux2mi_vae_has_encoder(const flux2mi_vae* v) {
 
 extern "C" int flux2mi_vae_encode(flux2mi_vae* v, const float* image, int H, int W, float* z_mean) {
     F2_REQUIRE(v && image && z_mean, FLUX2MI_ERR_INVALID_ARG, "vae_encode: NULL argument");
+    F2_WORKSPACE_USE(v->ctx->device);
     F2_REQUIRE(H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0, FLUX2MI_ERR_SHAPE,
                "vae_encode: image %dx%d must be a multiple of 16 (8x VAE stride, 2x2 patchify)", H, W);
     F2_REQUIRE(v->finalized, FLUX2MI_ERR_NOT_LOADED, "vae_encode: weights not finalized");

@@ -71,8 +71,13 @@ int flux2mi_ctx_sync(flux2mi_ctx* ctx);                 /* == MLX eval(): stream
 int flux2mi_ctx_memory_stats(flux2mi_ctx* ctx, size_t* active_bytes, size_t* peak_bytes, size_t* workspace_bytes);
 int flux2mi_ctx_reset_peak(flux2mi_ctx* ctx);
 /* MLX.Memory.clearCache() (Flux2CLI/InpaintCommand.swift:271): synchronises the device and releases every workspace of this GPU;
- * the next forward / decode reserves what it needs again (results unchanged).  Called from a callback of a running
- * flux2mi_generate it releases nothing.  *freed_bytes (may be NULL) = bytes given back. */
+ * the next forward / decode reserves what it needs again (results unchanged).  *freed_bytes (may be NULL) = bytes given back.
+ * Threading: callable from any thread at any time, like MLX's.  Every entry point of this header that reserves or hands out workspace
+ * memory (generate, forwards, decode / encode, text encoders, ingestion / finalize / LoRA merge, imaging and flux2mi_op_* calls,
+ * destroy) registers itself as a user of its GPU's workspaces for the duration of the call: a trim that finds a user on the GPU —
+ * another thread's call, or the generation whose hook called it — or another trim in progress releases nothing and returns OK with
+ * 0 bytes; while a trim releases, calls that want the workspaces wait for it to finish.  (One context is still one call at a time:
+ * the guard protects the workspaces against trims, it does not make a context re-entrant.) */
 int flux2mi_ctx_trim(flux2mi_ctx* ctx, size_t* freed_bytes);
 /* Plain device buffers for a host without a HIP binding of its own (the Swift shim: prompt embeddings, token ids, image bytes).
  * upload: the host bytes may be reused on return; download: behind everything queued on the stream, synchronises. */
@@ -88,6 +93,10 @@ int flux2mi_buffer_download(flux2mi_ctx* ctx, void* dst_host, const void* src_de
  * Both are enqueued on the context's stream, in stream order with flux2mi_generate — nothing to hand over, no host sync.
  * The 128-byte id is made on rank 0 and carried to the other ranks by the host (TCP store, file, environment). */
 #define FLUX2MI_DP_UNIQUE_ID_BYTES 128
+/* RCCL is bound by dlopen at the first flux2mi_dp_* call: $FLUX2MI_RCCL_LIB, else the librccl.so.1 the process has already loaded
+ * (a host running torch.distributed: one RCCL per process), else $ROCM_PATH/lib, /opt/rocm/lib, the loader's search path.
+ * Returns the file that was bound (NULL: none could be; the flux2mi_dp_* calls then return FLUX2MI_ERR_UNSUPPORTED). */
+const char* flux2mi_dp_rccl_library(void);
 int flux2mi_dp_unique_id(uint8_t* id /* [FLUX2MI_DP_UNIQUE_ID_BYTES] */);
 int flux2mi_dp_init(flux2mi_ctx* ctx, int rank, int world, const uint8_t* id);
 int flux2mi_dp_finalize(flux2mi_ctx* ctx);               /* also done by flux2mi_ctx_destroy */

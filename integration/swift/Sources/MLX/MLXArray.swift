@@ -114,7 +114,8 @@ public func eval(_ arrays: MLXArray...) { flux2mi_ctx_sync(MIContext.current) }
 
 /// `MLX.Memory` (mlx-swift 0.31.6 `Memory`; callers: Flux2CLI/InpaintCommand.swift:253-255, 271 and CompareEncoders.swift:112, 142):
 /// the numbers come from the library's own allocation table (flux2mi_ctx_memory_stats) — active = weights, arrays, buffers, KV caches;
-/// cache = the grow-only workspaces kept between calls; peak = the largest active + cache seen.  `clearCache()` = flux2mi_ctx_trim.
+/// cache = the grow-only workspaces kept between calls; peak = the largest active + cache seen.  `clearCache()` = flux2mi_ctx_trim:
+/// callable from any thread like MLX's — it gives nothing back while a library call is using the GPU's workspaces (flux2mi.h).
 public enum Memory {
     static func stats() -> (active: Int, peak: Int, cache: Int) {
         var a = 0, p = 0, c = 0

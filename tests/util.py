@@ -26,16 +26,29 @@ def oracle_cached(name: str, fingerprint_tensors, compute):
     for t in fingerprint_tensors:
         crc = zlib.crc32(t.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes(), crc)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"oracle_cache_{name}.npz")
+    made_by = oracle_version()
+    meta = ("fingerprint", "made_by")
     if os.path.exists(path) and not os.environ.get("FLUX2MI_ORACLE_LIVE"):
         z = np.load(path)
-        if int(z["fingerprint"]) == crc:
-            return {k: torch.from_numpy(z[k]) for k in z.files if k != "fingerprint"}, True
+        # the fixture stands for a run of THIS oracle source under THIS torch: an edited oracle falls back to the live run
+        if int(z["fingerprint"]) == crc and "made_by" in z.files and str(z["made_by"]) == made_by:
+            return {k: torch.from_numpy(z[k]) for k in z.files if k not in meta}, True
     out = compute()
     wdir = os.environ.get("FLUX2MI_WRITE_ORACLE_CACHE")
     if wdir:
         os.makedirs(wdir, exist_ok=True)
-        np.savez_compressed(os.path.join(wdir, f"oracle_cache_{name}.npz"), fingerprint=np.int64(crc), **{k: v.detach().cpu().numpy() for k, v in out.items()})
+        np.savez_compressed(os.path.join(wdir, f"oracle_cache_{name}.npz"), fingerprint=np.int64(crc), made_by=np.str_(made_by),
+                            **{k: v.detach().cpu().numpy() for k, v in out.items()})
     return out, False
+
+
+def oracle_version() -> str:
+    """What an oracle-cache fixture was made by: sha256 of oracle/flux2_ref.py + the torch version that ran it."""
+    import hashlib
+    import os
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "flux2_ref.py")
+    with open(src, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16] + "/torch-" + torch.__version__
 
 
 def tapped_stream(taps: dict, layer: int, n_double: int) -> torch.Tensor:
