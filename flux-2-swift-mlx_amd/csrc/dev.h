@@ -15,8 +15,17 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
     __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN-preserving
     return __builtin_bit_cast(uint16_t, h);
 }
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+// the three-instruction form (convert, convert, shift + or): kept for the e4m3 GEMM's epilogue, whose register allocation has no slack
+// (with the packed form below hipcc spills one VGPR there)
+__device__ __forceinline__ uint32_t pack_bf16x2_3op(float lo, float hi) {
     return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+// one v_cvt_pk_bf16_f32 (the scalar form above, shifted and or-ed, is three instructions per pair: with one wave per SIMD every VALU
+// instruction of an epilogue is four cycles of its own)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(pk_f32x2{lo, hi}, pk_bf16x2));
 }
 __device__ __forceinline__ float lo_bf16(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float hi_bf16(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }

@@ -181,8 +181,11 @@ __device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, I...>)
 
 // CONV: the A source of a K-tile jumps by conv_row_jump at every tap row (GemmProblem::conv_*, kernels.h) and the epilogue is EPI_CONV;
 // a separate instantiation, so that the DiT's kernels stay instruction for instruction what they were.
-template <int NI, bool FP8 = false, bool CONV = false, bool WIDE = false>
+// CFAST: the convolution epilogue's lean form, chosen by the launcher when every problem of the batch qualifies (gemm256s_conv_fast_ok);
+// a compile-time choice, because as a run-time branch next to the generic form hipcc merges the two bodies back into the generic one.
+template <int NI, bool FP8 = false, bool CONV = false, bool WIDE = false, bool CFAST = false>
 __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
+    static_assert(!CFAST || CONV, "the lean epilogue is the convolution's");
     static_assert(!WIDE || (CONV && !FP8 && NI == 8), "the 512 x 128 tile exists for the convolution form only");
     constexpr int PARTA = WIDE ? 4 * PART / 2 : PART;          // bytes of the A rows of a stage (512 or 256 rows x 128 B)
     constexpr int STG = WIDE ? PARTA + PART / 2 : STAGE;       // A rows + W rows (128 or 256 rows)
@@ -481,6 +484,9 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
 #undef GS_DSR
     // MFMA result -> first non-MFMA reader: hipcc pads nothing behind inline asm (guide §5.7 item 2)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#ifdef FLUX2MI_DEV
+    unsigned long long tr_c1 = 0;
+#endif
     if (batch.trace) {
         unsigned long long c1, r1;
         asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
@@ -488,6 +494,9 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
             unsigned long long* o = batch.trace + ((size_t)bid * 4 + wid) * 4;
             o[0] = c1 - tr_c0; o[1] = r1 - tr_r0; o[2] = (unsigned long long)nk; o[3] = 0;
         }
+#ifdef FLUX2MI_DEV
+        tr_c1 = c1;
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);   // the epilogue's address arithmetic stays behind the K loop (hoisted into the last K-tile it costs the
                                          // registers the fp8 operands need: spills)
@@ -513,8 +522,211 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
         if constexpr (FP8) return acc[i][j] * (fs_col[j] * fs_row[i]);
         else return acc[i][j];
     };
+    auto gs_pack = [&](float lo, float hi) GS_INLINE -> uint32_t {
+        if constexpr (FP8) return pack_bf16x2_3op(lo, hi);
+        else return pack_bf16x2(lo, hi);
+    };
     if constexpr (CONV) {
-        // ---- EPI_CONV: GEMM row -> pixel (kernels.h, GemmProblem::conv_*); bias, optional plain-layout residual, bf16 NHWC store.
+#ifdef FLUX2MI_DEV
+        auto conv_trace_end = [&]() GS_INLINE {
+            if (batch.trace) {   // dev diagnostic: the convolution epilogue, loop end -> everything issued -> every store retired (shader cycles)
+                unsigned long long c2, c3;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c2)::"memory");
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c3)::"memory");
+                if (lane == 0) batch.trace[((size_t)bid * 4 + wid) * 4 + 3] = ((c2 - tr_c1) & 0xffffffffull) | ((c3 - c2) << 32);
+            }
+        };
+#else
+        auto conv_trace_end = [&]() GS_INLINE {};
+#endif
+        // ---- EPI_CONV, the lean form (round 5; profiles/r05_*): the production layers' case — whole 16-byte runs (N % 32 == 0, 16-byte
+        // aligned rows) and an image wider than 16 pixels.  The generic form below spent 30-54k cycles per tile here, as long as an 18-K-tile
+        // loop (in-kernel stamps, FLUX2MI_GEMM_TRACE): every problem field re-read from the kernel-argument segment at each use (hipcc
+        // rematerialises such loads: ~100 exposed scalar-load waits per tile), 64-bit address arithmetic and a division per row and half,
+        // the residual in four batches of exposed HBM latency.  Here: every field once into SGPRs (opaque, so they stay there), the rows'
+        // pixel arithmetic once per tile and incrementally (rows of a lane are 16 apart: one division), 32-bit element offsets, and ALL
+        // residual loads of the tile in flight before the first accumulator is touched.  Same arithmetic on the same values in the same
+        // order as the generic form: bit-identical outputs and sums.
+        {
+            unsigned long long qC = reinterpret_cast<unsigned long long>(p.C), qR = reinterpret_cast<unsigned long long>(p.resid);
+            unsigned long long qV = reinterpret_cast<unsigned long long>(p.vec), qG = reinterpret_cast<unsigned long long>(p.gn_part);
+            uint32_t qN = (uint32_t)p.N, qM = (uint32_t)p.M, qldc = (uint32_t)p.ldc, qldr = (uint32_t)p.ldr, qwp = (uint32_t)p.conv_wp;
+            uint32_t qwi = (uint32_t)p.conv_w, qup = (uint32_t)p.conv_up, qopad = (uint32_t)p.conv_out_padded;
+            uint32_t qpy = (uint32_t)p.conv_py, qpx = (uint32_t)p.conv_px;
+            asm volatile("" : "+s"(qC), "+s"(qR), "+s"(qV), "+s"(qG));
+            asm volatile("" : "+s"(qN), "+s"(qM), "+s"(qldc), "+s"(qldr), "+s"(qwp), "+s"(qwi), "+s"(qup), "+s"(qopad), "+s"(qpy), "+s"(qpx));
+            if constexpr (CFAST) {
+                // global-memory pointers (from an integer hipcc would make them generic: flat_load / flat_store)
+                typedef __attribute__((address_space(1))) uint16_t g_u16;
+                typedef __attribute__((address_space(1))) float g_f32;
+                typedef __attribute__((address_space(1))) u32x4 g_u4;
+                typedef __attribute__((address_space(1))) f32x4 g_f4;
+                g_u16* const Cq = (g_u16*)qC;
+                const g_u16* const Rq = (const g_u16*)qR;
+                const g_f32* const Vq = (const g_f32*)qV;
+                const uint32_t wo = qup ? 2u * qwi : qwi;
+                const uint32_t cb = (uint32_t)(n0 + wn * 128);
+                const uint32_t wc = cb + (uint32_t)((fq & 1) * 16 + (fq >> 1) * 8);
+                int rb = row_base;
+                asm volatile("" : "+v"(rb));
+                uint32_t offC[NI], offR[NI];
+                uint32_t ibits = 0u, sbits = 0u;     // per lane: bit i = row i is an interior pixel / is stored
+                {
+                    uint32_t q = (uint32_t)rb + qwp + 1u;
+                    uint32_t yy = q / qwp, xx = q - yy * qwp;          // padded coordinates of row 0; the later rows follow by steps of 16
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const bool live = (uint32_t)rb + 16u * i < qM;
+                        const bool in = live && xx >= 1u && xx <= qwi;
+                        const uint32_t oy = qup ? 2u * (yy - 1u) + qpy : yy - 1u;
+                        const uint32_t ox = in ? (qup ? 2u * (xx - 1u) + qpx : xx - 1u) : 0u;
+                        const uint32_t opl = oy * wo + ox;
+                        const uint32_t oo = qopad ? (in ? (oy + 1u) * (wo + 2u) + (ox + 1u) : q) : opl;
+                        const bool st = in || (live && qopad && !qup);   // a halo column of a padded output is written as zeros
+                        offC[i] = st ? oo * qldc + wc : wc;
+                        offR[i] = in ? opl * qldr + wc : wc;             // rows without a pixel read a valid address and are masked
+                        ibits |= (in ? 1u : 0u) << i;
+                        sbits |= (st ? 1u : 0u) << i;
+                        q += 16u; xx += 16u;
+                        if (xx >= qwp) { xx -= qwp; yy += 1u; }
+                    }
+                }
+                // the residual of a half (2 NI loads of 16 bytes per lane) is in flight before the half's first accumulator is touched; the
+                // second half's loads are issued one by one as the first half's values are consumed: one exposed latency per tile.  (All
+                // 4 NI at once do not fit next to the sums: spills at NI = 8.)
+                // the bias of a half's 64 columns, then the residual; bias and residual are pinned (asm operands) at the top of their half:
+                // hipcc waits for them ONCE there.  Left to its own wait insertion, every use behind a branch got a vmcnt(0) of its own —
+                // which on this hardware also waits for every store issued so far (one in-order counter): the stores of a half went out
+                // one store latency apart.
+                auto bias_load = [&](int h, f32x4 (&b)[4]) GS_INLINE {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t col = cb + (4 * h + j) * 16 + fq * 4;
+                        b[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (Vq != nullptr && col < qN) b[j] = *(const g_f4*)(Vq + col);
+                    }
+                };
+                f32x4 bsv[4];
+                bias_load(0, bsv);
+                u32x4 rv[NI][2];   // ext-vector slots: a slot is written by the load itself
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int jq = 0; jq < 2; ++jq) {
+                        rv[i][jq] = u32x4{0u, 0u, 0u, 0u};
+                        if (Rq && cb + jq * 32u < qN) rv[i][jq] = *(const g_u4*)(Rq + offR[i] + jq * 32u);
+                    }
+                asm volatile("" ::: "memory");   // the loads stay in front of the arithmetic
+                asm volatile("" : "+v"(bsv[0]), "+v"(bsv[1]), "+v"(bsv[2]), "+v"(bsv[3]));
+                const bool want_gn = qG != 0;
+                float* red = reinterpret_cast<float*>(smem);   // gn_part: [quantity][wave][frow][128 + 1] floats
+                constexpr int RW = 129;
+                typedef float gs_f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    gs_f32x2 gs[4][2], gq[4][2];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        gs[j][0] = gs_f32x2{0.f, 0.f}; gs[j][1] = gs_f32x2{0.f, 0.f}; gq[j][0] = gs_f32x2{0.f, 0.f}; gq[j][1] = gs_f32x2{0.f, 0.f};
+                    }
+                    if (h == 1) {
+                        bias_load(1, bsv);
+                        asm volatile("" : "+v"(bsv[0]), "+v"(bsv[1]), "+v"(bsv[2]), "+v"(bsv[3]));   // the second half's residual (issued during the first half): one wait here instead of a vmcnt(0) per use.
+                                    // Unconditional: hipcc's wait insertion does not correlate branches on the same condition, so a pin under
+                                    // `if (resid)` leaves the loads "possibly pending" on the path around it.
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(rv[i][0]), "+v"(rv[i][1]));
+                    }
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const bool in = (ibits >> i) & 1u, st = (sbits >> i) & 1u;
+                        // everything of a row under its lanes' own validity (the exec mask): sums and stores need no per-value masks.  The lane
+                        // exchanges stay inside a GEMM row, whose four lanes share `in`.
+                        if (in) {
+#pragma unroll
+                            for (int jq = 0; jq < 2; ++jq) {
+                                const int jp = 2 * h + jq;
+                                if (cb + jp * 32u >= qN) continue;       // uniform over the wave (N % 32 == 0)
+                                f32x4 vx = acc[i][2 * jp] + bsv[2 * jq], vy = acc[i][2 * jp + 1] + bsv[2 * jq + 1];
+                                if (Rq) {
+                                    uint4 r4 = make_uint4(rv[i][jq][0], rv[i][jq][1], rv[i][jq][2], rv[i][jq][3]);
+                                    asm volatile("" : "+v"(r4.x), "+v"(r4.y), "+v"(r4.z), "+v"(r4.w));   // a copy: the slot itself is re-loaded next
+                                    // the second half's values, into the slot just read
+                                    if (h == 0 && cb + (2 + jq) * 32u < qN) rv[i][jq] = *(const g_u4*)(Rq + offR[i] + (2 + jq) * 32u);
+                                    s_swap16(r4.x, r4.z);
+                                    s_swap16(r4.y, r4.w);
+                                    vx[0] += lo_bf16(r4.x); vx[1] += hi_bf16(r4.x); vx[2] += lo_bf16(r4.y); vx[3] += hi_bf16(r4.y);
+                                    vy[0] += lo_bf16(r4.z); vy[1] += hi_bf16(r4.z); vy[2] += lo_bf16(r4.w); vy[3] += hi_bf16(r4.w);
+                                }
+                                if (want_gn) {
+#pragma unroll
+                                    for (int k = 0; k < 2; ++k) {
+                                        const gs_f32x2 ax = gs_f32x2{vx[2 * k], vx[2 * k + 1]}, ay = gs_f32x2{vy[2 * k], vy[2 * k + 1]};
+                                        gs[2 * jq][k] += ax; gq[2 * jq][k] += ax * ax;
+                                        gs[2 * jq + 1][k] += ay; gq[2 * jq + 1][k] += ay * ay;
+                                    }
+                                }
+                                uint32_t x0 = pack_bf16x2(vx[0], vx[1]), x1 = pack_bf16x2(vx[2], vx[3]);
+                                uint32_t y0 = pack_bf16x2(vy[0], vy[1]), y1 = pack_bf16x2(vy[2], vy[3]);
+                                s_swap16(x0, y0);
+                                s_swap16(x1, y1);
+                                *(g_u4*)(Cq + offC[i] + jp * 32u) = u32x4{x0, x1, y0, y1};
+                            }
+                        } else if (st) {   // a halo column of a padded output: zeros (rare: two pixels of an image row)
+#pragma unroll
+                            for (int jq = 0; jq < 2; ++jq)
+                                if (cb + (2 * h + jq) * 32u < qN) *(g_u4*)(Cq + offC[i] + (2 * h + jq) * 32u) = u32x4{0u, 0u, 0u, 0u};
+                        }
+                    }
+                    if (want_gn) {
+                        // the barrier in front of the first write: LDS holds the last K-tile until every wave has left the K loop
+                        if (h == 0) __syncthreads();
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int cc = (4 * h + jj) * 16 + fq * 4 + r;
+                                red[(wid * 16 + frow) * RW + cc] = gs[jj][r >> 1][r & 1];
+                                red[(64 + wid * 16 + frow) * RW + cc] = gq[jj][r >> 1][r & 1];
+                            }
+                    }
+                }
+                if (want_gn) {
+                    __syncthreads();
+                    constexpr int NWV = WIDE ? 4 : 2;                 // waves that hold a column
+                    const int cidx = WIDE ? (t & 127) : t;            // column of the tile; WIDE: threads 128.. do the squares
+                    const int cc = cidx & 127, w0 = WIDE ? 0 : (cidx >> 7);
+                    const int col = n0 + cidx;
+                    const int quant0 = WIDE ? (t >> 7) : 0;
+                    float va[NWV][16], vb[WIDE ? 1 : NWV][16];
+#pragma unroll
+                    for (int w = 0; w < NWV; ++w) {
+                        const int wv = WIDE ? w : w * 2 + w0;
+#pragma unroll
+                        for (int f = 0; f < 16; ++f) {
+                            va[w][f] = red[(quant0 * 64 + wv * 16 + f) * RW + cc];
+                            if constexpr (!WIDE) vb[w][f] = red[(64 + wv * 16 + f) * RW + cc];
+                        }
+                    }
+                    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NWV; ++w)
+#pragma unroll
+                        for (int f = 0; f < 16; ++f) {
+                            a0 += va[w][f];
+                            if constexpr (!WIDE) a1 += vb[w][f];
+                        }
+                    if ((uint32_t)col < qN) {
+                        g_f32* dst = (g_f32*)qG + ((size_t)tm * qN + col) * 2;
+                        if (WIDE) dst[quant0] = a0;
+                        else { dst[0] = a0; dst[1] = a1; }
+                    }
+                }
+                conv_trace_end();
+                return;
+            }
+        }
+        // ---- EPI_CONV, the generic form (any N % 4 == 0, any alignment, images down to 8 pixels wide): GEMM row -> pixel (kernels.h, GemmProblem::conv_*); bias, optional plain-layout residual, bf16 NHWC store.
         // 16-byte accesses: the 8-byte runs of accumulator blocks 2jp, 2jp + 1 are paired across the fq lanes of a row
         // (v_permlane16_swap: lane fq then owns the 8 consecutive columns starting at (fq & 1) 16 + (fq >> 1) 8 of the 32-column pair);
         // the residual is loaded in that arrangement and swapped back in front of the f32 add.  The exchange stays inside a GEMM row,
@@ -687,6 +899,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                 else { dst[0] = a0; dst[1] = a1; }
             }
         }
+        conv_trace_end();
         return;
     }
     int epi = p.epi;
@@ -749,7 +962,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                     s_swap16(e0, e1);
                     if (row < p.M) *reinterpret_cast<uint2*>(orow + jp * ostep) = make_uint2(e0, e1);
                 } else {
-                    uint32_t a0 = pack_bf16x2(r0, r1), a1 = pack_bf16x2(r2, r3), b0 = pack_bf16x2(t0, t1), b1 = pack_bf16x2(t2, t3);
+                    uint32_t a0 = gs_pack(r0, r1), a1 = gs_pack(r2, r3), b0 = gs_pack(t0, t1), b1 = gs_pack(t2, t3);
                     s_swap16(a0, b0);
                     s_swap16(a1, b1);
                     if (row < p.M) *reinterpret_cast<uint4*>(orow + jp * ostep) = make_uint4(a0, a1, b0, b1);
@@ -842,8 +1055,8 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
 #pragma unroll
                     for (int jp = 0; jp < 2; ++jp) {
                         const f32x4 vx = accv(i, 4 * h + 2 * jp) * p.alpha, vy = accv(i, 4 * h + 2 * jp + 1) * p.alpha;
-                        uint32_t x0 = pack_bf16x2(vx[0], vx[1]), x1 = pack_bf16x2(vx[2], vx[3]);
-                        uint32_t y0 = pack_bf16x2(vy[0], vy[1]), y1 = pack_bf16x2(vy[2], vy[3]);
+                        uint32_t x0 = gs_pack(vx[0], vx[1]), x1 = gs_pack(vx[2], vx[3]);
+                        uint32_t y0 = gs_pack(vy[0], vy[1]), y1 = gs_pack(vy[2], vy[3]);
                         if (p.col_perm16) {
                             s_swap32(x0, y0);
                             s_swap32(x1, y1);
@@ -869,7 +1082,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                         uint16_t* dst = C + (size_t)row * p.ldc + scol;
                         const f32x4 v = accv(i, 4 * h + j) * p.alpha;
                         if (vec_ok && col + 3 < p.N) {
-                            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                            *reinterpret_cast<uint2*>(dst) = make_uint2(gs_pack(v[0], v[1]), gs_pack(v[2], v[3]));
                         } else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
@@ -943,8 +1156,8 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                         ox[r] = silu_f(accv(i, 4 * h + 0)[r]) * accv(i, 4 * h + 2)[r];
                         oy[r] = silu_f(accv(i, 4 * h + 1)[r]) * accv(i, 4 * h + 3)[r];
                     }
-                    uint32_t x0 = pack_bf16x2(ox[0], ox[1]), x1 = pack_bf16x2(ox[2], ox[3]);
-                    uint32_t y0 = pack_bf16x2(oy[0], oy[1]), y1 = pack_bf16x2(oy[2], oy[3]);
+                    uint32_t x0 = gs_pack(ox[0], ox[1]), x1 = gs_pack(ox[2], ox[3]);
+                    uint32_t y0 = gs_pack(oy[0], oy[1]), y1 = gs_pack(oy[2], oy[3]);
                     s_swap16(x0, y0);
                     s_swap16(x1, y1);
                     if (row < p.M) *reinterpret_cast<uint4*>(C + (size_t)row * p.ldc2 + wh) = make_uint4(x0, x1, y0, y1);
@@ -962,7 +1175,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = silu_f(accv(i, 4 * h + j)[r]) * accv(i, 4 * h + j + 2)[r];
                         if (vec_ok && hh + 3 < hidden) {
-                            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                            *reinterpret_cast<uint2*>(dst) = make_uint2(gs_pack(o[0], o[1]), gs_pack(o[2], o[3]));
                         } else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
@@ -998,7 +1211,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                                 v[0] += bf16_bits_to_f32((uint16_t)(rv.x & 0xffff)); v[1] += bf16_bits_to_f32((uint16_t)(rv.x >> 16));
                                 v[2] += bf16_bits_to_f32((uint16_t)(rv.y & 0xffff)); v[3] += bf16_bits_to_f32((uint16_t)(rv.y >> 16));
                             }
-                            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                            *reinterpret_cast<uint2*>(dst) = make_uint2(gs_pack(v[0], v[1]), gs_pack(v[2], v[3]));
                         } else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
@@ -1083,7 +1296,9 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
     static const char* trace_env = F2_DEV_ENV("FLUX2MI_GEMM_TRACE");
     static int seen = 0;
     const size_t tn = (size_t)grid.x * 16;
-    if (trace_env && ++seen % 16 == 0 && hipMalloc((void**)&b.trace, tn * 8) != hipSuccess) b.trace = nullptr;
+    static const char* trace_every = F2_DEV_ENV("FLUX2MI_GEMM_TRACE_EVERY");   // trace every n-th launch (default 16)
+    static const int trace_n = trace_every ? (atoi(trace_every) > 0 ? atoi(trace_every) : 1) : 16;
+    if (trace_env && ++seen % trace_n == 0 && hipMalloc((void**)&b.trace, tn * 8) != hipSuccess) b.trace = nullptr;
     struct TraceOut {
         GemmBatch& b; hipStream_t stream; size_t tn; const GemmProblem* probs; int ni; int nprob;
         ~TraceOut() {
@@ -1092,8 +1307,14 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
             (void)hipStreamSynchronize(stream);
             (void)hipMemcpy(h.data(), b.trace, tn * 8, hipMemcpyDeviceToHost);
             (void)hipFree(b.trace);
-            double cyc = 0, rt = 0, kt = 0;
-            for (size_t w = 0; w < tn / 4; ++w) { cyc += (double)h[w * 4]; rt += (double)h[w * 4 + 1]; kt += (double)h[w * 4 + 2] + 1.5; }   // + prologue ~1.5 K-tiles
+            double cyc = 0, rt = 0, kt = 0, epi_issue = 0, epi_drain = 0;
+            for (size_t w = 0; w < tn / 4; ++w) {
+                cyc += (double)h[w * 4]; rt += (double)h[w * 4 + 1]; kt += (double)h[w * 4 + 2] + 1.5;   // + prologue ~1.5 K-tiles
+                epi_issue += (double)(h[w * 4 + 3] & 0xffffffffull); epi_drain += (double)(h[w * 4 + 3] >> 32);
+            }
+            if (probs[0].epi == EPI_CONV)
+                fprintf(stderr, "[gemm256s trace] conv epilogue: %.0f cycles to issue, %.0f more until its stores have retired (per wave, mean of %zu); prologue + K loop %.0f cycles per tile, %d K-tiles\n",
+                        epi_issue / (tn / 4), epi_drain / (tn / 4), tn / 4, cyc / (tn / 4), probs[0].K / 64);
             // a K-tile is 16 NI MFMAs of 16 cycles (bf16, 64 deep) or 8 NI of 32 (e4m3, 128 deep): 256 NI cycles of MFMA issue either way
             fprintf(stderr, "[gemm256s trace] M %d N %d K %d%s%s, %d-row tiles: %.0f shader cycles per K-tile (%d = MFMA issue alone; prologue counted as 1.5), clock %.0f MHz, %.3f us per K-tile\n",
                     probs[0].M, probs[0].N, probs[0].K, probs[0].fp8 ? " fp8" : "", nprob > 1 ? " (+ a second problem)" : "", 32 * ni, cyc / kt, 256 * ni,
@@ -1108,7 +1329,28 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
                 (q.K / 64 + q.conv_seg - 1) / q.conv_seg > 3)
                 return 1;
         }
-        if (wide) hipLaunchKernelGGL((gemm256s_kernel<8, false, true, true>), grid, block, 0, stream, b);
+        // the lean epilogue: whole 16-byte runs on aligned rows, an image wider than 16 pixels (every production layer)
+        bool fast = true;
+        for (int i = 0; i < nprob; ++i) {
+            const GemmProblem& q = probs[i];
+            fast = fast && (q.N & 31) == 0 && (q.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(q.C) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(q.vec) & 15) == 0 && q.conv_wp > 16 &&
+                   (!q.resid || ((q.ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(q.resid) & 15) == 0));
+        }
+        static const bool fast_on = [] {
+            const char* e = F2_DEV_ENV("FLUX2MI_CONV_FAST");
+            return e ? atoi(e) != 0 : true;
+        }();
+        fast = fast && fast_on;
+        if (fast) {
+            if (wide) hipLaunchKernelGGL((gemm256s_kernel<8, false, true, true, true>), grid, block, 0, stream, b);
+            else switch (ni) {
+                case 7: hipLaunchKernelGGL((gemm256s_kernel<7, false, true, false, true>), grid, block, 0, stream, b); break;
+                case 6: hipLaunchKernelGGL((gemm256s_kernel<6, false, true, false, true>), grid, block, 0, stream, b); break;
+                case 5: hipLaunchKernelGGL((gemm256s_kernel<5, false, true, false, true>), grid, block, 0, stream, b); break;
+                default: hipLaunchKernelGGL((gemm256s_kernel<8, false, true, false, true>), grid, block, 0, stream, b); break;
+            }
+        } else if (wide) hipLaunchKernelGGL((gemm256s_kernel<8, false, true, true>), grid, block, 0, stream, b);
         else switch (ni) {
             case 7: hipLaunchKernelGGL((gemm256s_kernel<7, false, true>), grid, block, 0, stream, b); break;
             case 6: hipLaunchKernelGGL((gemm256s_kernel<6, false, true>), grid, block, 0, stream, b); break;
