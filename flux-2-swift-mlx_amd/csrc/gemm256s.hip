@@ -183,9 +183,12 @@ __device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, I...>)
 // a separate instantiation, so that the DiT's kernels stay instruction for instruction what they were.
 // CFAST: the convolution epilogue's lean form, chosen by the launcher when every problem of the batch qualifies (gemm256s_conv_fast_ok);
 // a compile-time choice, because as a run-time branch next to the generic form hipcc merges the two bodies back into the generic one.
-template <int NI, bool FP8 = false, bool CONV = false, bool WIDE = false, bool CFAST = false>
+// GRT: every problem of the batch is EPI_GATE_RESID on whole, aligned column tiles: the epilogue is the transposed-domain form alone.  Its own
+// instantiation because next to the other epilogues hipcc's register allocation spills accumulators at the loop's exit (measured: 118 spills).
+template <int NI, bool FP8 = false, bool CONV = false, bool WIDE = false, bool CFAST = false, bool GRT = false>
 __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     static_assert(!CFAST || CONV, "the lean epilogue is the convolution's");
+    static_assert(!GRT || !CONV, "the transposed gate-residual epilogue belongs to the plain GEMM");
     static_assert(!WIDE || (CONV && !FP8 && NI == 8), "the 512 x 128 tile exists for the convolution form only");
     constexpr int PARTA = WIDE ? 4 * PART / 2 : PART;          // bytes of the A rows of a stage (512 or 256 rows x 128 B)
     constexpr int STG = WIDE ? PARTA + PART / 2 : STAGE;       // A rows + W rows (128 or 256 rows)
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
         unsigned long long c1, r1;
         asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
         if (lane == 0) {
-            unsigned long long* o = batch.trace + ((size_t)bid * 4 + wid) * 4;
+            unsigned long long* o = batch.trace + ((size_t)bid * 4 + wid) * 8;
             o[0] = c1 - tr_c0; o[1] = r1 - tr_r0; o[2] = (unsigned long long)nk; o[3] = 0;
         }
 #ifdef FLUX2MI_DEV
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                 unsigned long long c2, c3;
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c2)::"memory");
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c3)::"memory");
-                if (lane == 0) batch.trace[((size_t)bid * 4 + wid) * 4 + 3] = ((c2 - tr_c1) & 0xffffffffull) | ((c3 - c2) << 32);
+                if (lane == 0) batch.trace[((size_t)bid * 4 + wid) * 8 + 3] = ((c2 - tr_c1) & 0xffffffffull) | ((c3 - c2) << 32);
             }
         };
 #else
@@ -561,158 +564,182 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                 typedef __attribute__((address_space(1))) float g_f32;
                 typedef __attribute__((address_space(1))) u32x4 g_u4;
                 typedef __attribute__((address_space(1))) f32x4 g_f4;
+                typedef float gs_f32x2 __attribute__((ext_vector_type(2)));
                 g_u16* const Cq = (g_u16*)qC;
                 const g_u16* const Rq = (const g_u16*)qR;
                 const g_f32* const Vq = (const g_f32*)qV;
+                const bool want_gn = qG != 0;
                 const uint32_t wo = qup ? 2u * qwi : qwi;
                 const uint32_t cb = (uint32_t)(n0 + wn * 128);
-                const uint32_t wc = cb + (uint32_t)((fq & 1) * 16 + (fq >> 1) * 8);
-                int rb = row_base;
-                asm volatile("" : "+v"(rb));
-                uint32_t offC[NI], offR[NI];
-                uint32_t ibits = 0u, sbits = 0u;     // per lane: bit i = row i is an interior pixel / is stored
+                // ---- the TRANSPOSED domain.  A lane of the accumulator layout owns ONE row of a 16-row block (row = lane & 15): a 16-byte store
+                // per lane is then 64 separate accesses, which a CU's vector-memory path takes at 16 B/clk whatever the addresses
+                // (tools/store_pattern.hip, profiles/r05_a_store_pattern_probe.txt: 15.98 B/clk per CU for this pattern, 63 for lanes that
+                // cover whole rows; the K loops of the other CUs leave the chip's 7.2 TB/s far from binding).  So every (row block, 64-column
+                // half) goes through a private LDS tile as f32 — 4 ds_write_b128 in the accumulator layout, 4 ds_read_b128 in the
+                // transposed one — and everything behind it (bias, residual, GroupNorm sums, rounding, stores) happens where lane
+                // l owns 8 consecutive columns (l & 7) of rows (l >> 3) and (l >> 3) + 8: a store instruction is 8 whole 128-byte runs.
+                const int tr = lane >> 3, tc = lane & 7;
+                float* const tile = reinterpret_cast<float*>(smem + 36864 + wid * 8704);            // 2 x [16][68] f32, behind the sums' 33 KB
+                constexpr int TP = 68;                                                              // pitch in floats (272 B)
+                float* const wr = tile + frow * TP + fq * 4;                                        // + jj * 16: block jj of the half
+                const float* const rd = tile + tr * TP + tc * 8;                                    // + t * 8 * TP: rows tr, tr + 8
+                // the lane's 2 NI rows (tr + 8 n of the wave's rows): pixel arithmetic once, incrementally (steps of 8 rows: one division)
+                uint32_t offC[2 * NI], offR[2 * NI];
+                uint32_t ibits = 0u, sbits = 0u;     // bit n = row n is an interior pixel / is stored
                 {
-                    uint32_t q = (uint32_t)rb + qwp + 1u;
-                    uint32_t yy = q / qwp, xx = q - yy * qwp;          // padded coordinates of row 0; the later rows follow by steps of 16
+                    uint32_t r0 = (uint32_t)(m0 + wm * WROWS + tr);
+                    asm volatile("" : "+v"(r0));
+                    uint32_t q = r0 + qwp + 1u;
+                    uint32_t yy = q / qwp, xx = q - yy * qwp;          // padded coordinates of the first row
+                    const uint32_t wcol = cb + (uint32_t)tc * 8u;
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) {
-                        const bool live = (uint32_t)rb + 16u * i < qM;
+                    for (int n = 0; n < 2 * NI; ++n) {
+                        const bool live = r0 + 8u * n < qM;
                         const bool in = live && xx >= 1u && xx <= qwi;
                         const uint32_t oy = qup ? 2u * (yy - 1u) + qpy : yy - 1u;
                         const uint32_t ox = in ? (qup ? 2u * (xx - 1u) + qpx : xx - 1u) : 0u;
                         const uint32_t opl = oy * wo + ox;
                         const uint32_t oo = qopad ? (in ? (oy + 1u) * (wo + 2u) + (ox + 1u) : q) : opl;
                         const bool st = in || (live && qopad && !qup);   // a halo column of a padded output is written as zeros
-                        offC[i] = st ? oo * qldc + wc : wc;
-                        offR[i] = in ? opl * qldr + wc : wc;             // rows without a pixel read a valid address and are masked
-                        ibits |= (in ? 1u : 0u) << i;
-                        sbits |= (st ? 1u : 0u) << i;
-                        q += 16u; xx += 16u;
+                        offC[n] = st ? oo * qldc + wcol : wcol;
+                        offR[n] = in ? opl * qldr + wcol : wcol;
+                        ibits |= (in ? 1u : 0u) << n;
+                        sbits |= (st ? 1u : 0u) << n;
+                        q += 8u; xx += 8u;
                         if (xx >= qwp) { xx -= qwp; yy += 1u; }
                     }
                 }
-                // the residual of a half (2 NI loads of 16 bytes per lane) is in flight before the half's first accumulator is touched; the
-                // second half's loads are issued one by one as the first half's values are consumed: one exposed latency per tile.  (All
-                // 4 NI at once do not fit next to the sums: spills at NI = 8.)
-                // the bias of a half's 64 columns, then the residual; bias and residual are pinned (asm operands) at the top of their half:
-                // hipcc waits for them ONCE there.  Left to its own wait insertion, every use behind a branch got a vmcnt(0) of its own —
-                // which on this hardware also waits for every store issued so far (one in-order counter): the stores of a half went out
-                // one store latency apart.
-                auto bias_load = [&](int h, f32x4 (&b)[4]) GS_INLINE {
+                auto bias_load = [&](int h, f32x4 (&b)[2]) GS_INLINE {
+                    const uint32_t col = cb + h * 64 + tc * 8;
+                    b[0] = f32x4{0.f, 0.f, 0.f, 0.f}; b[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (Vq != nullptr && col < qN) { b[0] = *(const g_f4*)(Vq + col); b[1] = *(const g_f4*)(Vq + col + 4); }
+                };
+                // bias and residual of a half are pinned (asm operands) at the top of the half: hipcc waits for them ONCE there.  Left to its
+                // own wait insertion every use behind a branch got a vmcnt(0) of its own, which also waits for every store issued so far (one
+                // in-order counter): the stores went out one store latency apart.  The second half's residual is requested slot by slot as the
+                // first half consumes its values.
+                f32x4 bsv[2];
+                bias_load(0, bsv);
+                u32x4 rv[2 * NI];   // ext-vector slots: a slot is written by the load itself
+                const bool colv0 = cb + tc * 8u < qN, colv1 = cb + 64u + tc * 8u < qN;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t col = cb + (4 * h + j) * 16 + fq * 4;
-                        b[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (Vq != nullptr && col < qN) b[j] = *(const g_f4*)(Vq + col);
+                for (int n = 0; n < 2 * NI; ++n) {
+                    rv[n] = u32x4{0u, 0u, 0u, 0u};
+                    if (Rq && colv0) rv[n] = *(const g_u4*)(Rq + offR[n]);
+                }
+                asm volatile("" ::: "memory");   // the loads stay in front of the arithmetic
+#ifdef FLUX2MI_DEV
+                auto lean_stamp = [&](int k) GS_INLINE {
+                    if (batch.trace) {
+                        unsigned long long c;
+                        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c)::"memory");
+                        if (lane == 0) batch.trace[((size_t)bid * 4 + wid) * 8 + 4 + k] = c - tr_c1;
                     }
                 };
-                f32x4 bsv[4];
-                bias_load(0, bsv);
-                u32x4 rv[NI][2];   // ext-vector slots: a slot is written by the load itself
+#else
+                auto lean_stamp = [&](int) GS_INLINE {};
+#endif
+                lean_stamp(0);
+                __syncthreads();   // LDS holds the last K-tile until every wave has left the K loop
+                asm volatile("" : "+v"(bsv[0]), "+v"(bsv[1]));
 #pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int jq = 0; jq < 2; ++jq) {
-                        rv[i][jq] = u32x4{0u, 0u, 0u, 0u};
-                        if (Rq && cb + jq * 32u < qN) rv[i][jq] = *(const g_u4*)(Rq + offR[i] + jq * 32u);
-                    }
-                asm volatile("" ::: "memory");   // the loads stay in front of the arithmetic
-                asm volatile("" : "+v"(bsv[0]), "+v"(bsv[1]), "+v"(bsv[2]), "+v"(bsv[3]));
-                const bool want_gn = qG != 0;
-                float* red = reinterpret_cast<float*>(smem);   // gn_part: [quantity][wave][frow][128 + 1] floats
+                for (int n = 0; n < 2 * NI; ++n) asm volatile("" : "+v"(rv[n]));
+                lean_stamp(1);
+                float* red = reinterpret_cast<float*>(smem);   // gn_part: [quantity][wave][tr][128 + 1] floats
                 constexpr int RW = 129;
-                typedef float gs_f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    gs_f32x2 gs[4][2], gq[4][2];
+                    gs_f32x2 gs[4], gq[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        gs[j][0] = gs_f32x2{0.f, 0.f}; gs[j][1] = gs_f32x2{0.f, 0.f}; gq[j][0] = gs_f32x2{0.f, 0.f}; gq[j][1] = gs_f32x2{0.f, 0.f};
-                    }
+                    for (int k = 0; k < 4; ++k) { gs[k] = gs_f32x2{0.f, 0.f}; gq[k] = gs_f32x2{0.f, 0.f}; }
+                    const bool colv = h == 0 ? colv0 : colv1;
                     if (h == 1) {
                         bias_load(1, bsv);
-                        asm volatile("" : "+v"(bsv[0]), "+v"(bsv[1]), "+v"(bsv[2]), "+v"(bsv[3]));   // the second half's residual (issued during the first half): one wait here instead of a vmcnt(0) per use.
-                                    // Unconditional: hipcc's wait insertion does not correlate branches on the same condition, so a pin under
-                                    // `if (resid)` leaves the loads "possibly pending" on the path around it.
+                        asm volatile("" : "+v"(bsv[0]), "+v"(bsv[1]));
+                        // unconditional pins: hipcc's wait insertion does not correlate branches on the same condition
 #pragma unroll
-                        for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(rv[i][0]), "+v"(rv[i][1]));
+                        for (int n = 0; n < 2 * NI; ++n) asm volatile("" : "+v"(rv[n]));
+                        lean_stamp(3);
                     }
+                    // software pipeline over the row blocks (two LDS tiles per wave): block i + 2 is written and block i + 1 read back while
+                    // block i is worked on — with one wave per SIMD nothing else hides the LDS round trip (unpipelined: ~1000 cycles per block)
+                    auto tile_w = [&](int i) GS_INLINE {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4*>(wr + (i & 1) * (16 * TP) + jj * 16) = acc[i][4 * h + jj];
+                    };
+                    auto tile_r = [&](int i, f32x4 (&v)[4]) GS_INLINE {
+                        const float* r0 = rd + (i & 1) * (16 * TP);
+                        v[0] = *reinterpret_cast<const f32x4*>(r0); v[1] = *reinterpret_cast<const f32x4*>(r0 + 4);
+                        v[2] = *reinterpret_cast<const f32x4*>(r0 + 8 * TP); v[3] = *reinterpret_cast<const f32x4*>(r0 + 8 * TP + 4);
+                    };
+                    f32x4 cur[4], nxt[4];
+                    tile_w(0);
+                    if (NI > 1) tile_w(1);
+                    tile_r(0, cur);
 #pragma unroll
                     for (int i = 0; i < NI; ++i) {
-                        const bool in = (ibits >> i) & 1u, st = (sbits >> i) & 1u;
-                        // everything of a row under its lanes' own validity (the exec mask): sums and stores need no per-value masks.  The lane
-                        // exchanges stay inside a GEMM row, whose four lanes share `in`.
-                        if (in) {
+                        if (i + 1 < NI) tile_r(i + 1, nxt);
+                        if (i + 2 < NI) tile_w(i + 2);        // behind block i's reads in the LDS queue: its tile is free
 #pragma unroll
-                            for (int jq = 0; jq < 2; ++jq) {
-                                const int jp = 2 * h + jq;
-                                if (cb + jp * 32u >= qN) continue;       // uniform over the wave (N % 32 == 0)
-                                f32x4 vx = acc[i][2 * jp] + bsv[2 * jq], vy = acc[i][2 * jp + 1] + bsv[2 * jq + 1];
+                        for (int tt = 0; tt < 2; ++tt) {
+                            const int n = 2 * i + tt;
+                            const bool in = (ibits >> n) & 1u, st = (sbits >> n) & 1u;
+                            f32x4 va = cur[2 * tt], vb = cur[2 * tt + 1];
+                            if (in && colv) {
+                                va += bsv[0]; vb += bsv[1];
                                 if (Rq) {
-                                    uint4 r4 = make_uint4(rv[i][jq][0], rv[i][jq][1], rv[i][jq][2], rv[i][jq][3]);
-                                    asm volatile("" : "+v"(r4.x), "+v"(r4.y), "+v"(r4.z), "+v"(r4.w));   // a copy: the slot itself is re-loaded next
-                                    // the second half's values, into the slot just read
-                                    if (h == 0 && cb + (2 + jq) * 32u < qN) rv[i][jq] = *(const g_u4*)(Rq + offR[i] + (2 + jq) * 32u);
-                                    s_swap16(r4.x, r4.z);
-                                    s_swap16(r4.y, r4.w);
-                                    vx[0] += lo_bf16(r4.x); vx[1] += hi_bf16(r4.x); vx[2] += lo_bf16(r4.y); vx[3] += hi_bf16(r4.y);
-                                    vy[0] += lo_bf16(r4.z); vy[1] += hi_bf16(r4.z); vy[2] += lo_bf16(r4.w); vy[3] += hi_bf16(r4.w);
+                                    const u32x4 r4 = rv[n];
+                                    va[0] += lo_bf16(r4[0]); va[1] += hi_bf16(r4[0]); va[2] += lo_bf16(r4[1]); va[3] += hi_bf16(r4[1]);
+                                    vb[0] += lo_bf16(r4[2]); vb[1] += hi_bf16(r4[2]); vb[2] += lo_bf16(r4[3]); vb[3] += hi_bf16(r4[3]);
+                                    if (h == 0 && colv1) rv[n] = *(const g_u4*)(Rq + offR[n] + 64u);   // the second half's, into the slot just read
                                 }
                                 if (want_gn) {
-#pragma unroll
-                                    for (int k = 0; k < 2; ++k) {
-                                        const gs_f32x2 ax = gs_f32x2{vx[2 * k], vx[2 * k + 1]}, ay = gs_f32x2{vy[2 * k], vy[2 * k + 1]};
-                                        gs[2 * jq][k] += ax; gq[2 * jq][k] += ax * ax;
-                                        gs[2 * jq + 1][k] += ay; gq[2 * jq + 1][k] += ay * ay;
-                                    }
+                                    const gs_f32x2 a0 = {va[0], va[1]}, a1 = {va[2], va[3]}, b0 = {vb[0], vb[1]}, b1 = {vb[2], vb[3]};
+                                    gs[0] += a0; gq[0] += a0 * a0; gs[1] += a1; gq[1] += a1 * a1;
+                                    gs[2] += b0; gq[2] += b0 * b0; gs[3] += b1; gq[3] += b1 * b1;
                                 }
-                                uint32_t x0 = pack_bf16x2(vx[0], vx[1]), x1 = pack_bf16x2(vx[2], vx[3]);
-                                uint32_t y0 = pack_bf16x2(vy[0], vy[1]), y1 = pack_bf16x2(vy[2], vy[3]);
-                                s_swap16(x0, y0);
-                                s_swap16(x1, y1);
-                                *(g_u4*)(Cq + offC[i] + jp * 32u) = u32x4{x0, x1, y0, y1};
+                                *(g_u4*)(Cq + offC[n] + h * 64u) = u32x4{pack_bf16x2(va[0], va[1]), pack_bf16x2(va[2], va[3]), pack_bf16x2(vb[0], vb[1]), pack_bf16x2(vb[2], vb[3])};
+                            } else if (st && colv) {   // a halo column of a padded output: zeros (rare: two pixels of an image row)
+                                *(g_u4*)(Cq + offC[n] + h * 64u) = u32x4{0u, 0u, 0u, 0u};
                             }
-                        } else if (st) {   // a halo column of a padded output: zeros (rare: two pixels of an image row)
-#pragma unroll
-                            for (int jq = 0; jq < 2; ++jq)
-                                if (cb + (2 * h + jq) * 32u < qN) *(g_u4*)(Cq + offC[i] + (2 * h + jq) * 32u) = u32x4{0u, 0u, 0u, 0u};
                         }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
                     }
+                    if (h == 0) lean_stamp(2);
                     if (want_gn) {
-                        // the barrier in front of the first write: LDS holds the last K-tile until every wave has left the K loop
-                        if (h == 0) __syncthreads();
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int cc = (4 * h + jj) * 16 + fq * 4 + r;
-                                red[(wid * 16 + frow) * RW + cc] = gs[jj][r >> 1][r & 1];
-                                red[(64 + wid * 16 + frow) * RW + cc] = gq[jj][r >> 1][r & 1];
-                            }
+                        for (int k = 0; k < 8; ++k) {
+                            const int cc = h * 64 + tc * 8 + k;
+                            red[(wid * 8 + tr) * RW + cc] = gs[k >> 1][k & 1];
+                            red[(32 + wid * 8 + tr) * RW + cc] = gq[k >> 1][k & 1];
+                        }
                     }
                 }
                 if (want_gn) {
+                    // ---- the tile's per-channel (sum, sum of squares): one thread per column adds the 8 row groups of every wave that holds the
+                    // column, in a fixed order
                     __syncthreads();
                     constexpr int NWV = WIDE ? 4 : 2;                 // waves that hold a column
                     const int cidx = WIDE ? (t & 127) : t;            // column of the tile; WIDE: threads 128.. do the squares
                     const int cc = cidx & 127, w0 = WIDE ? 0 : (cidx >> 7);
                     const int col = n0 + cidx;
                     const int quant0 = WIDE ? (t >> 7) : 0;
-                    float va[NWV][16], vb[WIDE ? 1 : NWV][16];
+                    float va[NWV][8], vb[WIDE ? 1 : NWV][8];
 #pragma unroll
                     for (int w = 0; w < NWV; ++w) {
                         const int wv = WIDE ? w : w * 2 + w0;
 #pragma unroll
-                        for (int f = 0; f < 16; ++f) {
-                            va[w][f] = red[(quant0 * 64 + wv * 16 + f) * RW + cc];
-                            if constexpr (!WIDE) vb[w][f] = red[(64 + wv * 16 + f) * RW + cc];
+                        for (int f = 0; f < 8; ++f) {
+                            va[w][f] = red[(quant0 * 32 + wv * 8 + f) * RW + cc];
+                            if constexpr (!WIDE) vb[w][f] = red[(32 + wv * 8 + f) * RW + cc];
                         }
                     }
                     float a0 = 0.f, a1 = 0.f;
 #pragma unroll
                     for (int w = 0; w < NWV; ++w)
 #pragma unroll
-                        for (int f = 0; f < 16; ++f) {
+                        for (int f = 0; f < 8; ++f) {
                             a0 += va[w][f];
                             if constexpr (!WIDE) a1 += vb[w][f];
                         }
@@ -904,7 +931,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     }
     int epi = p.epi;
     if (epi == EPI_QKV_MLP) epi = (n0 >= p.n_split) ? EPI_SWIGLU : EPI_BF16;
-    if (p.qk_qw != nullptr && epi == EPI_BF16 && n0 < p.qk_cols) {
+    if (!GRT && p.qk_qw != nullptr && epi == EPI_BF16 && n0 < p.qk_cols) {
         // ---- fused QK RMSNorm + RoPE (Flux2Attention.swift:137-157).  A 256-column tile is two heads and a wave holds all
         // 128 columns of one: the sum of squares is the lane's 32 values + the 4 fq lanes of a row (two lane exchanges).
         int fqo = fq;
@@ -977,7 +1004,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     // low changes no e4m3 value above the subnormals — (the lane's 16 products per row block, the wave by lane exchange, the two waves
     // of a row through LDS), exponents, scale bytes; the stores below compute the values and write bytes.
     float bs_mult[NI];
-    const bool q8_out = FP8 && !CONV && epi == EPI_SWIGLU && p.c2_q8 != nullptr;
+    const bool q8_out = !GRT && FP8 && !CONV && epi == EPI_SWIGLU && p.c2_q8 != nullptr;
     if constexpr (FP8 && !CONV) {
         if (q8_out) {
             // |g u| = |acc_g acc_u| x (column scale of g x column scale of u) x (row scale)^2: the column products once per lane
@@ -1014,6 +1041,102 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
             }
         }
     }
+#ifdef FLUX2MI_DEV
+    auto epi_trace_end = [&]() GS_INLINE {
+        if (batch.trace) {   // dev diagnostic: the epilogue, loop end -> everything issued -> every store retired (shader cycles)
+            unsigned long long c2, c3;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c2)::"memory");
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c3)::"memory");
+            if (lane == 0) batch.trace[((size_t)bid * 4 + wid) * 8 + 3] = ((c2 - tr_c1) & 0xffffffffull) | ((c3 - c2) << 32) | (1ull << 63);
+        }
+    };
+#else
+    auto epi_trace_end = [&]() GS_INLINE {};
+#endif
+    // ---- EPI_GATE_RESID, whole column tiles on aligned rows (every production launch): x += gate * y in the TRANSPOSED domain.
+    // A lane of the accumulator layout owns one row of a 16-row block, so its 16-byte read-modify-write is 64 separate accesses per
+    // instruction, which a CU's vector-memory path takes at 16 B/clk whatever the addresses (tools/store_pattern.hip: 15.98 B/clk against
+    // 42-63 for lanes that cover whole rows) — and row by row every access paid its own latency: 70-80k cycles per tile in the first
+    // form, 42 % of a proj launch and 15 % of linear2 (profiles/r05_c_dit_epilogue_trace.txt).  Here every (row block, 64-column half) goes
+    // through a private LDS tile (4 ds_write_b128 in the accumulator layout, 4 ds_read_b128 transposed, software-pipelined over the row
+    // blocks) to lanes that own 4 consecutive columns (lane & 15) of rows (lane >> 4) + 4 t: a load / store instruction is 4 whole
+    // 256-byte runs.  The residual of a batch of row blocks is requested before the batch's first value is used.  Same products and
+    // sums per element as before: bit-identical results.
+    if constexpr (GRT) {
+        {
+            unsigned long long qC = reinterpret_cast<unsigned long long>(p.C), qV = reinterpret_cast<unsigned long long>(p.vec);
+            uint32_t qN = (uint32_t)p.N, qM = (uint32_t)p.M, qldc = (uint32_t)p.ldc;
+            asm volatile("" : "+s"(qC), "+s"(qV), "+s"(qN), "+s"(qM), "+s"(qldc));
+            {
+                typedef __attribute__((address_space(1))) uint8_t g_u8;
+                typedef __attribute__((address_space(1))) float g_f32;
+                typedef __attribute__((address_space(1))) f32x4 g_f4;
+                g_u8* const Cq = (g_u8*)qC;
+                const g_f32* const Vq = (const g_f32*)qV;
+                // every per-lane value of this path from opaque copies made HERE: derived from `lane` / `wid` directly hipcc computes them in
+                // front of the K loop and carries them through it (spills inside the loop: every VGPR there is spoken for)
+                int ln = lane, wd = wid;
+                asm volatile("" : "+v"(ln), "+v"(wd));
+                const int tr = ln >> 4, tc = ln & 15, wm_ = WIDE ? wd : wd >> 1, wn_ = WIDE ? 0 : wd & 1;
+                constexpr int TP = 68;                                                       // tile pitch in floats (272 B)
+                float* const tile = reinterpret_cast<float*>(smem + wd * 8704);             // 2 x [16][68] f32 per wave
+                float* const wr = tile + (ln & 15) * TP + (ln >> 4) * 4;                     // + jj * 16: block jj of the half
+                const float* const rd = tile + tr * TP + tc * 4;                             // + t * 4 * TP: rows tr + 4 t
+                const uint32_t rowt = (uint32_t)(m0 + wm_ * WROWS + tr);
+                const uint32_t lim = rowt < qM ? qM - rowt : 0u;                             // row tr + k of the wave is valid while k < lim
+                const uint32_t ldcB = qldc * 4u;                                             // bytes per row
+                const uint32_t off0 = (rowt * qldc + (uint32_t)(n0 + wn_ * 128 + tc * 4)) * 4u;
+                __syncthreads();   // LDS holds the last K-tile until every wave has left the K loop
+                constexpr int RB = FP8 ? 2 : 4;                                              // row blocks per residual batch (the e4m3 form keeps its scales in registers)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 g4 = *(const g_f4*)(Vq + (n0 + wn_ * 128 + h * 64 + tc * 4));
+                    auto tile_w = [&](int i) GS_INLINE {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4*>(wr + (i & 1) * (16 * TP) + jj * 16) = accv(i, 4 * h + jj);
+                    };
+                    auto tile_r = [&](int i, f32x4 (&v)[4]) GS_INLINE {
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) v[tt] = *reinterpret_cast<const f32x4*>(rd + (i & 1) * (16 * TP) + tt * 4 * TP);
+                    };
+                    f32x4 cur[4], nxt[4];
+                    tile_w(0);
+                    if (NI > 1) tile_w(1);
+                    tile_r(0, cur);
+                    f32x4 rv[RB][4];
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        if (i % RB == 0) {   // the residual of the next RB row blocks: requested together, one wait (unconditional pins: see the convolution's epilogue)
+#pragma unroll
+                            for (int ii = 0; ii < RB; ++ii)
+#pragma unroll
+                                for (int tt = 0; tt < 4; ++tt) {
+                                    const uint32_t k = (uint32_t)((i + ii) * 16 + tt * 4);
+                                    rv[ii][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                    if (i + ii < NI && k < lim) rv[ii][tt] = *(const g_f4*)(Cq + (off0 + k * ldcB + (uint32_t)h * 256u));
+                                }
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (int ii = 0; ii < RB; ++ii) asm volatile("" : "+v"(rv[ii][0]), "+v"(rv[ii][1]), "+v"(rv[ii][2]), "+v"(rv[ii][3]));
+                        }
+                        if (i + 1 < NI) tile_r(i + 1, nxt);
+                        if (i + 2 < NI) tile_w(i + 2);        // behind block i's reads in the LDS queue: its tile is free
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) {
+                            const uint32_t k = (uint32_t)(i * 16 + tt * 4);
+                            const f32x4 v = rv[i % RB][tt] + g4 * cur[tt];
+                            if (k < lim) *(g_f4*)(Cq + (off0 + k * ldcB + (uint32_t)h * 256u)) = v;
+                        }
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) cur[tt] = nxt[tt];
+                    }
+                }
+                epi_trace_end();
+                return;
+            }
+        }
+    }
+    if constexpr (!GRT)
     for_seq([&](auto hc) GS_INLINE {
         constexpr int h = decltype(hc)::value;
         (void)acc; (void)bs_mult;
@@ -1226,6 +1349,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
             }
         }
     }, std::make_integer_sequence<int, 2>{});
+    epi_trace_end();
 }
 
 }  // namespace
@@ -1295,7 +1419,7 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
     const dim3 grid(tiles[0] + tiles[1]), block(256);
     static const char* trace_env = F2_DEV_ENV("FLUX2MI_GEMM_TRACE");
     static int seen = 0;
-    const size_t tn = (size_t)grid.x * 16;
+    const size_t tn = (size_t)grid.x * 32;   // 8 words per wave
     static const char* trace_every = F2_DEV_ENV("FLUX2MI_GEMM_TRACE_EVERY");   // trace every n-th launch (default 16)
     static const int trace_n = trace_every ? (atoi(trace_every) > 0 ? atoi(trace_every) : 1) : 16;
     if (trace_env && ++seen % trace_n == 0 && hipMalloc((void**)&b.trace, tn * 8) != hipSuccess) b.trace = nullptr;
@@ -1308,13 +1432,28 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
             (void)hipMemcpy(h.data(), b.trace, tn * 8, hipMemcpyDeviceToHost);
             (void)hipFree(b.trace);
             double cyc = 0, rt = 0, kt = 0, epi_issue = 0, epi_drain = 0;
-            for (size_t w = 0; w < tn / 4; ++w) {
-                cyc += (double)h[w * 4]; rt += (double)h[w * 4 + 1]; kt += (double)h[w * 4 + 2] + 1.5;   // + prologue ~1.5 K-tiles
-                epi_issue += (double)(h[w * 4 + 3] & 0xffffffffull); epi_drain += (double)(h[w * 4 + 3] >> 32);
+            double st[4] = {0, 0, 0, 0};
+            for (size_t w = 0; w < tn / 8; ++w) {
+                cyc += (double)h[w * 8]; rt += (double)h[w * 8 + 1]; kt += (double)h[w * 8 + 2] + 1.5;   // + prologue ~1.5 K-tiles
+                epi_issue += (double)(h[w * 8 + 3] & 0xffffffffull); epi_drain += (double)(h[w * 8 + 3] >> 32);
+                for (int k = 0; k < 4; ++k) st[k] += (double)h[w * 8 + 4 + k];
             }
-            if (probs[0].epi == EPI_CONV)
+            const double nw = (double)(tn / 8);
+            if (probs[0].epi != EPI_CONV && epi_issue > 0) {
+                double ei = 0, ed = 0, n = 0;
+                for (size_t w = 0; w < tn / 8; ++w)
+                    if (h[w * 8 + 3] >> 63) { ei += (double)(h[w * 8 + 3] & 0xffffffffull); ed += (double)((h[w * 8 + 3] >> 32) & 0x7fffffffull); n += 1; }
+                if (n > 0)
+                    fprintf(stderr, "[gemm256s trace] epilogue (epi %d): %.0f cycles to issue, %.0f more until its stores have retired (mean of %.0f waves that reached the common epilogue); prologue + K loop %.0f cycles per tile, %d K-tiles\n",
+                            probs[0].epi, ei / n, ed / n, n, cyc / nw, probs[0].K / (probs[0].fp8 ? 128 : 64));
+            }
+            if (probs[0].epi == EPI_CONV) {
                 fprintf(stderr, "[gemm256s trace] conv epilogue: %.0f cycles to issue, %.0f more until its stores have retired (per wave, mean of %zu); prologue + K loop %.0f cycles per tile, %d K-tiles\n",
-                        epi_issue / (tn / 4), epi_drain / (tn / 4), tn / 4, cyc / (tn / 4), probs[0].K / 64);
+                        epi_issue / nw, epi_drain / nw, tn / 8, cyc / nw, probs[0].K / 64);
+                if (st[3] > 0)   // the lean epilogue's own stamps (cycles from the loop's end)
+                    fprintf(stderr, "[gemm256s trace]   lean epilogue: loads issued at %.0f, first half starts (bias + residual landed) %.0f, ends %.0f, second half starts %.0f (from the loop's end)\n",
+                            st[0] / nw, st[1] / nw, st[2] / nw, st[3] / nw);
+            }
             // a K-tile is 16 NI MFMAs of 16 cycles (bf16, 64 deep) or 8 NI of 32 (e4m3, 128 deep): 256 NI cycles of MFMA issue either way
             fprintf(stderr, "[gemm256s trace] M %d N %d K %d%s%s, %d-row tiles: %.0f shader cycles per K-tile (%d = MFMA issue alone; prologue counted as 1.5), clock %.0f MHz, %.3f us per K-tile\n",
                     probs[0].M, probs[0].N, probs[0].K, probs[0].fp8 ? " fp8" : "", nprob > 1 ? " (+ a second problem)" : "", 32 * ni, cyc / kt, 256 * ni,
@@ -1356,6 +1495,33 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
             case 6: hipLaunchKernelGGL((gemm256s_kernel<6, false, true>), grid, block, 0, stream, b); break;
             case 5: hipLaunchKernelGGL((gemm256s_kernel<5, false, true>), grid, block, 0, stream, b); break;
             default: hipLaunchKernelGGL((gemm256s_kernel<8, false, true>), grid, block, 0, stream, b); break;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
+    // the transposed gate-residual epilogue: every problem x += gate * y on whole, aligned 256-column tiles (proj, mlp_out, linear2 of every model)
+    bool grt = true;
+    for (int i = 0; i < nprob; ++i) {
+        const GemmProblem& q = probs[i];
+        grt = grt && q.epi == EPI_GATE_RESID && (q.N % TN) == 0 && (q.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(q.C) & 15) == 0 &&
+              q.vec != nullptr && (reinterpret_cast<uintptr_t>(q.vec) & 15) == 0;
+    }
+    static const bool grt_on = [] {
+        const char* e = F2_DEV_ENV("FLUX2MI_GEMM_GRT");
+        return e ? atoi(e) != 0 : true;
+    }();
+    grt = grt && grt_on;
+    if (grt) {
+        if (probs[0].fp8) switch (ni) {
+            case 7: hipLaunchKernelGGL((gemm256s_kernel<7, true, false, false, false, true>), grid, block, 0, stream, b); break;
+            case 6: hipLaunchKernelGGL((gemm256s_kernel<6, true, false, false, false, true>), grid, block, 0, stream, b); break;
+            case 5: hipLaunchKernelGGL((gemm256s_kernel<5, true, false, false, false, true>), grid, block, 0, stream, b); break;
+            default: hipLaunchKernelGGL((gemm256s_kernel<8, true, false, false, false, true>), grid, block, 0, stream, b); break;
+        }
+        else switch (ni) {
+            case 7: hipLaunchKernelGGL((gemm256s_kernel<7, false, false, false, false, true>), grid, block, 0, stream, b); break;
+            case 6: hipLaunchKernelGGL((gemm256s_kernel<6, false, false, false, false, true>), grid, block, 0, stream, b); break;
+            case 5: hipLaunchKernelGGL((gemm256s_kernel<5, false, false, false, false, true>), grid, block, 0, stream, b); break;
+            default: hipLaunchKernelGGL((gemm256s_kernel<8, false, false, false, false, true>), grid, block, 0, stream, b); break;
         }
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }

@@ -87,6 +87,23 @@ int main() {
     hipMalloc((void**)&clk, ncu * 16);
     hipMalloc((void**)&sink, 4);
     printf("%d CUs, one wave per SIMD, each wave its own %zu KB\n", ncu, wave_bytes / 1024);
+    // how much of the figure is the chip's, how much a CU's own: the epilogue's pattern and the best one on fewer CUs
+    for (int n : {8, 64}) {
+        printf("-- %d workgroups\n", n);
+        run<0, false>("mfma", buf, wave_bytes, 256, clk, sink, n);
+        run<1, false>("quad", buf, wave_bytes, 256, clk, sink, n);
+        run<2, false>("line", buf, wave_bytes, 256, clk, sink, n);
+        run<3, false>("row256", buf, wave_bytes, 256, clk, sink, n);
+        run<2, false>("line", buf, wave_bytes, 6144, clk, sink, n);
+        run<3, false>("row256", buf, wave_bytes, 6144, clk, sink, n);
+        run<0, true>("mfma", buf, wave_bytes, 256, clk, sink, n);
+        run<1, true>("quad", buf, wave_bytes, 256, clk, sink, n);
+        run<2, true>("line", buf, wave_bytes, 256, clk, sink, n);
+        run<3, true>("row256", buf, wave_bytes, 256, clk, sink, n);
+        run<2, true>("line", buf, wave_bytes, 6144, clk, sink, n);
+        run<3, true>("row256", buf, wave_bytes, 6144, clk, sink, n);
+    }
+    printf("-- all CUs\n");
     for (int pitch : {256, 512, 6144, 55296}) {
         run<0, false>("mfma", buf, wave_bytes, pitch, clk, sink, ncu);
         run<1, false>("quad", buf, wave_bytes, pitch, clk, sink, ncu);
