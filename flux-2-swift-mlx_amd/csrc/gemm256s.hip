@@ -609,6 +609,14 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                         if (xx >= qwp) { xx -= qwp; yy += 1u; }
                     }
                 }
+                // row blocks whose 16 rows are interior pixels in every lane (all but the blocks that touch a halo column: two pixels of an
+                // image row) take a straight-line form: no exec masks, no branches — with one wave per SIMD every instruction is ~4 cycles
+                uint32_t fullmask = 0u;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const bool both = ((ibits >> (2 * i)) & 3u) == 3u;
+                    fullmask |= (__builtin_amdgcn_ballot_w64(both) == ~0ull ? 1u : 0u) << i;
+                }
                 auto bias_load = [&](int h, f32x4 (&b)[2]) GS_INLINE {
                     const uint32_t col = cb + h * 64 + tc * 8;
                     b[0] = f32x4{0.f, 0.f, 0.f, 0.f}; b[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -622,6 +630,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                 bias_load(0, bsv);
                 u32x4 rv[2 * NI];   // ext-vector slots: a slot is written by the load itself
                 const bool colv0 = cb + tc * 8u < qN, colv1 = cb + 64u + tc * 8u < qN;
+                const bool colv_all = cb + 128u <= qN;   // uniform: the wave's 128 columns all exist
 #pragma unroll
                 for (int n = 0; n < 2 * NI; ++n) {
                     rv[n] = u32x4{0u, 0u, 0u, 0u};
@@ -662,7 +671,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                         lean_stamp(3);
                     }
                     // software pipeline over the row blocks (two LDS tiles per wave): block i + 2 is written and block i + 1 read back while
-                    // block i is worked on — with one wave per SIMD nothing else hides the LDS round trip (unpipelined: ~1000 cycles per block)
+                    // block i is worked on
                     auto tile_w = [&](int i) GS_INLINE {
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4*>(wr + (i & 1) * (16 * TP) + jj * 16) = acc[i][4 * h + jj];
@@ -680,6 +689,25 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                     for (int i = 0; i < NI; ++i) {
                         if (i + 1 < NI) tile_r(i + 1, nxt);
                         if (i + 2 < NI) tile_w(i + 2);        // behind block i's reads in the LDS queue: its tile is free
+                        if (((fullmask >> i) & 1u) && colv_all) {   // uniform: 16 interior rows in every lane, the straight-line form
+#pragma unroll
+                            for (int tt = 0; tt < 2; ++tt) {
+                                const int n = 2 * i + tt;
+                                f32x4 va = cur[2 * tt] + bsv[0], vb = cur[2 * tt + 1] + bsv[1];
+                                if (Rq) {
+                                    const u32x4 r4 = rv[n];
+                                    va[0] += lo_bf16(r4[0]); va[1] += hi_bf16(r4[0]); va[2] += lo_bf16(r4[1]); va[3] += hi_bf16(r4[1]);
+                                    vb[0] += lo_bf16(r4[2]); vb[1] += hi_bf16(r4[2]); vb[2] += lo_bf16(r4[3]); vb[3] += hi_bf16(r4[3]);
+                                    if (h == 0) rv[n] = *(const g_u4*)(Rq + offR[n] + 64u);   // the second half's, into the slot just read
+                                }
+                                if (want_gn) {
+                                    const gs_f32x2 a0 = {va[0], va[1]}, a1 = {va[2], va[3]}, b0 = {vb[0], vb[1]}, b1 = {vb[2], vb[3]};
+                                    gs[0] += a0; gq[0] += a0 * a0; gs[1] += a1; gq[1] += a1 * a1;
+                                    gs[2] += b0; gq[2] += b0 * b0; gs[3] += b1; gq[3] += b1 * b1;
+                                }
+                                *(g_u4*)(Cq + offC[n] + h * 64u) = u32x4{pack_bf16x2(va[0], va[1]), pack_bf16x2(va[2], va[3]), pack_bf16x2(vb[0], vb[1]), pack_bf16x2(vb[2], vb[3])};
+                            }
+                        } else
 #pragma unroll
                         for (int tt = 0; tt < 2; ++tt) {
                             const int n = 2 * i + tt;
@@ -929,6 +957,18 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
         conv_trace_end();
         return;
     }
+#ifdef FLUX2MI_DEV
+    auto epi_trace_end = [&](int tag = 0) GS_INLINE {
+        if (batch.trace) {   // dev diagnostic: the epilogue, loop end -> everything issued -> every store retired (shader cycles)
+            unsigned long long c2, c3;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c2)::"memory");
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c3)::"memory");
+            if (lane == 0) batch.trace[((size_t)bid * 4 + wid) * 8 + 3] = ((c2 - tr_c1) & 0xffffffffull) | (((c3 - c2) & 0xfffffffull) << 32) | ((unsigned long long)tag << 60) | (1ull << 63);
+        }
+    };
+#else
+    auto epi_trace_end = [&](int = 0) GS_INLINE {};
+#endif
     int epi = p.epi;
     if (epi == EPI_QKV_MLP) epi = (n0 >= p.n_split) ? EPI_SWIGLU : EPI_BF16;
     if (!GRT && p.qk_qw != nullptr && epi == EPI_BF16 && n0 < p.qk_cols) {
@@ -955,11 +995,31 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
         uint8_t* const obase = e4 ? p.qk8 + (size_t)p.qk_row0 * p.qk8_ld + wcol : reinterpret_cast<uint8_t*>(p.C) + (size_t)wcol * 2;
         const unsigned ostride = e4 ? (unsigned)p.qk8_ld : (unsigned)p.ldc * 2u, ostep = e4 ? 32u : 64u;
         const float m8 = is_k ? p.qk8_kmul : p.qk8_qmul;
+        // the norm weights of the lane's columns (8 x 8 bytes) and the positions of its rows, ONCE, in front of the rows: read where they are
+        // used (a weight pair per (row, block): 64 loads) every read got a vmcnt(0..2) of its own, which on this hardware also waits for the
+        // stores issued so far (one in-order counter) — the rows went out one store latency apart: 32-33k cycles per tile, a quarter of a
+        // q | k tile (in-kernel stamps, profiles/r05_e_dit_epilogue_trace_rope.txt)
+        const int qM = p.M, qrow0 = p.qk_row0;
+        uint2 uwv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) uwv[j] = *reinterpret_cast<const uint2*>(wv + j * 16);
+        float4 psv[4];   // the positions of four rows at a time (all NI: spills): the second batch's wait drains the first rows' stores, once
+        auto pos_load = [&](int i0) GS_INLINE {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+                if (i0 + ii < NI) psv[ii] = *reinterpret_cast<const float4*>(p.qk_pos + (size_t)(unsigned)(qrow0 + min(rbase + (i0 + ii) * 16, qM - 1)) * 4);
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) asm volatile("" : "+v"(psv[ii].x), "+v"(psv[ii].y), "+v"(psv[ii].z), "+v"(psv[ii].w));
+        };
+        pos_load(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(uwv[j].x), "+v"(uwv[j].y));
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int row = rbase + i * 16;
             uint8_t* const orow = obase + (size_t)((unsigned)row * ostride);
-            const float4 ps = *reinterpret_cast<const float4*>(p.qk_pos + (size_t)(unsigned)(p.qk_row0 + min(row, p.M - 1)) * 4);
+            if (i == 4) pos_load(4);
+            const float4 ps = psv[i & 3];
             float ssq = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -969,7 +1029,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
             ssq += __shfl_xor(ssq, 32);
             const float rinv = rsqrtf(ssq * (1.0f / 128.0f) + 1e-6f);
             auto rotated = [&](int j, float& r0, float& r1, float& r2, float& r3) GS_INLINE {
-                const uint2 uw = *reinterpret_cast<const uint2*>(wv + j * 16);
+                const uint2 uw = uwv[j];
                 const float w0 = lo_bf16(uw.x) * qm, w1 = hi_bf16(uw.x) * qm, w2 = lo_bf16(uw.y) * qm, w3 = hi_bf16(uw.y) * qm;
                 const float pos = (j >> 1) == 0 ? ps.x : (j >> 1) == 1 ? ps.y : (j >> 1) == 2 ? ps.z : ps.w;
                 const float f0 = __builtin_amdgcn_fractf(pos * wrev[j & 1][0]), f1 = __builtin_amdgcn_fractf(pos * wrev[j & 1][1]);
@@ -987,15 +1047,16 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                 if (e4) {   // 8-byte runs after the same lane exchange; the bf16 columns are not needed then
                     uint32_t e0 = pack_fp8x4(r0 * m8, r1 * m8, r2 * m8, r3 * m8), e1 = pack_fp8x4(t0 * m8, t1 * m8, t2 * m8, t3 * m8);
                     s_swap16(e0, e1);
-                    if (row < p.M) *reinterpret_cast<uint2*>(orow + jp * ostep) = make_uint2(e0, e1);
+                    if (row < qM) *reinterpret_cast<uint2*>(orow + jp * ostep) = make_uint2(e0, e1);
                 } else {
                     uint32_t a0 = gs_pack(r0, r1), a1 = gs_pack(r2, r3), b0 = gs_pack(t0, t1), b1 = gs_pack(t2, t3);
                     s_swap16(a0, b0);
                     s_swap16(a1, b1);
-                    if (row < p.M) *reinterpret_cast<uint4*>(orow + jp * ostep) = make_uint4(a0, a1, b0, b1);
+                    if (row < qM) *reinterpret_cast<uint4*>(orow + jp * ostep) = make_uint4(a0, a1, b0, b1);
                 }
             }
         }
+        epi_trace_end(1);   // tag 1: the fused QK norm + RoPE path
         return;
     }
     // ---- SwiGLU hidden as block-scaled e4m3 (GemmProblem::c2_q8): a tile's 128 hidden columns x the 16 rows of an MFMA row block are
@@ -1041,18 +1102,6 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
             }
         }
     }
-#ifdef FLUX2MI_DEV
-    auto epi_trace_end = [&]() GS_INLINE {
-        if (batch.trace) {   // dev diagnostic: the epilogue, loop end -> everything issued -> every store retired (shader cycles)
-            unsigned long long c2, c3;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c2)::"memory");
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c3)::"memory");
-            if (lane == 0) batch.trace[((size_t)bid * 4 + wid) * 8 + 3] = ((c2 - tr_c1) & 0xffffffffull) | ((c3 - c2) << 32) | (1ull << 63);
-        }
-    };
-#else
-    auto epi_trace_end = [&]() GS_INLINE {};
-#endif
     // ---- EPI_GATE_RESID, whole column tiles on aligned rows (every production launch): x += gate * y in the TRANSPOSED domain.
     // A lane of the accumulator layout owns one row of a 16-row block, so its 16-byte read-modify-write is 64 separate accesses per
     // instruction, which a CU's vector-memory path takes at 16 B/clk whatever the addresses (tools/store_pattern.hip: 15.98 B/clk against
@@ -1088,6 +1137,63 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                 const uint32_t off0 = (rowt * qldc + (uint32_t)(n0 + wn_ * 128 + tc * 4)) * 4u;
                 __syncthreads();   // LDS holds the last K-tile until every wave has left the K loop
                 constexpr int RB = FP8 ? 2 : 4;                                              // row blocks per residual batch (the e4m3 form keeps its scales in registers)
+                if constexpr (!FP8)   // (the e4m3 form, whose de-quantisation scales fill the registers, keeps the one-batch-at-a-time form below)
+                if ((uint32_t)(m0 + BMT) <= qM) {
+                    // ---- the tile lies inside M (all but the last row of tiles): no per-row predicates, so hipcc's waits are COUNTED and the
+                    // residual of batch s + 1 is in flight while batch s is worked on (two register sets; batches run through both halves)
+                    constexpr int NB = (NI + RB - 1) / RB, NS = 2 * NB;                        // batches per half, in all
+                    f32x4 rv[2][RB][4];
+                    f32x4 g4[2];
+                    g4[0] = *(const g_f4*)(Vq + (n0 + wn_ * 128 + tc * 4));
+                    g4[1] = *(const g_f4*)(Vq + (n0 + wn_ * 128 + 64 + tc * 4));
+                    auto issue = [&](int sq) GS_INLINE {
+                        const int h = sq / NB, i0 = (sq % NB) * RB;
+#pragma unroll
+                        for (int ii = 0; ii < RB; ++ii)
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt)
+                                if (i0 + ii < NI)
+                                    rv[sq & 1][ii][tt] = *(const g_f4*)(Cq + (off0 + (uint32_t)((i0 + ii) * 16 + tt * 4) * ldcB + (uint32_t)h * 256u));
+                    };
+                    issue(0);
+                    if (NS > 1) issue(1);
+                    f32x4 cur[4], nxt[4];
+#pragma unroll
+                    for (int sq = 0; sq < NS; ++sq) {
+                        const int h = sq / NB, i0 = (sq % NB) * RB;
+                        auto tile_w = [&](int i) GS_INLINE {
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4*>(wr + (i & 1) * (16 * TP) + jj * 16) = accv(i, 4 * h + jj);
+                        };
+                        auto tile_r = [&](int i, f32x4 (&v)[4]) GS_INLINE {
+#pragma unroll
+                            for (int tt = 0; tt < 4; ++tt) v[tt] = *reinterpret_cast<const f32x4*>(rd + (i & 1) * (16 * TP) + tt * 4 * TP);
+                        };
+                        if (i0 == 0) {   // a half starts: its first two row blocks into the LDS tiles
+                            tile_w(0);
+                            if (NI > 1) tile_w(1);
+                            tile_r(0, cur);
+                        }
+#pragma unroll
+                        for (int ii = 0; ii < RB; ++ii) asm volatile("" : "+v"(rv[sq & 1][ii][0]), "+v"(rv[sq & 1][ii][1]), "+v"(rv[sq & 1][ii][2]), "+v"(rv[sq & 1][ii][3]));
+#pragma unroll
+                        for (int ii = 0; ii < RB; ++ii) {
+                            const int i = i0 + ii;
+                            if (i < NI) {
+                                if (i + 1 < NI) tile_r(i + 1, nxt);
+                                if (i + 2 < NI) tile_w(i + 2);        // behind block i's reads in the LDS queue: its tile is free
+#pragma unroll
+                                for (int tt = 0; tt < 4; ++tt)
+                                    *(g_f4*)(Cq + (off0 + (uint32_t)(i * 16 + tt * 4) * ldcB + (uint32_t)h * 256u)) = rv[sq & 1][ii][tt] + g4[h] * cur[tt];
+#pragma unroll
+                                for (int tt = 0; tt < 4; ++tt) cur[tt] = nxt[tt];
+                            }
+                        }
+                        if (sq + 2 < NS) issue(sq + 2);   // into the set just consumed
+                    }
+                    epi_trace_end();
+                    return;
+                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const f32x4 g4 = *(const g_f4*)(Vq + (n0 + wn_ * 128 + h * 64 + tc * 4));
@@ -1170,25 +1276,30 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                 // 16-byte stores: half the store instructions of the 8-byte form below.  col_perm16: the four-column
                 // groups of a 16-group go fq 0,2,1,3, so the 16-byte runs pair fq with fq^2 (lanes l, l^32): after the
                 // exchange lanes fq 0,1 hold block 2jp at (fq&1)*8 and lanes fq 2,3 block 2jp+1
-                const int wcol = p.col_perm16 ? n0 + wnv * 64 + (fq >> 1) * 16 + (fq & 1) * 8
-                                              : n0 + wnv * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
+                // the fields once, as opaque scalars: read at their uses hipcc re-loads them from the kernel-argument segment every time
+                // (it treats such loads as free to rematerialise): 32 exposed scalar-load waits per half in the V^T launches
+                float alpha = p.alpha;
+                int perm = p.col_perm16, qM = p.M, qldc = p.ldc;
+                asm volatile("" : "+s"(alpha), "+s"(perm), "+s"(qM), "+s"(qldc));
+                const int wcol = perm ? n0 + wnv * 64 + (fq >> 1) * 16 + (fq & 1) * 8
+                                      : n0 + wnv * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int row = row_base + i * 16;
 #pragma unroll
                     for (int jp = 0; jp < 2; ++jp) {
-                        const f32x4 vx = accv(i, 4 * h + 2 * jp) * p.alpha, vy = accv(i, 4 * h + 2 * jp + 1) * p.alpha;
+                        const f32x4 vx = accv(i, 4 * h + 2 * jp) * alpha, vy = accv(i, 4 * h + 2 * jp + 1) * alpha;
                         uint32_t x0 = gs_pack(vx[0], vx[1]), x1 = gs_pack(vx[2], vx[3]);
                         uint32_t y0 = gs_pack(vy[0], vy[1]), y1 = gs_pack(vy[2], vy[3]);
-                        if (p.col_perm16) {
+                        if (perm) {
                             s_swap32(x0, y0);
                             s_swap32(x1, y1);
                         } else {
                             s_swap16(x0, y0);
                             s_swap16(x1, y1);
                         }
-                        if (row < p.M)
-                            *reinterpret_cast<uint4*>(C + (size_t)row * p.ldc + wcol + jp * 32) = make_uint4(x0, x1, y0, y1);
+                        if (row < qM)
+                            *reinterpret_cast<uint4*>(C + (size_t)row * qldc + wcol + jp * 32) = make_uint4(x0, x1, y0, y1);
                     }
                 }
             } else
@@ -1440,12 +1551,14 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
             }
             const double nw = (double)(tn / 8);
             if (probs[0].epi != EPI_CONV && epi_issue > 0) {
-                double ei = 0, ed = 0, n = 0;
-                for (size_t w = 0; w < tn / 8; ++w)
-                    if (h[w * 8 + 3] >> 63) { ei += (double)(h[w * 8 + 3] & 0xffffffffull); ed += (double)((h[w * 8 + 3] >> 32) & 0x7fffffffull); n += 1; }
-                if (n > 0)
-                    fprintf(stderr, "[gemm256s trace] epilogue (epi %d): %.0f cycles to issue, %.0f more until its stores have retired (mean of %.0f waves that reached the common epilogue); prologue + K loop %.0f cycles per tile, %d K-tiles\n",
-                            probs[0].epi, ei / n, ed / n, n, cyc / nw, probs[0].K / (probs[0].fp8 ? 128 : 64));
+                for (int tag = 0; tag < 2; ++tag) {
+                    double ei = 0, ed = 0, n = 0;
+                    for (size_t w = 0; w < tn / 8; ++w)
+                        if ((h[w * 8 + 3] >> 63) && (int)((h[w * 8 + 3] >> 60) & 7) == tag) { ei += (double)(h[w * 8 + 3] & 0xffffffffull); ed += (double)((h[w * 8 + 3] >> 32) & 0xfffffffull); n += 1; }
+                    if (n > 0)
+                        fprintf(stderr, "[gemm256s trace] epilogue (epi %d%s): %.0f cycles to issue, %.0f more until its stores have retired (mean of %.0f waves); prologue + K loop %.0f cycles per tile, %d K-tiles\n",
+                                probs[0].epi, tag ? ", the QK norm + RoPE path" : "", ei / n, ed / n, n, cyc / nw, probs[0].K / (probs[0].fp8 ? 128 : 64));
+                }
             }
             if (probs[0].epi == EPI_CONV) {
                 fprintf(stderr, "[gemm256s trace] conv epilogue: %.0f cycles to issue, %.0f more until its stores have retired (per wave, mean of %zu); prologue + K loop %.0f cycles per tile, %d K-tiles\n",
