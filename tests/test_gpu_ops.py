@@ -264,6 +264,8 @@ def test_gemm_race_screen(ctx):
     (4608, 3072, 3072),    # attention projection
     (2304, 3072, 12288),   # 512x512 image
     (4608, 4096, 4096),    # Klein-9B width (tile height 160)
+    (100, 512, 256),       # every tile partial in M: the transposed-domain epilogue's predicated form only
+    (4645, 3072, 3072),    # whole tiles (residual requested a batch ahead) and a last row of tiles with 37 rows
 ])
 def test_gemm_gate_resid_exact(ctx, M, N, K):
     """x += gate * (A W^T) on integer-valued data (every partial sum exact in f32): bit-exact against
