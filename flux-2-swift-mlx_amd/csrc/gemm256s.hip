@@ -1003,7 +1003,6 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
         uint2 uwv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) uwv[j] = *reinterpret_cast<const uint2*>(wv + j * 16);
-        f32x4 wq[8];   // the lane's 32 norm weights x qmul, once (per (row, block) they were 4 unpacks + 4 multiplies: 512 instructions per tile)
         float4 psv[4];   // the positions of four rows at a time (all NI: spills): the second batch's wait drains the first rows' stores, once
         auto pos_load = [&](int i0) GS_INLINE {
 #pragma unroll
@@ -1016,8 +1015,6 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(uwv[j].x), "+v"(uwv[j].y));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wq[j] = f32x4{lo_bf16(uwv[j].x) * qm, hi_bf16(uwv[j].x) * qm, lo_bf16(uwv[j].y) * qm, hi_bf16(uwv[j].y) * qm};
-#pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int row = rbase + i * 16;
             uint8_t* const orow = obase + (size_t)((unsigned)row * ostride);
@@ -1028,35 +1025,19 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
             for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ssq += accv(i, j)[r] * accv(i, j)[r];
-            {   // the four lanes of a row (16 apart) by two lane-row exchanges instead of two ds_bpermute round trips; the same two
-                // additions per lane ((v0 + v1) + (v2 + v3), commuted in half the lanes): bit-identical
-                uint32_t sa = __float_as_uint(ssq), sb = sa;
-                s_swap16(sa, sb);
-                ssq = __uint_as_float(sa) + __uint_as_float(sb);
-                sa = __float_as_uint(ssq); sb = sa;
-                s_swap32(sa, sb);
-                ssq = __uint_as_float(sa) + __uint_as_float(sb);
-            }
+            ssq += __shfl_xor(ssq, 16);
+            ssq += __shfl_xor(ssq, 32);
             const float rinv = rsqrtf(ssq * (1.0f / 128.0f) + 1e-6f);
-            // an axis whose position is 0 in every row of the wave's 16 (image tokens: T and L; text tokens: T, H, W) rotates by the angle 0:
-            // cos 1, sin 0, the rotation the identity — bit for bit (a c - b s with c = 1, s = 0 is a).  Skipped as a whole (uniform
-            // branch): half of the 32 sin / cos of a row and their rotations
-            const bool zax[4] = {__builtin_amdgcn_ballot_w64(ps.x != 0.f) == 0ull, __builtin_amdgcn_ballot_w64(ps.y != 0.f) == 0ull,
-                                 __builtin_amdgcn_ballot_w64(ps.z != 0.f) == 0ull, __builtin_amdgcn_ballot_w64(ps.w != 0.f) == 0ull};
             auto rotated = [&](int j, float& r0, float& r1, float& r2, float& r3) GS_INLINE {
-                const float w0 = wq[j][0], w1 = wq[j][1], w2 = wq[j][2], w3 = wq[j][3];
-                const float a0 = accv(i, j)[0] * rinv * w0, a1 = accv(i, j)[1] * rinv * w1;
-                const float a2 = accv(i, j)[2] * rinv * w2, a3 = accv(i, j)[3] * rinv * w3;
-                if (zax[j >> 1]) { r0 = a0; r1 = a1; r2 = a2; r3 = a3; return; }
+                const uint2 uw = uwv[j];
+                const float w0 = lo_bf16(uw.x) * qm, w1 = hi_bf16(uw.x) * qm, w2 = lo_bf16(uw.y) * qm, w3 = hi_bf16(uw.y) * qm;
                 const float pos = (j >> 1) == 0 ? ps.x : (j >> 1) == 1 ? ps.y : (j >> 1) == 2 ? ps.z : ps.w;
                 const float f0 = __builtin_amdgcn_fractf(pos * wrev[j & 1][0]), f1 = __builtin_amdgcn_fractf(pos * wrev[j & 1][1]);
                 const float c0 = __builtin_amdgcn_cosf(f0), s0 = __builtin_amdgcn_sinf(f0);
                 const float c1 = __builtin_amdgcn_cosf(f1), s1 = __builtin_amdgcn_sinf(f1);
-                // the contraction spelled out (x cos first, then the fused rot(x) sin): left to hipcc, WHICH of the two products of a
-                // component is fused depended on the instruction order around it, and an edit elsewhere in this epilogue moved the forward's
-                // output by 7e-3 (1-ulp f32 differences in front of the bf16 rounding, then the rounding cascade of NOTEBOOK round 4)
-                r0 = __builtin_fmaf(-a1, s0, a0 * c0); r1 = __builtin_fmaf(a0, s0, a1 * c0);
-                r2 = __builtin_fmaf(-a3, s1, a2 * c1); r3 = __builtin_fmaf(a2, s1, a3 * c1);
+                const float a0 = accv(i, j)[0] * rinv * w0, a1 = accv(i, j)[1] * rinv * w1;
+                const float a2 = accv(i, j)[2] * rinv * w2, a3 = accv(i, j)[3] * rinv * w3;
+                r0 = a0 * c0 - a1 * s0, r1 = a1 * c0 + a0 * s0, r2 = a2 * c1 - a3 * s1, r3 = a3 * c1 + a2 * s1;
             };
 #pragma unroll
             for (int jp = 0; jp < 4; ++jp) {
