@@ -399,13 +399,36 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 
 // Statistics from the producing convolution's epilogue (GemmProblem::gn_part): part f32 [rows][C][2].  One workgroup per group;
 // thread t adds rows t, t + 256, ... of the group's channels in f64, the 256 threads are combined in a fixed order.
+// CPG = channels per group when it is one of the decoders' (3, 4, 6, 8, 12, 16), else 0 = the run-time loop.  With CPG known the values of
+// four of the thread's rows are REQUESTED before the first is added (the additions keep their order: identical sums): row by row the
+// kernel was a chain of dependent memory latencies — 6-14 us per launch, 44 us behind an upsampling convolution, 55 launches per decode.
+template <int CPG>
 __global__ __launch_bounds__(256) void gn_finalize_channels_kernel(const float* __restrict__ part, int rows, int64_t pixels, int C, int groups,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                    float* __restrict__ ab) {
     __shared__ double ps[256], pq[256];
     __shared__ float s_mean, s_rstd;
-    const int g = blockIdx.x, cpg = C / groups, t = threadIdx.x;
+    const int g = blockIdx.x, cpg = CPG ? CPG : C / groups, t = threadIdx.x;
     double s = 0.0, q = 0.0;
+    if constexpr (CPG != 0) {
+        constexpr int RU = CPG <= 4 ? 8 : (CPG <= 8 ? 4 : 2);   // rows in flight per thread
+        for (int r0 = t; r0 < rows; r0 += 256 * RU) {
+            float2 v[RU][CPG];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int r = r0 + 256 * u;
+                const float2* pp = reinterpret_cast<const float2*>(part + ((size_t)(r < rows ? r : t) * C + (size_t)g * CPG) * 2);
+#pragma unroll
+                for (int c = 0; c < CPG; ++c) v[u][c] = pp[c];
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u)
+                if (r0 + 256 * u < rows) {
+#pragma unroll
+                    for (int c = 0; c < CPG; ++c) { s += (double)v[u][c].x; q += (double)v[u][c].y; }
+                }
+        }
+    } else
     for (int r = t; r < rows; r += 256) {
         const float2* pp = reinterpret_cast<const float2*>(part + ((size_t)r * C + (size_t)g * cpg) * 2);
         for (int c = 0; c < cpg; ++c) {
@@ -806,7 +829,17 @@ int launch_groupnorm_stats(hipStream_t stream, const uint16_t* x, int64_t pixels
 int launch_groupnorm_finalize_channels(hipStream_t stream, const float* part, int rows, int64_t pixels, int C, int groups,
                                        const float* gamma, const float* beta, float eps, float* ab) {
     if (!part || rows <= 0 || pixels <= 0 || C <= 0 || groups <= 0 || C % groups || C / groups > 256) return 1;
-    hipLaunchKernelGGL(gn_finalize_channels_kernel, dim3(groups), dim3(256), 0, stream, part, rows, pixels, C, groups, gamma, beta, eps, ab);
+#define GNF_GO(CPG_) hipLaunchKernelGGL(gn_finalize_channels_kernel<CPG_>, dim3(groups), dim3(256), 0, stream, part, rows, pixels, C, groups, gamma, beta, eps, ab)
+    switch (C / groups) {
+        case 3: GNF_GO(3); break;
+        case 4: GNF_GO(4); break;
+        case 6: GNF_GO(6); break;
+        case 8: GNF_GO(8); break;
+        case 12: GNF_GO(12); break;
+        case 16: GNF_GO(16); break;
+        default: GNF_GO(0); break;
+    }
+#undef GNF_GO
     VK_DONE();
 }
 int launch_groupnorm_apply(hipStream_t stream, const uint16_t* x, uint16_t* y, int64_t pixels, int C,
