@@ -185,8 +185,11 @@ __device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, I...>)
 // a compile-time choice, because as a run-time branch next to the generic form hipcc merges the two bodies back into the generic one.
 // GRT: every problem of the batch is EPI_GATE_RESID on whole, aligned column tiles: the epilogue is the transposed-domain form alone.  Its own
 // instantiation because next to the other epilogues hipcc's register allocation spills accumulators at the loop's exit (measured: 118 spills).
-template <int NI, bool FP8 = false, bool CONV = false, bool WIDE = false, bool CFAST = false, bool GRT = false>
+// BT: every problem of the batch is a plain EPI_BF16 store (no QK norm + RoPE columns) on whole, aligned column tiles — the V^T launches: the bf16 rows leave
+// through the transposed domain as well (own instantiation for the same reason as GRT).
+template <int NI, bool FP8 = false, bool CONV = false, bool WIDE = false, bool CFAST = false, bool GRT = false, bool BT = false>
 __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
+    static_assert(!BT || (!CONV && !GRT), "the transposed bf16 store belongs to the plain GEMM");
     static_assert(!CFAST || CONV, "the lean epilogue is the convolution's");
     static_assert(!GRT || !CONV, "the transposed gate-residual epilogue belongs to the plain GEMM");
     static_assert(!WIDE || (CONV && !FP8 && NI == 8), "the 512 x 128 tile exists for the convolution form only");
@@ -989,7 +992,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
 #endif
     int epi = p.epi;
     if (epi == EPI_QKV_MLP) epi = (n0 >= p.n_split) ? EPI_SWIGLU : EPI_BF16;
-    if (!GRT && p.qk_qw != nullptr && epi == EPI_BF16 && n0 < p.qk_cols) {
+    if (!GRT && !BT && p.qk_qw != nullptr && epi == EPI_BF16 && n0 < p.qk_cols) {
         // ---- fused QK RMSNorm + RoPE (Flux2Attention.swift:137-157).  A 256-column tile is two heads and a wave holds all
         // 128 columns of one: the sum of squares is the lane's 32 values + the 4 fq lanes of a row (two lane exchanges).
         int fqo = fq;
@@ -1083,7 +1086,7 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     // low changes no e4m3 value above the subnormals — (the lane's 16 products per row block, the wave by lane exchange, the two waves
     // of a row through LDS), exponents, scale bytes; the stores below compute the values and write bytes.
     float bs_mult[NI];
-    const bool q8_out = !GRT && FP8 && !CONV && epi == EPI_SWIGLU && p.c2_q8 != nullptr;
+    const bool q8_out = !GRT && !BT && FP8 && !CONV && epi == EPI_SWIGLU && p.c2_q8 != nullptr;
     if constexpr (FP8 && !CONV) {
         if (q8_out) {
             // |g u| = |acc_g acc_u| x (column scale of g x column scale of u) x (row scale)^2: the column products once per lane
@@ -1260,7 +1263,64 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
             }
         }
     }
-    if constexpr (!GRT)
+    // ---- EPI_BF16 on whole, aligned column tiles (the V^T launches), in the transposed domain: C bf16 = alpha * acc, optionally key-permuted
+    // inside every 16-column group (col_perm16: applied to the LDS column of the accumulator-layout write).  Lane l owns 8 consecutive
+    // columns (l & 7) of rows (l >> 3) and (l >> 3) + 8 of a 16-row block: a store instruction is 8 whole 128-byte runs.
+    if constexpr (BT) {
+        unsigned long long qC = reinterpret_cast<unsigned long long>(p.C);
+        uint32_t qM = (uint32_t)p.M, qldc = (uint32_t)p.ldc, qperm = (uint32_t)p.col_perm16;
+        float alpha = p.alpha;
+        asm volatile("" : "+s"(qC), "+s"(qM), "+s"(qldc), "+s"(qperm), "+s"(alpha));
+        typedef __attribute__((address_space(1))) uint8_t g_u8;
+        typedef __attribute__((address_space(1))) u32x4 g_u4;
+        g_u8* const Cq = (g_u8*)qC;
+        int ln = lane, wd = wid;
+        asm volatile("" : "+v"(ln), "+v"(wd));   // per-lane values of this path from opaque copies made HERE (see the gate-residual form)
+        const int tr = ln >> 3, tc = ln & 7, wm_ = wd >> 1, wn_ = wd & 1, fq_ = ln >> 4;
+        constexpr int TP = 68;                                                       // tile pitch in floats (272 B)
+        float* const tile = reinterpret_cast<float*>(smem + wd * 8704);             // 2 x [16][68] f32 per wave
+        float* const wr = tile + (ln & 15) * TP + (qperm ? (fq_ & 1) * 8 + (fq_ >> 1) * 4 : fq_ * 4);   // + jj * 16: block jj of the half
+        const float* const rd = tile + tr * TP + tc * 8;                             // + tt * 8 * TP: rows tr, tr + 8
+        const uint32_t rowt = (uint32_t)(m0 + wm_ * WROWS + tr);
+        const uint32_t lim = rowt < qM ? qM - rowt : 0u;                             // row tr + k of the wave is valid while k < lim
+        const uint32_t ldcB = qldc * 2u;                                             // bytes per row
+        const uint32_t off0 = (rowt * qldc + (uint32_t)(n0 + wn_ * 128 + tc * 8)) * 2u;
+        __syncthreads();   // LDS holds the last K-tile until every wave has left the K loop
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            auto tile_w = [&](int i) GS_INLINE {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4*>(wr + (i & 1) * (16 * TP) + jj * 16) = accv(i, 4 * h + jj);
+            };
+            auto tile_r = [&](int i, f32x4 (&v)[4]) GS_INLINE {
+                const float* r0 = rd + (i & 1) * (16 * TP);
+                v[0] = *reinterpret_cast<const f32x4*>(r0); v[1] = *reinterpret_cast<const f32x4*>(r0 + 4);
+                v[2] = *reinterpret_cast<const f32x4*>(r0 + 8 * TP); v[3] = *reinterpret_cast<const f32x4*>(r0 + 8 * TP + 4);
+            };
+            f32x4 cur[4], nxt[4];
+            tile_w(0);
+            if (NI > 1) tile_w(1);
+            tile_r(0, cur);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                if (i + 1 < NI) tile_r(i + 1, nxt);
+                if (i + 2 < NI) tile_w(i + 2);        // behind block i's reads in the LDS queue: its tile is free
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const uint32_t k = (uint32_t)(i * 16 + tt * 8);
+                    const f32x4 va = cur[2 * tt] * alpha, vb = cur[2 * tt + 1] * alpha;
+                    if (k < lim)
+                        *(g_u4*)(Cq + (off0 + k * ldcB + (uint32_t)h * 128u)) =
+                            u32x4{pack_bf16x2(va[0], va[1]), pack_bf16x2(va[2], va[3]), pack_bf16x2(vb[0], vb[1]), pack_bf16x2(vb[2], vb[3])};
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+            }
+        }
+        epi_trace_end();
+        return;
+    }
+    if constexpr (!GRT && !BT)
     for_seq([&](auto hc) GS_INLINE {
         constexpr int h = decltype(hc)::value;
         (void)acc; (void)bs_mult;
@@ -1645,6 +1705,33 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
         return e ? atoi(e) != 0 : true;
     }();
     grt = grt && grt_on;
+    // the transposed bf16 store: every problem a plain EPI_BF16 (no QK norm + RoPE columns, no e4m3 copy) on whole, aligned 256-column tiles (V^T)
+    bool bt = !grt;
+    for (int i = 0; i < nprob; ++i) {
+        const GemmProblem& q = probs[i];
+        bt = bt && q.epi == EPI_BF16 && q.qk_qw == nullptr && q.qk8 == nullptr && (q.N % TN) == 0 && (q.ldc & 7) == 0 &&
+             (reinterpret_cast<uintptr_t>(q.C) & 15) == 0 && (size_t)q.M * (size_t)q.ldc * 2 < (1ull << 32);
+    }
+    static const bool bt_on = [] {
+        const char* e = F2_DEV_ENV("FLUX2MI_GEMM_BT");
+        return e ? atoi(e) != 0 : true;
+    }();
+    bt = bt && bt_on;
+    if (bt) {
+        if (probs[0].fp8) switch (ni) {
+            case 7: hipLaunchKernelGGL((gemm256s_kernel<7, true, false, false, false, false, true>), grid, block, 0, stream, b); break;
+            case 6: hipLaunchKernelGGL((gemm256s_kernel<6, true, false, false, false, false, true>), grid, block, 0, stream, b); break;
+            case 5: hipLaunchKernelGGL((gemm256s_kernel<5, true, false, false, false, false, true>), grid, block, 0, stream, b); break;
+            default: hipLaunchKernelGGL((gemm256s_kernel<8, true, false, false, false, false, true>), grid, block, 0, stream, b); break;
+        }
+        else switch (ni) {
+            case 7: hipLaunchKernelGGL((gemm256s_kernel<7, false, false, false, false, false, true>), grid, block, 0, stream, b); break;
+            case 6: hipLaunchKernelGGL((gemm256s_kernel<6, false, false, false, false, false, true>), grid, block, 0, stream, b); break;
+            case 5: hipLaunchKernelGGL((gemm256s_kernel<5, false, false, false, false, false, true>), grid, block, 0, stream, b); break;
+            default: hipLaunchKernelGGL((gemm256s_kernel<8, false, false, false, false, false, true>), grid, block, 0, stream, b); break;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
     if (grt) {
         if (probs[0].fp8) switch (ni) {
             case 7: hipLaunchKernelGGL((gemm256s_kernel<7, true, false, false, false, true>), grid, block, 0, stream, b); break;

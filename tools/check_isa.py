@@ -102,16 +102,17 @@ def main():
     text = compile_s("gemm256s")
     check_m0("gemm256s", text, errors)
     for kname, body in kernels(text):
-        m = re.search(r"gemm256s_kernelILi(\d)ELb(\d)E(?:Lb(\d)E)?(?:Lb(\d)E)?(?:Lb(\d)E)?(?:Lb(\d)E)?", kname)
+        m = re.search(r"gemm256s_kernelILi(\d)ELb(\d)E(?:Lb(\d)E)?(?:Lb(\d)E)?(?:Lb(\d)E)?(?:Lb(\d)E)?(?:Lb(\d)E)?", kname)
         if not m:
             continue
         ni, fp8 = int(m.group(1)), int(m.group(2))
         conv, wide = int(m.group(3) or 0), int(m.group(4) or 0)   # the convolution form; its 512 x 128 tile (16 A + 4 W pieces per wave)
         lean = int(m.group(5) or 0)                               # the convolution's lean epilogue (same K loop)
         grt = int(m.group(6) or 0)                                # the transposed-domain gate-residual epilogue alone (same K loop)
+        bt = int(m.group(7) or 0)                                 # the transposed-domain bf16 store alone (same K loop)
         scratch = meta(text, kname, "private_segment_fixed_size")
         spills = meta(text, kname, "vgpr_spill_count")
-        print(f"gemm256s_kernel<{ni}, {'fp8' if fp8 else 'bf16'}{', conv' if conv else ''}{', 512x128' if wide else ''}{', lean epilogue' if lean else ''}{', gate-residual epilogue' if grt else ''}>: scratch {scratch} B, spills {spills}")
+        print(f"gemm256s_kernel<{ni}, {'fp8' if fp8 else 'bf16'}{', conv' if conv else ''}{', 512x128' if wide else ''}{', lean epilogue' if lean else ''}{', gate-residual epilogue' if grt else ''}{', transposed bf16 store' if bt else ''}>: scratch {scratch} B, spills {spills}")
         if scratch:
             errors.append((kname, "scratch", scratch))
         for label, ins in blocks(body):
