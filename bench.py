@@ -260,6 +260,9 @@ def main():
 
     par.barrier()
     sampler = None
+    if world > 1:
+        par.collective_stats(reset=True)       # the warm-up's exchanges (RCCL's lazy channel set-up among them) are not the timed ones
+        par.collective_timing(True)            # HIP events on the library's stream around both exchanges (gloo dry run: wall clock)
     if not dry:
         torch.cuda.synchronize()
         pipe.ctx.prof_begin(args.prof_class)
@@ -280,6 +283,19 @@ def main():
     card = sampler.finish() if sampler is not None else None
     n_launch, prof_ms, prof_flops = (0, 0.0, 0.0) if dry else pipe.ctx.prof_end()
     elapsed = par.all_reduce_max(elapsed, dev)
+    # per-exchange time on this rank's generating stream, max over ranks (a rank that arrives early waits inside the exchange)
+    collective_ms = None
+    if world > 1:
+        st = par.collective_stats(reset=True)
+        par.collective_timing(False)
+        collective_ms = {}
+        for name in ("broadcast", "all_gather"):
+            per_batch = st[name]["ms"] / max(st[name]["calls"], 1)
+            collective_ms[name] = round(par.all_reduce_max(per_batch, dev), 4)
+            collective_ms[name + "_bytes"] = st[name]["bytes"] // max(st[name]["calls"], 1)
+        collective_ms["measured"] = ("wall clock around the gloo collectives (dry run)" if dry else
+                                     "HIP events on the context's stream around every exchange of the timed region") + \
+                                    "; ms per batch, max over ranks (includes waiting for the slowest peer)"
 
     # ---- outside the timed region: the output is a real result (finite latents on every rank, a checksum of the batch)
     ok = 1.0
@@ -381,6 +397,17 @@ def main():
         cpu_baseline = run_cpu_baseline(P, cfg, syn, H, W, T, s_txt) if P is not None else \
             {"skipped": f"the oracle leg is timed for Klein-4B only ({args.model}: one fp32 CPU forward is minutes and the tensors do not fit the host)"}
 
+    # ---- analytic scaling model (SURVEY §8e "Measurability"): 1 -> 8 GPUs from ONE image's time + the two exchanges + the batch D2H.
+    # At N = 1 the base is the measured seconds/image; at N > 1 this run's own time minus its measured exchanges (what one replica
+    # takes for its image), so that a measured curve and the model can be held against each other.  Dry run: a nominal 1 s base.
+    base = 1.0 if dry else sec_per_image
+    if world > 1 and collective_ms is not None and not dry:
+        base = max(1e-6, sec_per_image - 1e-3 * (collective_ms["broadcast"] + collective_ms["all_gather"])
+                   - (world - 1) * H * W * 3 / (par.PCIE_D2H_GBS * 1e9))
+    scaling = par.scaling_model(base, T_eff, s_txt, J, H, W)
+    scaling["base_from"] = ("nominal 1 s (dry run)" if dry else "measured seconds_per_image of this 1-GPU run" if world == 1 else
+                            f"this {world}-GPU run's seconds_per_image minus its measured exchanges and the modelled extra D2H")
+
     out = {
         "metric": f"denoise-steps/sec (Flux.2 {args.model} {H}x{W} @ {T} steps; seconds/image reported alongside)"
                   + (" — DRY RUN: launcher/collectives self-test, no compute" if dry else ""),
@@ -419,6 +446,8 @@ def main():
         "output_check": {"latents_finite": True, "image_crc32": checksum, "u8_histogram": hist,
                          "weights": "synthetic.LazyDitWeights(seed 1234) + make_vae_weights(seed 4321)"},
         "model_load_s": round(t_load, 2),
+        "collective_ms": collective_ms,
+        "scaling_model": scaling,
         "roofline": roofline,
         "roofline_secondary": roofline_secondary,
         "roofline_hbm": roofline_hbm,

@@ -96,6 +96,8 @@ PROTOTYPES = {
     "flux2mi_dp_broadcast_embeddings": (_I, [_P, _P, C.c_int64, _I]),
     "flux2mi_dp_all_gather_images": (_I, [_P, _P, _P, C.c_int64]),
     "flux2mi_dp_all_reduce_max": (_I, [_P, C.POINTER(C.c_double)]),
+    "flux2mi_dp_collective_timing": (_I, [_P, _I]),
+    "flux2mi_dp_collective_stats": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I]),
     "flux2mi_array_to_bf16": (_I, [_P, _P, _P]),
     "flux2mi_dit_load_lora_safetensors": (_I, [_P, C.c_char_p, C.c_float, C.POINTER(_I), C.POINTER(_I)]),
     "flux2mi_ctx_stream": (_P, [_P]),

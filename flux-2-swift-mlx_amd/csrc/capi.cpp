@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <unordered_map>
@@ -90,32 +91,47 @@ WorkspaceUse::~WorkspaceUse() {
 
 DevBuf::DevBuf() { std::lock_guard<std::mutex> g(mem().mu); mem().bufs.insert(this); }
 DevBuf::~DevBuf() {
-    {   // leave the table first (a trim collects its victims from it), and never under a trim that may hold this buffer as a victim
+    {   // leave the table first (a trim collects its victims from it), and not under a trim that may hold this buffer as a victim.
+        // The wait is bounded: a trim sits in hipDeviceSynchronize() meanwhile, and a wedged device must not turn teardown (static
+        // objects at process exit included) into a hang — after the bound the buffer leaves the table anyway (the trim re-checks
+        // membership under the lock before it touches a victim, so this is safe) and the HIP error surfaces from the trim's caller.
         MemTable& t = mem();
         std::unique_lock<std::mutex> g(t.mu);
-        t.cv.wait(g, [&] { return device < 0 || !t.trimming[dev_slot(device)]; });
+        if (!t.cv.wait_for(g, std::chrono::seconds(30), [&] { return device < 0 || !t.trimming[dev_slot(device)]; }))
+            fprintf(stderr, "[flux2mi] a workspace trim on device %d has not finished within 30 s (device wedged?): releasing a buffer beside it\n", device);
         t.bufs.erase(this);
     }
     release();
 }
+// ptr / bytes / device are published under the table's mutex: flux2mi_ctx_trim reads them for EVERY registered buffer (other devices'
+// included) while other threads reserve on their own devices
 int DevBuf::reserve(size_t n) {
     if (n <= bytes) return FLUX2MI_OK;
     release();
     const size_t rounded = (n + 255) & ~(size_t)255;
-    hipError_t e = f2_malloc(&ptr, rounded, !keep);
+    void* p = nullptr;
+    hipError_t e = f2_malloc(&p, rounded, !keep);
     if (e != hipSuccess) {
-        ptr = nullptr;
         flux2mi_set_error("hipMalloc(%zu bytes) failed: %s", rounded, hipGetErrorString(e));
         return FLUX2MI_ERR_OOM;
     }
-    (void)hipGetDevice(&device);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mem().mu);
+    ptr = p;
+    device = dev;
     bytes = rounded;
     return FLUX2MI_OK;
 }
 void DevBuf::release() {
-    if (ptr) f2_free(ptr);
-    ptr = nullptr;
-    bytes = 0;
+    void* p = nullptr;
+    {
+        std::lock_guard<std::mutex> g(mem().mu);
+        p = ptr;
+        ptr = nullptr;
+        bytes = 0;
+    }
+    if (p) f2_free(p);
 }
 
 extern "C" int flux2mi_ctx_memory_stats(flux2mi_ctx* ctx, size_t* active_bytes, size_t* peak_bytes, size_t* workspace_bytes) {
@@ -155,15 +171,20 @@ extern "C" int flux2mi_ctx_trim(flux2mi_ctx* ctx, size_t* freed_bytes) {
     }
     const hipError_t se = hipDeviceSynchronize();   // work queued on any context of this device may still use them
     size_t freed = 0;
-    if (se == hipSuccess)
-        for (DevBuf* b : victims) {
-            freed += b->bytes;
-            b->release();
-        }
+    std::vector<void*> stolen;
     {
         std::lock_guard<std::mutex> g(t.mu);
+        if (se == hipSuccess)
+            for (DevBuf* b : victims) {
+                if (!t.bufs.count(b) || !b->ptr) continue;   // destroyed beside a slow trim (its destructor's bounded wait ran out)
+                freed += b->bytes;
+                stolen.push_back(b->ptr);
+                b->ptr = nullptr;
+                b->bytes = 0;
+            }
         t.trimming[d] = false;
     }
+    for (void* p : stolen) f2_free(p);
     t.cv.notify_all();
     F2_CHECK_HIP(se);
     if (freed_bytes) *freed_bytes = freed;

@@ -79,7 +79,54 @@ int rccl_require() {
 struct flux2mi_dp {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    // flux2mi_dp_collective_timing: HIP event pairs on the context's stream around each exchange, by kind (0 broadcast, 1 all-gather)
+    bool timing = false;
+    struct Pair { hipEvent_t a, b; int kind; };
+    std::vector<Pair> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[2] = {0.0, 0.0};
+    long long calls[2] = {0, 0};
+    long long bytes[2] = {0, 0};
 };
+
+namespace {
+hipEvent_t dp_event(flux2mi_dp* d) {
+    if (!d->pool.empty()) { hipEvent_t e = d->pool.back(); d->pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
+// folds the finished pairs into the sums (synchronises the stream when there are any)
+void dp_fold(flux2mi_ctx* ctx) {
+    flux2mi_dp* d = ctx->dp;
+    if (!d || d->pending.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (const flux2mi_dp::Pair& p : d->pending) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) d->ms[p.kind] += (double)t;
+        d->pool.push_back(p.a);
+        d->pool.push_back(p.b);
+    }
+    d->pending.clear();
+}
+struct DpTimed {   // start event at construction, stop event at destruction, both on the context's stream
+    flux2mi_ctx* ctx; int kind; hipEvent_t a = nullptr, b = nullptr;
+    DpTimed(flux2mi_ctx* c, int k, long long nbytes) : ctx(c), kind(k) {
+        flux2mi_dp* d = c->dp;
+        d->calls[k] += 1;
+        d->bytes[k] += nbytes;
+        if (!d->timing) return;
+        if (d->pending.size() >= 1024) dp_fold(c);
+        a = dp_event(d);
+        b = dp_event(d);
+        if (a && b) (void)hipEventRecord(a, c->stream);
+    }
+    ~DpTimed() {
+        if (!a || !b) return;
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->dp->pending.push_back({a, b, kind});
+    }
+};
+}  // namespace
 
 static_assert(NCCL_UNIQUE_ID_BYTES == FLUX2MI_DP_UNIQUE_ID_BYTES, "unique id size");
 
@@ -131,6 +178,8 @@ extern "C" int flux2mi_dp_finalize(flux2mi_ctx* ctx) {
     if (!ctx->dp) return FLUX2MI_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    dp_fold(ctx);
+    for (hipEvent_t e : ctx->dp->pool) (void)hipEventDestroy(e);
     ncclResult_t r = g_rccl.CommDestroy(ctx->dp->comm);
     delete ctx->dp;
     ctx->dp = nullptr;
@@ -150,6 +199,7 @@ extern "C" int flux2mi_dp_broadcast_embeddings(flux2mi_ctx* ctx, void* embedding
     F2_REQUIRE(ctx->dp, FLUX2MI_ERR_NOT_LOADED, "dp_broadcast_embeddings: flux2mi_dp_init has not been called on this context");
     F2_REQUIRE(root >= 0 && root < ctx->dp->world, FLUX2MI_ERR_INVALID_ARG, "dp_broadcast_embeddings: root %d of %d", root, ctx->dp->world);
     F2_CHECK_HIP(hipSetDevice(ctx->device));
+    DpTimed timed(ctx, 0, (long long)elems * 2);
     F2_CHECK_NCCL(g_rccl.Broadcast(embeddings, embeddings, (size_t)elems, ncclBfloat16, root, ctx->dp->comm, ctx->stream));
     return FLUX2MI_OK;
 }
@@ -160,7 +210,33 @@ extern "C" int flux2mi_dp_all_gather_images(flux2mi_ctx* ctx, const uint8_t* loc
     F2_REQUIRE(ctx && local_images && all_images && bytes_per_rank > 0, FLUX2MI_ERR_INVALID_ARG, "dp_all_gather_images: bad argument");
     F2_REQUIRE(ctx->dp, FLUX2MI_ERR_NOT_LOADED, "dp_all_gather_images: flux2mi_dp_init has not been called on this context");
     F2_CHECK_HIP(hipSetDevice(ctx->device));
+    DpTimed timed(ctx, 1, (long long)bytes_per_rank * ctx->dp->world);
     F2_CHECK_NCCL(g_rccl.AllGather(local_images, all_images, (size_t)bytes_per_rank, ncclUint8, ctx->dp->comm, ctx->stream));
+    return FLUX2MI_OK;
+}
+
+// Per-exchange timings for the bench line (SURVEY §8e "Measurability"): with timing on, every broadcast / all-gather is bracketed by
+// HIP events on the context's stream — the time between them is what the exchange costs the generating stream at that point,
+// waiting for the slowest peer included.  flux2mi_dp_collective_stats folds what has finished (synchronises the stream) and
+// returns, per kind (0 broadcast, 1 all-gather): summed milliseconds, number of calls, payload bytes; `reset` clears the sums.
+extern "C" int flux2mi_dp_collective_timing(flux2mi_ctx* ctx, int on) {
+    F2_REQUIRE(ctx, FLUX2MI_ERR_INVALID_ARG, "dp_collective_timing: NULL ctx");
+    F2_REQUIRE(ctx->dp, FLUX2MI_ERR_NOT_LOADED, "dp_collective_timing: flux2mi_dp_init has not been called on this context");
+    ctx->dp->timing = on != 0;
+    return FLUX2MI_OK;
+}
+extern "C" int flux2mi_dp_collective_stats(flux2mi_ctx* ctx, double ms[2], int64_t calls[2], int64_t bytes[2], int reset) {
+    F2_REQUIRE(ctx, FLUX2MI_ERR_INVALID_ARG, "dp_collective_stats: NULL ctx");
+    F2_REQUIRE(ctx->dp, FLUX2MI_ERR_NOT_LOADED, "dp_collective_stats: flux2mi_dp_init has not been called on this context");
+    F2_CHECK_HIP(hipSetDevice(ctx->device));
+    dp_fold(ctx);
+    flux2mi_dp* d = ctx->dp;
+    for (int k = 0; k < 2; ++k) {
+        if (ms) ms[k] = d->ms[k];
+        if (calls) calls[k] = d->calls[k];
+        if (bytes) bytes[k] = d->bytes[k];
+        if (reset) { d->ms[k] = 0.0; d->calls[k] = 0; d->bytes[k] = 0; }
+    }
     return FLUX2MI_OK;
 }
 

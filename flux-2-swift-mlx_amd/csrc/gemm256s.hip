@@ -1615,7 +1615,11 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
     const size_t tn = (size_t)grid.x * 32;   // 8 words per wave
     static const char* trace_every = F2_DEV_ENV("FLUX2MI_GEMM_TRACE_EVERY");   // trace every n-th launch (default 16)
     static const int trace_n = trace_every ? (atoi(trace_every) > 0 ? atoi(trace_every) : 1) : 16;
-    if (trace_env && ++seen % trace_n == 0 && hipMalloc((void**)&b.trace, tn * 8) != hipSuccess) b.trace = nullptr;
+    if (trace_env && ++seen % trace_n == 0) {
+        // zeroed: words 4..7 are written by the lean convolution epilogue only, word 3 by dev builds only
+        if (hipMalloc((void**)&b.trace, tn * 8) != hipSuccess) b.trace = nullptr;
+        else if (hipMemsetAsync(b.trace, 0, tn * 8, stream) != hipSuccess) { (void)hipFree(b.trace); b.trace = nullptr; }
+    }
     struct TraceOut {
         GemmBatch& b; hipStream_t stream; size_t tn; const GemmProblem* probs; int ni; int nprob;
         ~TraceOut() {
@@ -1669,7 +1673,10 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
             const GemmProblem& q = probs[i];
             fast = fast && (q.N & 31) == 0 && (q.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(q.C) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(q.vec) & 15) == 0 && q.conv_wp > 16 && q.M < (1 << 24) && q.ldc < (1 << 24) && q.ldr < (1 << 24) &&
-                   (!q.resid || ((q.ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(q.resid) & 15) == 0));
+                   (!q.resid || ((q.ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(q.resid) & 15) == 0)) &&
+                   // 32-bit ELEMENT offsets into the output (up to 4 M + a padded row of slack rows for the upsampling form) and the residual
+                   (4ull * (unsigned long long)q.M + 4ull * (unsigned long long)q.conv_wp + 64ull) *
+                       (unsigned long long)(q.ldc > q.ldr ? q.ldc : q.ldr) < (1ull << 32);
         }
         static const bool fast_on = [] {
             const char* e = F2_DEV_ENV("FLUX2MI_CONV_FAST");
@@ -1698,7 +1705,9 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
     for (int i = 0; i < nprob; ++i) {
         const GemmProblem& q = probs[i];
         grt = grt && q.epi == EPI_GATE_RESID && (q.N % TN) == 0 && (q.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(q.C) & 15) == 0 &&
-              q.vec != nullptr && (reinterpret_cast<uintptr_t>(q.vec) & 15) == 0;
+              q.vec != nullptr && (reinterpret_cast<uintptr_t>(q.vec) & 15) == 0 &&
+              // the transposed epilogue addresses X by 32-bit BYTE offsets: larger problems take the generic (64-bit) epilogue
+              (unsigned long long)q.M * (unsigned long long)q.ldc * 4ull < (1ull << 32);
     }
     static const bool grt_on = [] {
         const char* e = F2_DEV_ENV("FLUX2MI_GEMM_GRT");

@@ -17,12 +17,15 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
 
 _CTX = None          # api.Context with a communicator (attach_context)
+# gloo path (dry runs, CPU tests): wall-clock per exchange, same shape as flux2mi_dp_collective_stats
+_GLOO_STATS = {"timing": False, "ms": [0.0, 0.0], "calls": [0, 0], "bytes": [0, 0]}
 
 
 def init_distributed(backend: Optional[str] = None) -> tuple:
@@ -88,7 +91,9 @@ def broadcast_text_embeddings(emb: Optional[torch.Tensor], shape: Sequence[int],
         _CTX._exit()       # torch's current stream waits for the broadcast
         return buf
     bits = buf.view(torch.uint8)  # gloo on CPU tensors: bf16 as raw bytes
+    t0 = time.perf_counter()
     dist.broadcast(bits, src=src)
+    _gloo_account(0, time.perf_counter() - t0, bits.numel())
     return bits.view(torch.bfloat16)
 
 
@@ -108,9 +113,82 @@ def all_gather_images(local_images: torch.Tensor) -> torch.Tensor:
         _CTX._exit()
         return parts.transpose(0, 1).reshape(-1, *local_images.shape[1:])
     parts = [torch.empty_like(local_images) for _ in range(world)]
+    t0 = time.perf_counter()
     dist.all_gather(parts, local_images)
+    _gloo_account(1, time.perf_counter() - t0, local_images.numel() * world)
     stacked = torch.stack(parts, dim=1)  # [n_local, world, H, W, 3]
     return stacked.reshape(-1, *local_images.shape[1:])
+
+
+def _gloo_account(kind: int, seconds: float, nbytes: int) -> None:
+    _GLOO_STATS["calls"][kind] += 1
+    _GLOO_STATS["bytes"][kind] += int(nbytes)
+    if _GLOO_STATS["timing"]:
+        _GLOO_STATS["ms"][kind] += seconds * 1e3
+
+
+def collective_timing(on: bool) -> None:
+    """Bracket every exchange with HIP events on the library's stream (flux2mi_dp_collective_timing); on the gloo path: wall clock."""
+    if _CTX is not None:
+        from ._lib import check, lib
+        check(lib().flux2mi_dp_collective_timing(_CTX.handle, 1 if on else 0))
+    _GLOO_STATS["timing"] = bool(on)
+
+
+def collective_stats(reset: bool = False) -> dict:
+    """{"broadcast": {"ms", "calls", "bytes"}, "all_gather": {...}} since the last reset (flux2mi_dp_collective_stats; synchronises)."""
+    if _CTX is not None:
+        from ._lib import check, lib
+        ms, calls, nbytes = (C.c_double * 2)(), (C.c_int64 * 2)(), (C.c_int64 * 2)()
+        check(lib().flux2mi_dp_collective_stats(_CTX.handle, ms, calls, nbytes, 1 if reset else 0))
+        vals = [list(ms), list(calls), list(nbytes)]
+    else:
+        vals = [list(_GLOO_STATS["ms"]), list(_GLOO_STATS["calls"]), list(_GLOO_STATS["bytes"])]
+        if reset:
+            _GLOO_STATS.update(ms=[0.0, 0.0], calls=[0, 0], bytes=[0, 0])
+    return {name: {"ms": float(vals[0][k]), "calls": int(vals[1][k]), "bytes": int(vals[2][k])}
+            for k, name in enumerate(("broadcast", "all_gather"))}
+
+
+# ---- analytic scaling model (SURVEY.md §8e "Measurability", BASELINE.md §3) -------------------------------------------------------
+# One node, image-granular replicas: the only terms that grow with the world size are the two exchanges and rank 0's D2H of the
+# gathered batch.  xGMI is point-to-point (7 links per GPU, ~153 GB/s each; PCIe Gen5 x16 63 GB/s spec: /opt/skills/guides/MI355X_MICROARCH.md), RCCL's
+# ring forms are bound by ONE link: a broadcast of B bytes streams B through every hop of the chain (pipelined: ~B / link + hops x
+# latency); a ring all-gather moves (N - 1) / N of the gathered bytes through each link.
+XGMI_LINK_GBS = 153.0          # per link, per direction (data sheet)
+XGMI_EFFICIENCY = 0.70         # what a ring protocol sustains of that (assumed; no multi-GPU box was available to measure it)
+HOP_LATENCY_US = 12.0          # per ring step, launch + protocol (assumed)
+PCIE_D2H_GBS = 50.0            # rank 0's D2H of the gathered images (pinned host memory, PCIe 5 x16; assumed)
+
+
+def scaling_model(seconds_per_image_1gpu: float, denoise_steps: int, s_txt: int, joint_dim: int, height: int, width: int,
+                  worlds=(1, 2, 4, 8)) -> dict:
+    """Predicted seconds/image, denoise-steps/s and weak-scaling efficiency at N GPUs from the measured 1-GPU time of one image
+    (which already holds one image's D2H) plus the modelled per-batch terms.  One batch = N images, one per GPU."""
+    link = XGMI_LINK_GBS * XGMI_EFFICIENCY * 1e9
+    img = height * width * 3
+    rows = []
+    for n in worlds:
+        b_bytes = n * s_txt * joint_dim * 2                      # bf16 embeddings of the whole batch, from rank 0
+        g_bytes = n * img                                        # u8 images, every rank ends with all of them
+        if n == 1:
+            t_b = t_g = t_d = 0.0
+        else:
+            t_b = b_bytes / link + (n - 1) * HOP_LATENCY_US * 1e-6
+            t_g = (n - 1) * img / link + (n - 1) * HOP_LATENCY_US * 1e-6
+            t_d = (n - 1) * img / (PCIE_D2H_GBS * 1e9)           # the first image's D2H is inside the 1-GPU measurement
+        t = seconds_per_image_1gpu + t_b + t_g + t_d
+        rows.append({"n_gpus": n, "broadcast_bytes": b_bytes, "all_gather_bytes": g_bytes,
+                     "broadcast_ms": round(t_b * 1e3, 4), "all_gather_ms": round(t_g * 1e3, 4), "extra_d2h_ms": round(t_d * 1e3, 4),
+                     "seconds_per_image": round(t, 5), "denoise_steps_per_s": round(n * denoise_steps / t, 3),
+                     "efficiency": round(seconds_per_image_1gpu / t, 5)})
+    return {"model": "t(N) = t(1) + broadcast(N x s_txt x J x 2 B, chain over one xGMI link) + ring all-gather((N-1) x H x W x 3 B per "
+                     "link) + rank 0's D2H of the other N-1 images; no term inside the denoise loop (image-granular replicas)",
+            "assumptions": {"xgmi_link_GBps": XGMI_LINK_GBS, "ring_efficiency": XGMI_EFFICIENCY, "hop_latency_us": HOP_LATENCY_US,
+                            "pcie_d2h_GBps": PCIE_D2H_GBS,
+                            "not_modelled": "per-GPU clock differences inside a node (boxes of the pool differ by up to 11 % on one "
+                                            "binary; the batch takes the slowest rank's time) and host-side launch jitter"},
+            "base_seconds_per_image": round(seconds_per_image_1gpu, 5), "predicted": rows}
 
 
 def finalize():

@@ -108,6 +108,12 @@ int flux2mi_dp_broadcast_embeddings(flux2mi_ctx* ctx, void* embeddings, int64_t 
 int flux2mi_dp_all_gather_images(flux2mi_ctx* ctx, const uint8_t* local_images, uint8_t* all_images, int64_t bytes_per_rank);
 /* max over the ranks of one host f64, in place (the bench's max-over-ranks time; doubles as a barrier); synchronises */
 int flux2mi_dp_all_reduce_max(flux2mi_ctx* ctx, double* value);
+/* Timings of the two exchanges for the bench line (SURVEY.md §8e "Measurability"; the reference has no counterpart: single process,
+ * Flux2Pipeline.swift:135).  With timing on, every broadcast / all-gather is bracketed by HIP events on the context's stream;
+ * _stats folds the finished ones (synchronises the stream) and returns per kind (index 0 broadcast, 1 all-gather) the summed
+ * milliseconds, the number of calls and the payload bytes since the last reset; any output pointer may be NULL. */
+int flux2mi_dp_collective_timing(flux2mi_ctx* ctx, int on);
+int flux2mi_dp_collective_stats(flux2mi_ctx* ctx, double ms[2], int64_t calls[2], int64_t bytes[2], int reset);
 void* flux2mi_ctx_stream(flux2mi_ctx* ctx);             /* hipStream_t */
 
 /* ---- scheduler (host) -------------------------------------------------- */

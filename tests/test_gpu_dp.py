@@ -27,6 +27,8 @@ def test_dp_one_rank_rccl_collectives_in_stream_order_with_generate(flux2mi):
     for round_ in range(2):                                   # finalise + re-create
         par.attach_context(ctx)
         assert lib().flux2mi_dp_world(ctx.handle) == 1
+        par.collective_stats(reset=True)
+        par.collective_timing(round_ == 0)                    # round 0: HIP events around both exchanges; round 1: counted, not timed
         inp = syn.make_inputs(cfg, 128, 128, s_txt=16)
         emb = par.broadcast_text_embeddings(inp["txt"].cuda(), tuple(inp["txt"].shape), torch.device("cuda"))
         assert torch.equal(emb.cpu().view(torch.int16), inp["txt"].view(torch.int16))
@@ -38,6 +40,15 @@ def test_dp_one_rank_rccl_collectives_in_stream_order_with_generate(flux2mi):
         assert tuple(allimgs.shape) == (1, 128, 128, 3)
         assert np.array_equal(allimgs[0].cpu().numpy(), ref.image) and len(np.unique(ref.image)) > 16
         assert par.all_reduce_max(3.25) == 3.25
+        # flux2mi_dp_collective_stats: one call of each kind with its payload; event time only while timing is on
+        st = par.collective_stats(reset=True)
+        assert st["broadcast"]["calls"] == 1 and st["broadcast"]["bytes"] == inp["txt"].numel() * 2
+        assert st["all_gather"]["calls"] == 1 and st["all_gather"]["bytes"] == 128 * 128 * 3
+        if round_ == 0:
+            assert 0.0 < st["broadcast"]["ms"] < 1000.0 and 0.0 < st["all_gather"]["ms"] < 1000.0
+        else:
+            assert st["broadcast"]["ms"] == 0.0 and st["all_gather"]["ms"] == 0.0
+        assert par.collective_stats()["broadcast"]["calls"] == 0
         # a second communicator on the same context is refused
         ident = (C.c_uint8 * 128)()
         check(lib().flux2mi_dp_unique_id(ident))

@@ -604,6 +604,10 @@ def test_trim_from_another_thread_while_calls_run(flux2mi, ctx):
         stop.set()
         th.join()
     assert trims["err"] is None, trims["err"]
-    assert trims["n"] > 40 and trims["freed"] > 0      # the trims ran, and between calls they did give memory back
+    assert trims["n"] > 0                               # the trimmer ran beside the calls (how often it won a gap is the box's business)
+    # the deterministic half: with the thread joined and no call running, one trim gives the workspaces back and results do not change
+    assert torch.equal(_fwd(dit, cfg, inp, lat, 64, 64, 16), ref_f)
+    assert ctx.clear_cache() > 0
+    assert torch.equal(_fwd(dit, cfg, inp, lat, 64, 64, 16), ref_f)
     dit.close()
     vae.close()

@@ -281,6 +281,25 @@ def test_gemm_gate_resid_exact(ctx, M, N, K):
         assert torch.equal(x, ref), (M, N, K, it)
 
 
+def test_gemm_gate_resid_beyond_32bit_offsets(ctx):
+    """X of 4 GiB or more: the transposed-domain epilogue addresses X by 32-bit byte offsets, so the launcher must hand such a
+    problem to the generic (64-bit offset) epilogue (csrc/gemm256s.hip, `grt` predicate) — rows behind the 4 GiB line included.
+    Integer-valued data: exact."""
+    M, N, K = 33024, 32768, 64                       # M * N * 4 = 4.03 GiB
+    g = torch.Generator(device="cuda").manual_seed(77)
+    a = torch.randint(-2, 3, (M, K), generator=g, device="cuda").to(torch.bfloat16)
+    w = torch.randint(-2, 3, (N, K), generator=g, device="cuda").to(torch.bfloat16)
+    gate = torch.randint(-2, 3, (N,), generator=g, device="cuda").float()
+    x = torch.full((M, N), 3.0, device="cuda")
+    x = ctx.op_gemm_gate_resid(a, w, gate, x)
+    wf = w.float().t()
+    for lo, hi in ((0, 300), (16000, 16300), (32700, M)):     # the last band lies behind byte offset 2^32
+        ref = 3.0 + gate[None, :] * (a[lo:hi].float() @ wf)
+        assert torch.equal(x[lo:hi], ref), (lo, hi)
+    del x
+    torch.cuda.empty_cache()
+
+
 def test_gemm_gate_resid_random_deterministic(ctx):
     g = torch.Generator(device="cuda").manual_seed(5)
     a = torch.randn((4608, 12288), generator=g, device="cuda").to(torch.bfloat16)

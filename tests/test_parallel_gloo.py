@@ -76,6 +76,35 @@ def test_bench_launches_its_own_ranks_dry_run():
     assert out["config"]["images_per_bench_step"] == 2 and out["config"]["parallelism"] == "dp2"
     expect = bytes([1]) * (64 * 64 * 3) + bytes([2]) * (64 * 64 * 3)      # all-gathered batch in rank order
     assert out["output_check"]["image_crc32"] == f"{zlib.crc32(expect) & 0xffffffff:08x}"
+    # SURVEY §8e "Measurability": per-exchange timings of the timed region (here: wall clock around the gloo collectives) with the
+    # payload of ONE batch, and the analytic 1 -> 8 model next to them
+    cm = out["collective_ms"]
+    assert cm["broadcast"] > 0 and cm["all_gather"] > 0
+    assert cm["broadcast_bytes"] == 2 * 512 * 64 * 2 and cm["all_gather_bytes"] == 2 * 64 * 64 * 3
+    sm = out["scaling_model"]
+    assert [r["n_gpus"] for r in sm["predicted"]] == [1, 2, 4, 8]
+    assert sm["predicted"][1]["broadcast_bytes"] == cm["broadcast_bytes"] and sm["predicted"][1]["all_gather_bytes"] == cm["all_gather_bytes"]
+
+
+def test_scaling_model_terms():
+    """The model of SURVEY §8e / DESIGN §1e: per-batch bytes of the two exchanges, efficiency 1 at N = 1 and falling with N,
+    aggregate throughput growing with N; a longer image time dilutes the exchanges."""
+    sys.path.insert(0, ROOT)
+    import flux2mi  # noqa: F401
+    from flux2mi import parallel as par
+    m = par.scaling_model(0.75, 28, 512, 7680, 1024, 1024)
+    rows = m["predicted"]
+    assert rows[0]["efficiency"] == 1.0 and rows[0]["broadcast_ms"] == 0.0
+    for a, b in zip(rows, rows[1:]):
+        assert b["efficiency"] < a["efficiency"] and b["denoise_steps_per_s"] > a["denoise_steps_per_s"]
+    r8 = rows[-1]
+    assert r8["broadcast_bytes"] == 8 * 512 * 7680 * 2 and r8["all_gather_bytes"] == 8 * 1024 * 1024 * 3
+    link = par.XGMI_LINK_GBS * par.XGMI_EFFICIENCY * 1e9
+    assert abs(r8["broadcast_ms"] - (r8["broadcast_bytes"] / link + 7 * par.HOP_LATENCY_US * 1e-6) * 1e3) < 1e-3
+    assert abs(r8["all_gather_ms"] - (7 * 1024 * 1024 * 3 / link + 7 * par.HOP_LATENCY_US * 1e-6) * 1e3) < 1e-3
+    assert r8["efficiency"] > 0.99                       # two exchanges per IMAGE, not per step: the path is compute-bound at any N
+    slow = par.scaling_model(7.5, 50, 512, 15360, 1024, 1024)["predicted"][-1]
+    assert slow["efficiency"] > r8["efficiency"]
 
 
 def test_bench_refuses_world_size_mismatch():
