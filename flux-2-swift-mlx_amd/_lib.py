@@ -197,6 +197,7 @@ PROTOTYPES = {
     "flux2mi_op_gemm_fp8_blocks": (_I, [_P, _P, _P, _P, _I, _I, _I]),
     "flux2mi_op_attention_qk8_blocks": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float]),
     "flux2mi_op_gemm_gate_resid": (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
+    "flux2mi_op_vae_attention": (_I, [_P, _P, _P, _P, _P, _I, _I]),
     "flux2mi_op_layernorm_modulate": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "flux2mi_op_qk_norm_rope": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _F]),
     "flux2mi_op_qk_proj_norm_rope": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _F, _P]),

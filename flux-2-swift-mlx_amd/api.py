@@ -310,6 +310,8 @@ class Context:
         5: "layernorm_modulate_kernel (LayerNorm + AdaLN modulate; work = algorithmic bytes: f32 row in, bf16 / e4m3 row out)",
         6: "gn_apply_padded_kernel (GroupNorm apply + SiLU into the zero-haloed operand; work = algorithmic bytes)",
         7: "gemm256s_kernel (double blocks' attention proj and mlp_out: the one-round N = d GEMMs)",
+        8: "vae_attention_kernel (the VAE mid block's single-head attention, head dim 512 / 384, streaming: no P x P scores in HBM; "
+           "work = 4 P^2 C)",
     }
 
     def prof_kernel_name(self, kernel_class: int) -> str:
@@ -360,6 +362,16 @@ class Context:
         check(lib().flux2mi_op_gemm_gate_resid(self.handle, _ptr(a), _ptr(w), _ptr(gate), _ptr(x), m, n, k))
         self._exit()
         return x
+
+    def op_vae_attention(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+        """softmax(q k^T / sqrt(C)) v for bf16 [P, C] (C = 512 / 384): the VAE mid block's streaming attention kernel."""
+        q, k, v = _req(q, torch.bfloat16, "q"), _req(k, torch.bfloat16, "k"), _req(v, torch.bfloat16, "v")
+        p, c = q.shape
+        out = torch.empty_like(q)
+        self._enter()
+        check(lib().flux2mi_op_vae_attention(self.handle, _ptr(q), _ptr(k), _ptr(v), _ptr(out), p, c))
+        self._exit()
+        return out
 
     def op_gemm_fp8(self, a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
         a, w = _req(a, torch.bfloat16, "A"), _req(w, torch.bfloat16, "W")

@@ -312,7 +312,7 @@ extern "C" int flux2mi_debug_mfma_stream(flux2mi_ctx* ctx, int fp8, double secon
 }
 
 extern "C" int flux2mi_prof_begin(flux2mi_ctx* ctx, int kernel_class) {
-    F2_REQUIRE(ctx && kernel_class >= 0 && kernel_class < 8, FLUX2MI_ERR_INVALID_ARG, "prof_begin: bad args");
+    F2_REQUIRE(ctx && kernel_class >= 0 && kernel_class < 9, FLUX2MI_ERR_INVALID_ARG, "prof_begin: bad args");
     ProfState& p = ctx->prof;
     p.used = 0;
     p.flops = 0.0;

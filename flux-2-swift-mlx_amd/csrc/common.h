@@ -44,7 +44,7 @@ void flux2mi_set_error(const char* fmt, ...);
 // kernel classes for flux2mi_prof_begin (bit masks passed to prof_before/after)
 // classes 5 and 6 are HBM-bound: their prof_after "flops" argument carries the ALGORITHMIC BYTES of the launch
 enum { PROF_LINEAR1 = 1 << 0, PROF_DIT_GEMM = 1 << 1, PROF_ATTENTION = 1 << 2, PROF_VAE_CONV = 1 << 3, PROF_LINEAR2 = 1 << 4,
-       PROF_LN_MODULATE = 1 << 5, PROF_GN_APPLY = 1 << 6, PROF_PROJ_MLPOUT = 1 << 7 };
+       PROF_LN_MODULATE = 1 << 5, PROF_GN_APPLY = 1 << 6, PROF_PROJ_MLPOUT = 1 << 7, PROF_VAE_ATTN = 1 << 8 };
 
 // Accounted device memory: every hipMalloc / hipFree of the library goes through these two, so that
 // flux2mi_ctx_memory_stats (the MLX.Memory.activeMemory / peakMemory / cacheMemory of the shim) reports what the library holds.

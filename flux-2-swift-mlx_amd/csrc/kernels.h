@@ -293,6 +293,12 @@ int launch_nchw_f32_to_nhwc_bf16_padded(hipStream_t stream, const float* in, uin
 // NHWC bf16 [P, C] channels [c0, c0+n) -> f32 [n, P] (NCHW)
 int launch_nhwc_bf16_to_nchw_f32(hipStream_t stream, const uint16_t* in, float* out, int C, int c0, int n, int64_t P);
 int launch_softmax_rows(hipStream_t stream, const float* in, uint16_t* out, int rows, int cols);
+// vae_attention.hip — the VAE mid block's single-head attention as ONE streaming kernel (no P x P scores in HBM); head dim 512 / 384.
+// O [P, C] bf16 = softmax(Q K^T * scale) V + vbias; Q, K [P, C] bf16 row-major, V^T [C][ldv] bf16 with ldv >= ceil32(P), ldv % 8 == 0 and
+// FINITE values in the columns P .. ceil32(P) - 1; vbias f32 [C] or NULL.  0 ok / 1 unsupported / 2 launch error.
+bool vae_attention_supported(int C);
+int launch_vae_attention(hipStream_t stream, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, int ldv, const float* vbias,
+                         uint16_t* O, int P, int C, float scale);
 int launch_transpose_bf16(hipStream_t stream, const uint16_t* in, uint16_t* out, int rows, int cols);
 int launch_oihw_to_ohwi_bf16(hipStream_t stream, const uint16_t* in, uint16_t* out, int O, int I, int KH, int KW,
                              int O_pad, int I_pad = 0 /* 0 = I */);

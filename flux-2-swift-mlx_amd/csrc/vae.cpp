@@ -510,6 +510,11 @@ struct Dec {
         const int C = w.gn.c;
         const int P = H * Wd;
         const size_t pc = (size_t)P * C * 2;
+        static const bool flash_on = [] {
+            const char* e = F2_DEV_ENV("FLUX2MI_VAE_FLASH");
+            return e ? atoi(e) != 0 : true;
+        }();
+        if (flash_on && vae_attention_supported(C)) return attention_streaming(w, A, B, P, C);
         F2_TRY(v->aq.reserve(pc)); F2_TRY(v->ak.reserve(pc)); F2_TRY(v->av.reserve(pc)); F2_TRY(v->avt.reserve(pc));
         F2_TRY(v->scores.reserve((size_t)P * P * 4));
         F2_TRY(v->probs.reserve((size_t)P * P * 2));
@@ -517,6 +522,7 @@ struct Dec {
         F2_TRY(lin(w.q, B, v->aq.as<uint16_t>(), P, C, nullptr));
         F2_TRY(lin(w.k, B, v->ak.as<uint16_t>(), P, C, nullptr));
         F2_TRY(lin(w.v, B, v->av.as<uint16_t>(), P, C, nullptr));
+        prof_before(v->ctx, PROF_VAE_ATTN);
         GemmProblem s;
         memset(&s, 0, sizeof s);
         s.A = v->aq.as<uint16_t>(); s.lda = C; s.W = v->ak.as<uint16_t>(); s.ldw = C; s.C = v->scores.ptr; s.ldc = P;
@@ -529,7 +535,33 @@ struct Dec {
         o.A = v->probs.as<uint16_t>(); o.lda = P; o.W = v->avt.as<uint16_t>(); o.ldw = P; o.C = v->aq.ptr; o.ldc = C;
         o.M = P; o.N = C; o.K = P; o.epi = EPI_BF16; o.alpha = 1.0f;
         F2_LAUNCH(launch_gemm(st, &o, 1), "vae.pv");
+        prof_after(v->ctx, PROF_VAE_ATTN, 4.0 * (double)P * (double)P * C);
         F2_TRY(lin(w.o, v->aq.as<uint16_t>(), A, P, C, A));
+        return FLUX2MI_OK;
+    }
+    // The production widths (C = 512 standard decoder / encoder, 384 small decoder): one streaming kernel (vae_attention.hip), the P x P
+    // scores never in HBM (the form above: P*P*6 bytes = 1.5 GiB at 1024^2, 25.8 GiB at 2048^2).  V^T comes straight out of a role-swapped
+    // GEMM (W_v as the row operand: C = W_v x^T, [C][ldv]) — no transpose pass; its bias is added by the attention's epilogue (softmax
+    // rows sum to 1).
+    int attention_streaming(const AttnW& w, uint16_t* A, uint16_t* B, int P, int C) {
+        const size_t pc = (size_t)P * C * 2;
+        const int ldv = (P + 31) & ~31;
+        F2_TRY(v->aq.reserve(pc)); F2_TRY(v->ak.reserve(pc)); F2_TRY(v->av.reserve(pc)); F2_TRY(v->avt.reserve((size_t)C * ldv * 2));
+        F2_TRY(gn(w.gn, A, B, P, 0));
+        F2_TRY(lin(w.q, B, v->aq.as<uint16_t>(), P, C, nullptr));
+        F2_TRY(lin(w.k, B, v->ak.as<uint16_t>(), P, C, nullptr));
+        if (ldv != P) F2_CHECK_HIP(hipMemsetAsync(v->avt.ptr, 0, (size_t)C * ldv * 2, st));   // the key columns behind P: finite (they meet probability 0)
+        GemmProblem t;
+        memset(&t, 0, sizeof t);
+        t.A = W(w.v.w); t.lda = C; t.W = B; t.ldw = C; t.C = v->avt.ptr; t.ldc = ldv;
+        t.M = C; t.N = P; t.K = C; t.epi = EPI_BF16; t.alpha = 1.0f;
+        F2_LAUNCH(launch_gemm(st, &t, 1), "vae.v^T");
+        prof_before(v->ctx, PROF_VAE_ATTN);
+        const int r = launch_vae_attention(st, v->aq.as<uint16_t>(), v->ak.as<uint16_t>(), v->avt.as<uint16_t>(), ldv, F(w.v.b),
+                                           v->av.as<uint16_t>(), P, C, 1.0f / sqrtf((float)C));
+        prof_after(v->ctx, PROF_VAE_ATTN, 4.0 * (double)P * (double)P * C);
+        F2_LAUNCH(r, "vae.attention(streaming)");
+        F2_TRY(lin(w.o, v->av.as<uint16_t>(), A, P, C, A));
         return FLUX2MI_OK;
     }
 };
@@ -670,5 +702,34 @@ extern "C" int flux2mi_vae_encode(flux2mi_vae* v, const float* image, int H, int
     F2_TRY(d.conv(v->e_quant, C, h, w, 0, nullptr, B));              // quant_conv 1x1
     F2_LAUNCH(launch_nhwc_bf16_to_nchw_f32(d.st, B, z_mean, 2 * c.latent_channels, 0, c.latent_channels, (int64_t)h * w),
               "mean->nchw");
+    return FLUX2MI_OK;
+}
+
+// The mid block's attention alone (tests / microbenchmarks): q, k, v bf16 [P, C] as the projections leave them (biases included).
+// Same path as the decoder: V^T by a transpose pass here (the decoder gets it straight from its value GEMM), then the streaming kernel.
+extern "C" int flux2mi_op_vae_attention(flux2mi_ctx* ctx, const void* q, const void* k, const void* vv, void* out, int P, int C) {
+    F2_REQUIRE(ctx && q && k && vv && out && P > 0, FLUX2MI_ERR_INVALID_ARG, "op_vae_attention: bad argument");
+    F2_REQUIRE(vae_attention_supported(C), FLUX2MI_ERR_UNSUPPORTED, "op_vae_attention: head dim %d (512 and 384 are built)", C);
+    F2_WORKSPACE_USE(ctx->device);
+    F2_CHECK_HIP(hipSetDevice(ctx->device));
+    const int ldv = (P + 31) & ~31;
+    F2_TRY(ctx->scratch.reserve((size_t)C * ldv * 2));
+    uint16_t* vt = ctx->scratch.as<uint16_t>();
+    if (ldv != P) F2_CHECK_HIP(hipMemsetAsync(vt, 0, (size_t)C * ldv * 2, ctx->stream));
+    // [P, C] -> [C][ldv]: the transpose kernel writes pitch P; a 2-D copy re-pitches it when P is not a multiple of 32
+    if (ldv == P) {
+        F2_LAUNCH(launch_transpose_bf16(ctx->stream, reinterpret_cast<const uint16_t*>(vv), vt, P, C), "op_vae_attention: v^T");
+    } else {
+        DevBuf tmp;
+        F2_TRY(tmp.reserve((size_t)C * P * 2));
+        F2_LAUNCH(launch_transpose_bf16(ctx->stream, reinterpret_cast<const uint16_t*>(vv), tmp.as<uint16_t>(), P, C), "op_vae_attention: v^T");
+        F2_CHECK_HIP(hipMemcpy2DAsync(vt, (size_t)ldv * 2, tmp.ptr, (size_t)P * 2, (size_t)P * 2, C, hipMemcpyDeviceToDevice, ctx->stream));
+        F2_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // tmp is released on return
+    }
+    prof_before(ctx, PROF_VAE_ATTN);
+    const int r = launch_vae_attention(ctx->stream, reinterpret_cast<const uint16_t*>(q), reinterpret_cast<const uint16_t*>(k), vt, ldv, nullptr,
+                                       reinterpret_cast<uint16_t*>(out), P, C, 1.0f / sqrtf((float)C));
+    prof_after(ctx, PROF_VAE_ATTN, 4.0 * (double)P * (double)P * C);
+    F2_LAUNCH(r, "op_vae_attention");
     return FLUX2MI_OK;
 }

@@ -507,7 +507,8 @@ int flux2mi_generate(flux2mi_ctx* ctx, flux2mi_dit* dit, flux2mi_vae* vae, flux2
 /* ---- measurement aid ---------------------------------------------------- */
 /* HIP-event timing of one kernel class on the context's stream while the hot path
  * runs (bench.py roofline leg).  kernel_class: 0 = single-block linear1 GEMM,
- * 1 = all DiT GEMMs, 2 = attention, 3 = VAE conv. */
+ * 1 = all DiT GEMMs, 2 = attention, 3 = VAE conv, 4 = linear2, 5 = LayerNorm + modulate, 6 = GroupNorm apply, 7 = proj + mlp_out,
+ * 8 = the VAE mid block's attention (work = 4 P^2 C). */
 int flux2mi_prof_begin(flux2mi_ctx* ctx, int kernel_class);
 int flux2mi_prof_end(flux2mi_ctx* ctx, int* n_launches, double* total_ms, double* flops);
 /* The matrix-pipe rate THIS card sustains (diagnostic; bench.py's roofline.mfma_stream): a register-only stream of the MFMA the
@@ -517,6 +518,10 @@ int flux2mi_prof_end(flux2mi_ctx* ctx, int* n_launches, double* total_ms, double
 int flux2mi_debug_mfma_stream(flux2mi_ctx* ctx, int fp8, double seconds, double* tflops);
 
 /* Standalone op entry points (tests / microbenchmarks; same kernels the forward uses). */
+/* The VAE mid block's single-head attention (AttentionBlock, VAE/ResnetBlock.swift:281-313: softmax(q k^T / sqrt(C)) v) as the decoder
+ * runs it: ONE streaming kernel, the P x P scores never in HBM.  q, k, v bf16 [P, C] device (the projections WITH their biases), out bf16
+ * [P, C]; C = 512 or 384 (other widths: FLUX2MI_ERR_UNSUPPORTED — the decoder keeps the three-launch form for them). */
+int flux2mi_op_vae_attention(flux2mi_ctx* ctx, const void* q, const void* k, const void* v, void* out, int P, int C);
 /* C[M,N] (f32) = A[M,K] (bf16) * W[N,K]^T (bf16) */
 int flux2mi_op_gemm_bf16(flux2mi_ctx* ctx, const void* A, const void* W, float* C, int M, int N, int K);
 /* the same product stored as bf16 [M,N] (one rounding of the f32 accumulator), as the model's block GEMMs store it */

@@ -112,6 +112,40 @@ def test_config_c_dev32b_1024_50_steps_properties(dev32b):
     assert rel_l2(c.latents, d.latents) > 1e-4
 
 
+def test_dev32b_bf16_teacher_forced_blocks_vs_store_point_oracle(dev32b):
+    """Dev-32B block by block (8 double + 48 single, d 6144, 48 heads, guidance embedder), like Klein-4B / Klein-9B: every block is fed the
+    input the oracle's store-point emulation (`device_roundings`) gave it, through flux2mi_dit_forward_block, and must reproduce the
+    emulation's increment to 2e-3 (double blocks) / 5e-4 (single blocks) and its output to 3e-4.  S = 64 text + 256 image tokens (the
+    56 tapped streams of a 768-token forward are 1 GB and its emulating oracle two minutes of host time: the block arithmetic does not
+    depend on S); the oracle runs live (~30 s)."""
+    import time
+    from flux2mi import synthetic as syn
+    k = dev32b
+    cfg = k["cfg"]
+    s_txt = 64
+    inp = syn.make_inputs(cfg, 256, 256, s_txt=s_txt)
+    lat = R.pack_patchified_to_sequence(inp["noise"])
+    ii, ti = R.image_position_ids(256, 256), R.text_position_ids(s_txt)
+    Pc = k["W"].cpu()
+    taps = {}
+    t0 = time.time()
+    with torch.no_grad(), R.device_roundings():
+        R.dit_forward(Pc, cfg, lat, inp["txt"].float(), torch.tensor([0.6]), torch.tensor([4.0]), ii, ti, taps=taps)
+    t_oracle = time.time() - t0
+    nd, ns = cfg["n_double"], cfg["n_single"]
+    dit = k["pipe"].transformer
+    rows = []
+    for layer in range(nd + ns):
+        x_in, y_ref = tapped_stream(taps, layer - 1, nd), tapped_stream(taps, layer, nd)
+        y = dit.forward_block(layer, x_in.cuda(), inp["txt"].cuda(), 0.6, 4.0, ii.cuda(), ti.cuda()).cpu()
+        rows.append((layer, rel_l2(y, y_ref), rel_l2(y - x_in, y_ref - x_in)))
+    print(f"Dev-32B bf16 teacher-forced blocks, S {s_txt + 256} (oracle {t_oracle:.0f} s; layer: output / increment): "
+          + ", ".join(f"{l}: {a:.1e} / {b:.1e}" for l, a, b in rows))
+    assert max(r[1] for r in rows) < 3e-4, rows
+    assert max(r[2] for r in rows) < 2e-3, rows
+    assert max(r[2] for r in rows[nd:]) < 5e-4, rows[nd:]
+
+
 # ------------------------------------------------------------------------------------------------ E: Dev-32B, strength 0.7, RePaint
 def _repaint_inputs(S):
     g = torch.Generator().manual_seed(99)
