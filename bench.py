@@ -487,7 +487,7 @@ def secondary_rooflines(pipe, torch, dev, H, W, peak, stream_tf, traffic, short_
         g.manual_seed(11)
         z = torch.randn((1, 32, H // 8, W // 8), generator=g, device=dev, dtype=torch.float32)
         pipe.vae.decode(z, want_f32=False)
-        for cls in (3, 6):                            # VAE convolutions, GroupNorm apply
+        for cls in (3, 6, 8):                         # VAE convolutions, GroupNorm apply, the mid block's streaming attention
             ctx.prof_begin(cls)
             pipe.vae.decode(z, want_f32=False)
             n, ms, work = ctx.prof_end()
