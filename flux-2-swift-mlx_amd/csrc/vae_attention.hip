@@ -28,6 +28,7 @@
 // bound by those two streams, not the matrix pipe.
 #include "dev.h"
 #include "kernels.h"
+#include <utility>
 
 namespace {
 
@@ -35,6 +36,24 @@ constexpr int VA_BN = 32;                         // keys per tile
 constexpr int VA_NW = 4;                          // waves per workgroup
 constexpr int VA_BM = 16 * VA_NW;                 // queries per workgroup
 constexpr float VA_HEADROOM = 60.0f;              // log2 of the growth the numerators may take over the sampled offset before the loop is redone
+
+template <int I> using va_ic = std::integral_constant<int, I>;
+template <class F, int... I>
+__device__ __forceinline__ void va_for(F&& f, std::integer_sequence<int, I...>) {
+    (f(va_ic<I>{}), ...);
+}
+#define VA_INLINE __attribute__((always_inline))
+// MFMAs as inline asm with their accumulators tied in place: S^T in VGPRs (read by the softmax right away), O^T and the row sums in
+// AGPRs.  (As builtins hipcc selects untied forms around this loop's control flow and copies all 128 accumulators on every tile; the
+// "a" constraints also make it allocate AGPRs at all.)  Not volatile: hipcc places the LDS reads and the vector work around them.
+// hipcc does not know these statements are MFMAs, so the read-after-MFMA wait states are explicit below (s_nop).
+// all eight fragments of a batch "used" by one empty statement: hipcc puts ONE counted wait in front of it (for the youngest of them, the
+// next batch's reads stay in flight) and none in front of the MFMAs behind it — left alone it waits for each fragment in front of its own
+// MFMA, an issue slot per MFMA for a wave that is alone on its SIMD
+#define VA_FENCE8(f_) asm volatile("" : "+v"(f_[0]), "+v"(f_[1]), "+v"(f_[2]), "+v"(f_[3]), "+v"(f_[4]), "+v"(f_[5]), "+v"(f_[6]), "+v"(f_[7]))
+#define VA_MFMA_NEW(d_, a_, b_) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(d_) : "v"(a_), "v"(b_))
+#define VA_MFMA_V(d_, a_, b_) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d_) : "v"(a_), "v"(b_))
+#define VA_MFMA_A(d_, a_, b_) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(d_) : "v"(a_), "v"(b_))
 
 template <int HD>
 __global__ __launch_bounds__(64 * VA_NW, 1) void vae_attention_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K,
@@ -47,7 +66,11 @@ __global__ __launch_bounds__(64 * VA_NW, 1) void vae_attention_kernel(const uint
     constexpr int KT = VA_BN * KROW;              // 32 KB
     constexpr int VT = CB * 1024;                 // 32 KB (HD 384: 24 KB)
     constexpr int STG = KT + VT;
-    static_assert(HD % 128 == 0 && CB % VA_NW == 0 && VA_BN % VA_NW == 0, "tile shape");
+    constexpr int KPW = VA_BN / VA_NW;            // key rows a wave brings per tile (8)
+    constexpr int CPW = CB / VA_NW;               // V^T blocks a wave brings per tile (8 / 6)
+    constexpr int NKB = KS / 4;                   // fragment batches of Q K^T: 4 k-steps x 2 key blocks = 8 reads each
+    constexpr int NVB = CB / 8;                   // fragment batches of P V: 8 column blocks each
+    static_assert(HD % 128 == 0 && CB % VA_NW == 0 && VA_BN % VA_NW == 0 && CB % 8 == 0, "tile shape");
     __shared__ __attribute__((aligned(1024))) uint8_t smem[2 * STG];
 
     const int lane = threadIdx.x & 63;
@@ -55,6 +78,7 @@ __global__ __launch_bounds__(64 * VA_NW, 1) void vae_attention_kernel(const uint
     const int g = lane >> 4, r = lane & 15;
     const int q0 = blockIdx.x * VA_BM + wid * 16;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    const int nt = (P + VA_BN - 1) / VA_BN;
 
     // ---- Q fragments: B operand, lane (g, r) holds Q[q0 + r][32 ks + 8 g .. + 7]
     bf16x8 qf[KS];
@@ -65,32 +89,49 @@ __global__ __launch_bounds__(64 * VA_NW, 1) void vae_attention_kernel(const uint
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(src + 32 * ks);
     }
 
-    // ---- DMA of one key tile into stage `st`: wave w brings key rows 8w .. 8w+7 and V^T blocks (CB/4) w .. + CB/4 - 1
-    const uint32_t lane16 = (uint32_t)lane * 16u;
-    const uint32_t v_voff = ((uint32_t)r * (uint32_t)ldv + 8u * (uint32_t)g) * 2u;
-    auto issue = [&](int tile, int st) __attribute__((always_inline)) {
-        const int key0 = tile * VA_BN;
-        const uint32_t dst = lds_base + (uint32_t)st * STG;
+    // ---- DMA of one key tile into a stage: wave w brings key rows KPW w .. and V^T blocks CPW w ..; three instructions per piece
+    // (M0 <- LDS destination, the hazard nop, the DMA): per-lane offsets fixed, one scalar base per operand and tile.
+    // K row k of the tile: LDS chunk `lane` <- global chunk lane ^ swz(k); HD 384: lanes 48..63 fill the unused quarter with a valid chunk
+    uint32_t vo_k[KPW], vo_v[CPW];
 #pragma unroll
-        for (int j = 0; j < VA_BN / VA_NW; ++j) {
-            const int k = wid * (VA_BN / VA_NW) + j;                         // key row of the tile (wave-uniform)
-            const int row = min(key0 + k, P - 1);                            // rows behind the last key: any valid row (masked below)
-            const uint32_t swz = (uint32_t)((k & 3) | (((k >> 3) & 3) << 2));
-            uint32_t ch = (uint32_t)lane ^ swz;                              // LDS chunk `lane` of the row <- global chunk lane ^ swz
-            if (HD < 512 && ch >= (uint32_t)(HD / 8)) ch -= 16;              // HD 384: lanes 48..63 fill the unused quarter with a valid chunk
-            const uint8_t* sb = reinterpret_cast<const uint8_t*>(K) + (size_t)row * (HD * 2);
-            const uint32_t vo = ch * 16u;
-            const uint32_t m0v = dst + (uint32_t)k * KROW;
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(sb), "s"(m0v) : "memory");
-        }
+    for (int j = 0; j < KPW; ++j) {
+        const int k = wid * KPW + j;
+        uint32_t ch = (uint32_t)lane ^ (uint32_t)((k & 3) | (((k >> 3) & 3) << 2));
+        if (HD < 512 && ch >= (uint32_t)(HD / 8)) ch -= 16;
+        vo_k[j] = ch * 16u + (uint32_t)j * (HD * 2);
+    }
 #pragma unroll
-        for (int j = 0; j < CB / VA_NW; ++j) {
-            const int cb = wid * (CB / VA_NW) + j;
-            const uint8_t* sb = reinterpret_cast<const uint8_t*>(Vt) + ((size_t)(16 * cb) * (size_t)ldv + (size_t)key0) * 2;
-            const uint32_t m0v = dst + KT + (uint32_t)cb * 1024u;
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(v_voff), "s"(sb), "s"(m0v) : "memory");
-        }
-        (void)lane16;
+    for (int j = 0; j < CPW; ++j) vo_v[j] = ((uint32_t)(16 * j + r) * (uint32_t)ldv + 8u * (uint32_t)g) * 2u;
+    const uint8_t* k_src = reinterpret_cast<const uint8_t*>(K) + (size_t)(wid * KPW) * (HD * 2);               // + tile * 32 rows
+    const uint8_t* v_src = reinterpret_cast<const uint8_t*>(Vt) + (size_t)(16 * wid * CPW) * (size_t)ldv * 2;   // + tile * 64 bytes
+    const uint32_t m0_k = lds_base + (uint32_t)(wid * KPW) * KROW, m0_v = lds_base + KT + (uint32_t)(wid * CPW) * 1024u;
+#define VA_DMA(vo_, sb_, m0_, off_) \
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo_), "s"(sb_), "s"(m0_), "i"(off_) : "memory", "scc")
+    // every tile but the last: whole rows exist
+    auto issue = [&](int tile, int st) VA_INLINE {
+        const uint8_t* ks_ = k_src + (size_t)tile * (VA_BN * HD * 2);
+        const uint8_t* vs_ = v_src + (size_t)tile * (VA_BN * 2);
+        const uint32_t mk = m0_k + (uint32_t)st * STG, mv = m0_v + (uint32_t)st * STG;
+        va_for([&](auto jc) VA_INLINE { constexpr int j = decltype(jc)::value; (void)vo_k; (void)ks_; (void)mk; VA_DMA(vo_k[j], ks_, mk, j * KROW); }, std::make_integer_sequence<int, KPW>{});
+        va_for([&](auto jc) VA_INLINE { constexpr int j = decltype(jc)::value; (void)vo_v; (void)vs_; (void)mv; VA_DMA(vo_v[j], vs_, mv, j * 1024); }, std::make_integer_sequence<int, CPW>{});
+    };
+    // the last tile: rows behind the last key re-read row P - 1 (finite scores, masked below); V^T columns exist up to ldv (finite)
+    auto issue_last = [&](int tile, int st) VA_INLINE {
+        const uint8_t* vs_ = v_src + (size_t)tile * (VA_BN * 2);
+        const uint32_t mk = m0_k + (uint32_t)st * STG, mv = m0_v + (uint32_t)st * STG;
+        va_for([&](auto jc) VA_INLINE {
+            constexpr int j = decltype(jc)::value;
+            (void)vo_k; (void)mk;
+            const int row = min(tile * VA_BN + wid * KPW + j, P - 1);
+            const uint8_t* ks_ = reinterpret_cast<const uint8_t*>(K) + (size_t)row * (HD * 2);
+            const uint32_t vo = vo_k[j] - (uint32_t)j * (HD * 2);
+            VA_DMA(vo, ks_, mk, j * KROW);
+        }, std::make_integer_sequence<int, KPW>{});
+        va_for([&](auto jc) VA_INLINE { constexpr int j = decltype(jc)::value; (void)vo_v; (void)vs_; (void)mv; VA_DMA(vo_v[j], vs_, mv, j * 1024); }, std::make_integer_sequence<int, CPW>{});
+    };
+    auto issue_any = [&](int tile, int st) VA_INLINE {
+        if (tile == nt - 1) issue_last(tile, st);
+        else issue(tile, st);
     };
 
     // ---- fragment addresses.  K: A row r of key block kb is key 8 (r >> 2) + 4 kb + (r & 3); chunk (4 ks + g) ^ r
@@ -98,97 +139,128 @@ __global__ __launch_bounds__(64 * VA_NW, 1) void vae_attention_kernel(const uint
     uint32_t k_x[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) k_x[j] = k_row + ((((uint32_t)(4 * j + g)) ^ (uint32_t)r) << 4);
-    const uint32_t v_x = KT + lane16;
+    const uint32_t v_x = KT + (uint32_t)lane * 16u;
 
-    const int nt = (P + VA_BN - 1) / VA_BN;
-    float sv[8];
-    // S^T = K Q^T of the tile staged in `sp` (two key blocks of 16), scaled + masked scores in sv
-    // lane (g, r): s0[i] = key 8g + i, s1[i] = key 8g + 4 + i of the tile, query r
-    auto scores = [&](int t, const uint8_t* sp) __attribute__((always_inline)) {
-        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const uint8_t* a = sp + k_x[ks & 3] + (ks >> 2) * 256;
-            const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(a);
-            const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(a + 4 * KROW);
-            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[ks], s1, 0, 0, 0);
-        }
-        const int kbase = t * VA_BN + 8 * g;
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    asm volatile("" : "+v"(ones));
+
+    f32x4 s0, s1;                // S^T of the tile: lane (g, r): s0[i] = key 8g + i, s1[i] = key 8g + 4 + i, query r (RAW scores)
+    bf16x8 fa[8], fb[8];         // two fragment batches in flight
+    // reads of batch b of the K tile (4 k-steps x 2 key blocks) / of the V^T tile (8 column blocks)
+    auto read_k = [&](const uint8_t* sp, int b, bf16x8 (&f)[8]) VA_INLINE {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            sv[i] = (kbase + i < P) ? s0[i] * scale_log2e : -1.0e30f;
-            sv[4 + i] = (kbase + 4 + i < P) ? s1[i] * scale_log2e : -1.0e30f;
-        }
+        for (int e = 0; e < 8; ++e)                             // k-step 4 b + (e >> 1): chunk 16 b + (4 (e >> 1) + g) ^ r; e & 1: key block
+            f[e] = *reinterpret_cast<const bf16x8*>(sp + k_x[e >> 1] + b * 256 + (e & 1) * 4 * KROW);
     };
-    auto max8 = [&]() __attribute__((always_inline)) -> float {
-        return fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+    auto read_v = [&](const uint8_t* sp, int b, bf16x8 (&f)[8]) VA_INLINE {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const bf16x8*>(sp + v_x + (8 * b + i) * 1024);
     };
-    auto query_max = [&](float v) __attribute__((always_inline)) -> float {   // over the 4 lanes (g) of a query
+    // S^T = K Q^T of the tile staged at `sp`; leaves the first V^T batch requested in fa when with_v
+    auto scores = [&](const uint8_t* sp, bool with_v) VA_INLINE {
+        read_k(sp, 0, fa);
+        va_for([&](auto bc_) VA_INLINE {
+            constexpr int b = decltype(bc_)::value;
+            (void)fa; (void)fb; (void)qf; (void)s0; (void)s1; (void)sp; (void)with_v;
+            bf16x8 (&cur)[8] = (b & 1) ? fb : fa;
+            bf16x8 (&nxt)[8] = (b & 1) ? fa : fb;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (b + 1 < NKB) read_k(sp, b + 1, nxt);
+            else if (with_v) read_v(sp, 0, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            VA_FENCE8(cur);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (b == 0 && i == 0) { VA_MFMA_NEW(s0, cur[0], qf[0]); VA_MFMA_NEW(s1, cur[1], qf[0]); }
+                else { VA_MFMA_V(s0, cur[2 * i], qf[4 * b + i]); VA_MFMA_V(s1, cur[2 * i + 1], qf[4 * b + i]); }
+            }
+        }, std::make_integer_sequence<int, NKB>{});
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15" ::: "memory");      // the last two MFMAs' results are in s0 / s1
+    };
+    auto max8 = [&]() VA_INLINE -> float {
+        return fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+    };
+    auto query_max = [&](float v) VA_INLINE -> float {   // over the 4 lanes (g) of a query
         v = fmaxf(v, __shfl_xor(v, 16));
         return fmaxf(v, __shfl_xor(v, 32));
     };
+    // keys of the last tile that do not exist get a score far below everything (their numerators are exactly 0)
+    auto mask_last = [&]() VA_INLINE {
+        const int kbase = (nt - 1) * VA_BN + 8 * g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (kbase + i >= P) s0[i] = -3.0e38f;
+            if (kbase + 4 + i >= P) s1[i] = -3.0e38f;
+        }
+    };
 
-    // ---- the offset: the query's maximum over the first key tile
-    issue(0, 0);
+    // ---- the offset: the query's maximum over the first key tile (scaled: log2 domain)
+    issue_any(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    scores(0, smem);
-    float m_off = query_max(max8());
+    scores(smem, false);
+    if (nt == 1) mask_last();
+    float m_off = query_max(max8()) * scale_log2e;
 
     f32x4 acc[CB];
-    float l_part = 0.f;          // this lane's share of the row sum (its 8 keys of every tile)
+    f32x4 lsum;                  // row sums on the matrix pipe: A = ones gives sum_k P^T[k][q] in every row (the sum of the bf16 numerators)
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        l_part = 0.f;
-        float mx = -1.0e30f;     // this lane's running maximum
+        lsum = f32x4{0.f, 0.f, 0.f, 0.f};
+        float mx = -3.0e38f;     // this lane's running maximum (raw scores)
         __syncthreads();         // stage 0 is free (the sample above / the previous pass)
-        issue(0, 0);
+        issue_any(0, 0);
         asm volatile("s_nop 7" ::: "memory");
         for (int t = 0; t < nt; ++t) {
             const int st = t & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile t have landed
             __syncthreads();                                      // everybody's have; everybody is done with tile t - 1 (the other stage)
-            if (t + 1 < nt) issue(t + 1, st ^ 1);
+            if (t + 1 < nt - 1) issue(t + 1, st ^ 1);
+            else if (t + 1 == nt - 1) issue_last(t + 1, st ^ 1);
             const uint8_t* sp = smem + st * STG;
-            scores(t, sp);
+            scores(sp, true);                                     // first V^T batch now in flight in (NKB odd ? fa : fb)
+            if (t == nt - 1) mask_last();
             mx = fmaxf(mx, max8());
-            // numerators (bf16) and their sum
-            uint32_t pk[4];
-            float psum = 0.f;
+            // numerators 2^(s c - m) as bf16: the B operand (k = 8 g + j) of O^T += V^T P^T
+            const float nm = -m_off;
+            const uint32_t p0 = pack_bf16x2(__builtin_amdgcn_exp2f(fmaf(s0[0], scale_log2e, nm)), __builtin_amdgcn_exp2f(fmaf(s0[1], scale_log2e, nm)));
+            const uint32_t p1 = pack_bf16x2(__builtin_amdgcn_exp2f(fmaf(s0[2], scale_log2e, nm)), __builtin_amdgcn_exp2f(fmaf(s0[3], scale_log2e, nm)));
+            const uint32_t p2 = pack_bf16x2(__builtin_amdgcn_exp2f(fmaf(s1[0], scale_log2e, nm)), __builtin_amdgcn_exp2f(fmaf(s1[1], scale_log2e, nm)));
+            const uint32_t p3 = pack_bf16x2(__builtin_amdgcn_exp2f(fmaf(s1[2], scale_log2e, nm)), __builtin_amdgcn_exp2f(fmaf(s1[3], scale_log2e, nm)));
+            bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4{p0, p1, p2, p3});
+            // the packs (VALU) feed MFMAs that hipcc does not recognise as such: an MFMA issued right behind v_cvt_pk_bf16_f32 read the
+            // OLD register contents (measured: row sums of garbage, run to run different) — wait states here, and the row-sum MFMA last
+            asm volatile("s_nop 7" : "+v"(pf));
+            va_for([&](auto bc_) VA_INLINE {
+                constexpr int b = decltype(bc_)::value;
+                (void)fa; (void)fb; (void)acc; (void)pf; (void)sp;
+                constexpr bool cur_is_fb = ((NKB + b) & 1) != 0;      // the batch `scores` left in flight continues the fa / fb alternation
+                bf16x8 (&cur)[8] = cur_is_fb ? fb : fa;
+                bf16x8 (&nxt)[8] = cur_is_fb ? fa : fb;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (b + 1 < NVB) read_v(sp, b + 1, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+                VA_FENCE8(cur);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float a = __builtin_amdgcn_exp2f(sv[2 * i] - m_off), b = __builtin_amdgcn_exp2f(sv[2 * i + 1] - m_off);
-                pk[i] = pack_bf16x2(a, b);
-                psum += lo_bf16(pk[i]) + hi_bf16(pk[i]);
-            }
-            l_part += psum;
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4{pk[0], pk[1], pk[2], pk[3]});
-            // O^T += V^T P^T, in place in the AGPRs ("+a": as a builtin hipcc selects the untied MFMA form here and copies all 128
-            // accumulators every tile; the constraint also makes it allocate AGPRs at all).  Not volatile: hipcc schedules the LDS
-            // reads around them.  Hazards hipcc cannot see (it does not count an asm MFMA's passes): the next reader of acc[cb] is this
-            // statement one tile later, or the code behind the loop (explicit s_nops there).
-            const uint8_t* vp = sp + v_x;
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vp + cb * 1024);
-                asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[cb]) : "v"(vf), "v"(pf));
-            }
+                for (int i = 0; i < 8; ++i) VA_MFMA_A(acc[8 * b + i], cur[i], pf);
+            }, std::make_integer_sequence<int, NVB>{});
+            VA_MFMA_A(lsum, ones, pf);
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last tile's MFMAs have retired
         if (pass == 1) break;
         // a numerator above 2^60 somewhere in the workgroup: once more with the exact maxima (then every numerator is <= 1)
-        const float qm = query_max(mx);
+        const float qm = query_max(mx) * scale_log2e;
         if (!__syncthreads_or(qm - m_off > VA_HEADROOM)) break;
         m_off = qm;
     }
 
-    // ---- epilogue: lane (g, r) holds O^T[16 cb + 4 g + i][query r]
-    float l = l_part;
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    const float inv = 1.0f / l;
+    // ---- epilogue: lane (g, r) holds O^T[16 cb + 4 g + i][query r]; every component of lsum is the row sum of query r
+    const float inv = 1.0f / lsum[0];
     if (q0 + r < P) {
         uint16_t* dst = O + (size_t)(q0 + r) * HD + 4 * g;
 #pragma unroll
