@@ -24,6 +24,7 @@
 //
 // Requirements: K % 64 == 0, rows 16-byte aligned (lda, ldw multiples of 8).
 // M and N are arbitrary (loads are clamped, stores are masked).
+#include <string.h>
 #include "dev.h"
 #include "kernels.h"
 #include <stdlib.h>
@@ -56,13 +57,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128x128_kernel(GemmBatch bat
     __shared__ __attribute__((aligned(16))) uint8_t smem[2 * 2 * BM * BK * 2];  // [buf][A|W][128][64] bf16 = 64 KB
 
     const int bid = blockIdx.x;
-    const int pi = (batch.nprob > 1 && bid >= batch.tile_start1) ? 1 : 0;
-    const GemmProblem& p = batch.p[pi];
+    const int pi = (batch.nprob > 1 && bid >= batch.tile_start[1]) ? 1 : 0;
+    // the descriptor read where it lies in the kernel-argument segment (indexing the by-value copy would move the batch to scratch)
+    using KProblem = const __attribute__((address_space(4))) GemmProblem;
+    KProblem& p = ((KProblem*)__builtin_amdgcn_kernarg_segment_ptr())[pi];
+    static_assert(offsetof(GemmBatch, p) == 0, "the problems are the first member of the only kernel argument");
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     // split-K (single-problem launches): workgroup = (K range `split`, tile `local`), split-major
     const int splits = batch.splits;
     const int split = splits > 1 ? bid / (tiles_m * tiles_n) : 0;
-    const int local = splits > 1 ? bid - split * (tiles_m * tiles_n) : bid - (pi ? batch.tile_start1 : 0);
+    const int local = splits > 1 ? bid - split * (tiles_m * tiles_n) : bid - (pi ? batch.tile_start[1] : 0);
     int tm, tn;
     tile_coords(local, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
@@ -299,6 +303,38 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmProblem p, 
     }
 }
 
+// The same reduction, four columns per thread (N % 4 == 0, rows and planes 16-byte aligned): the form behind the 256x256 kernel's
+// split-K (launch_gemm), whose workspaces are tens of MB.  Same order of additions as the scalar form: bit-identical results.
+__global__ __launch_bounds__(256) void gemm_splitk_reduce4_kernel(GemmProblem p, int splits) {
+    const int n4 = p.N >> 2;
+    const long total = (long)p.M * n4;
+    const size_t plane = (size_t)p.M * p.N;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int row = (int)(idx / n4), col = (int)(idx - (long)row * n4) * 4;
+        const size_t e = (size_t)row * p.N + col;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(p.splitk_ws + e);
+        for (int s = 1; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(p.splitk_ws + (size_t)s * plane + e);
+        if (p.epi == EPI_F32) {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + col) = acc * p.alpha;
+        } else if (p.epi == EPI_BF16) {
+            const f32x4 v = acc * p.alpha;
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + (size_t)row * p.ldc + col) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        } else if (p.epi == EPI_GATE_RESID) {
+            f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + col);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(p.vec + col);
+            *dst = *dst + g * acc;
+        } else {   // EPI_BIAS_BF16
+            f32x4 v = acc * p.alpha;
+            if (p.vec) v += *reinterpret_cast<const f32x4*>(p.vec + col);
+            if (p.resid) {
+                const uint2 r = *reinterpret_cast<const uint2*>(p.resid + (size_t)row * p.ldr + col);
+                v += f32x4{lo_bf16(r.x), hi_bf16(r.x), lo_bf16(r.y), hi_bf16(r.y)};
+            }
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.C) + (size_t)row * p.ldc + col) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+    }
+}
+
 // Fallback for shapes the MFMA kernel does not take (K % 64 != 0), e.g. the VAE's
 // 32->32 post_quant_conv.  One thread per output element, f32 accumulate.
 __global__ void gemm_naive_kernel(GemmProblem p) {
@@ -334,9 +370,52 @@ static int gemm_splitk_plan(int M, int N, int K) {
     if (s > nk / 8) s = nk / 8;
     return s < 2 ? 1 : (int)s;
 }
+// ---- split-K on the 256x256 kernel (gemm256s.hip): launches whose 256 x 256 tiles cover at most half of the 256 CUs and whose K is long
+// — the N = d GEMMs of the blocks at small sequence lengths: linear2 at 256^2 is 36 tiles (of K 12288) on 256 CUs.  The K-tiles of every
+// problem are cut into `s` ranges; each range is a problem of its own in the batch (A / W advanced along K, plain f32 output into its
+// plane of the workspace), one launch fills the chip, and the reduce kernel adds a problem's planes in range order and applies its real
+// epilogue: deterministic, no atomics.  Unchanged (s = 1) for every launch with more than 128 tiles: the 1024^2 shapes of every model.
+static bool splitk_epi_ok(int epi) { return epi == EPI_F32 || epi == EPI_BF16 || epi == EPI_GATE_RESID || epi == EPI_BIAS_BF16; }
+static int gemm256s_splitk_plan(const GemmProblem* probs, int nprob, bool need_ws) {
+    static const bool on = [] {
+        const char* e = F2_DEV_ENV("FLUX2MI_GEMM_SPLITK");
+        return e ? atoi(e) != 0 : true;
+    }();
+    if (!on || nprob < 1 || nprob > 2) return 1;
+    long tiles = 0;
+    int nk_min = 1 << 30;
+    for (int i = 0; i < nprob; ++i) {
+        const GemmProblem& q = probs[i];
+        if (q.fp8 || q.M <= 0 || q.N <= 0 || q.K <= 0 || q.K % 64 != 0 || !splitk_epi_ok(q.epi) || q.qk_qw || q.qk8 || q.col_perm16) return 1;
+        if ((q.N & 3) || (q.ldc & 3) || (reinterpret_cast<uintptr_t>(q.C) & 15) || (q.vec && (reinterpret_cast<uintptr_t>(q.vec) & 15)) ||
+            (q.resid && ((q.ldr & 3) || (reinterpret_cast<uintptr_t>(q.resid) & 7))))
+            return 1;
+        tiles += (long)((q.M + 255) / 256) * ((q.N + 255) / 256);
+        nk_min = q.K / 64 < nk_min ? q.K / 64 : nk_min;
+    }
+    if (tiles > 128 || nk_min < 16) return 1;
+    int s = GEMM_MAX_PROBS / nprob;
+    if (s > 256 / tiles) s = (int)(256 / tiles);
+    if (s > nk_min / 8) s = nk_min / 8;
+    if (need_ws)
+        for (int i = 0; i < nprob; ++i) {
+            const GemmProblem& q = probs[i];
+            if (!q.splitk_ws || (reinterpret_cast<uintptr_t>(q.splitk_ws) & 15)) return 1;
+            const size_t plane = (size_t)q.M * q.N * sizeof(float);
+            if (q.splitk_ws_bytes < (size_t)s * plane) s = (int)(q.splitk_ws_bytes / plane);
+        }
+    return s < 2 ? 1 : s;
+}
 size_t gemm_splitk_ws_bytes(int M, int N, int K) {
     const int s = gemm_splitk_plan(M, N, K);
-    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+    size_t need = s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+    // the 256x256 kernel's split-K: what a single-problem launch of this shape would take (a two-problem launch takes at most as much per problem)
+    GemmProblem q;
+    memset((void*)&q, 0, sizeof q);
+    q.M = M; q.N = N; q.K = K; q.epi = EPI_F32; q.ldc = N;
+    const int s2 = gemm256s_splitk_plan(&q, 1, false);
+    if (s2 > 1 && (size_t)s2 * M * N * sizeof(float) > need) need = (size_t)s2 * M * N * sizeof(float);
+    return need;
 }
 
 int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
@@ -377,6 +456,40 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
         }
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
+    // few tiles, long K: split-K on the 256x256 kernel (above)
+    {
+        const int sk = gemm256s_splitk_plan(probs, nprob, true);
+        if (sk > 1) {
+            GemmProblem sub[GEMM_MAX_PROBS];
+            int ns = 0;
+            for (int i = 0; i < nprob; ++i) {
+                const GemmProblem& q = probs[i];
+                const int nk = q.K / 64, chunk = (nk + sk - 1) / sk;
+                for (int j = 0; j < sk; ++j) {
+                    const int k0 = j * chunk, k1 = (j + 1) * chunk < nk ? (j + 1) * chunk : nk;
+                    GemmProblem& t = sub[ns++];
+                    memset((void*)&t, 0, sizeof t);
+                    t.A = q.A + (size_t)k0 * 64; t.lda = q.lda;
+                    t.W = q.W + (size_t)k0 * 64; t.ldw = q.ldw;
+                    t.C = q.splitk_ws + (size_t)j * q.M * q.N; t.ldc = q.N;
+                    t.M = q.M; t.N = q.N; t.K = (k1 > k0 ? k1 - k0 : 0) * 64;
+                    t.epi = EPI_F32; t.alpha = 1.0f;
+                }
+            }
+            bool ok = gemm256s_eligible(sub, ns);
+            for (int i = 0; i < ns; ++i) ok = ok && sub[i].K > 0;
+            if (ok) {
+                const int r = launch_gemm256s(stream, sub, ns);
+                if (r != 0) return r;
+                for (int i = 0; i < nprob; ++i) {
+                    const long total4 = (long)probs[i].M * (probs[i].N >> 2);
+                    const unsigned blocks = (unsigned)((total4 + 255) / 256 > 4096 ? 4096 : (total4 + 255) / 256);
+                    hipLaunchKernelGGL(gemm_splitk_reduce4_kernel, dim3(blocks), dim3(256), 0, stream, probs[i], sk);
+                }
+                return hipGetLastError() == hipSuccess ? 0 : 2;
+            }
+        }
+    }
     // large problems -> 256x256 LDS-DMA kernel (gemm256s.hip); FLUX2MI_GEMM=128|256 forces a kernel
     {
         static const int force = [] {
@@ -407,8 +520,10 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
         b.p[i] = probs[i];
         tiles[i] = ((probs[i].M + BM - 1) / BM) * ((probs[i].N + BN - 1) / BN);
     }
-    if (nprob == 1) b.p[1] = probs[0];
-    b.tile_start1 = tiles[0];
+    for (int i = nprob; i < GEMM_MAX_PROBS; ++i) b.p[i] = probs[0];
+    for (int i = 0; i < GEMM_MAX_PROBS; ++i) b.tile_start[i] = tiles[0] + tiles[1];
+    b.tile_start[0] = 0;
+    b.tile_start[1] = tiles[0];
     b.splits = 1;
     if (nprob == 1 && probs[0].splitk_ws != nullptr) {
         const GemmProblem& q = probs[0];

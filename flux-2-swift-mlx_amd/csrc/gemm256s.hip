@@ -206,13 +206,20 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
     constexpr int BMT = WIDE ? 512 : 32 * NI, WROWS = WIDE ? 128 : 16 * NI;
 
     const int bid = blockIdx.x;
-    const int pi = (batch.nprob > 1 && bid >= batch.tile_start1) ? 1 : 0;
+    // problem of this workgroup: the last one whose first workgroup is <= bid (constant indices: the by-value batch stays in the
+    // kernel-argument segment)
+    int pi = 0, pstart = 0;
+    if (batch.nprob > 1) {
+#pragma unroll
+        for (int k = 1; k < GEMM_MAX_PROBS; ++k)
+            if (k < batch.nprob && bid >= batch.tile_start[k]) { pi = k; pstart = batch.tile_start[k]; }
+    }
     // the descriptor of this tile's problem, read where it lies in the kernel-argument segment (scalar loads): indexing the by-value
     // copy with `pi` makes hipcc move the whole batch to scratch once the struct is large enough
     using KProblem = const __attribute__((address_space(4))) GemmProblem;
     KProblem& p = ((KProblem*)__builtin_amdgcn_kernarg_segment_ptr())[pi];
     static_assert(offsetof(GemmBatch, p) == 0, "the problems are the first member of the only kernel argument");
-    const int local = bid - (pi ? batch.tile_start1 : 0);
+    const int local = bid - pstart;
     const int tiles_m = (p.M + BMT - 1) / BMT, tiles_n = (p.N + TN - 1) / TN;
     int tm, tn;
     tile_coords_s(local, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
@@ -1591,7 +1598,9 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
     // convolutions with <= 128 output channels: the 512 x 128 tile (a 256-column tile would idle half of every MFMA)
     const bool wide = probs[0].epi == EPI_CONV && nprob == 1 && probs[0].N <= 128;
     if (wide) ni = 8;
-    int tiles[2] = {0, 0};
+    if (nprob < 1 || nprob > GEMM_MAX_PROBS) return 1;
+    int tiles[GEMM_MAX_PROBS] = {};
+    int total_tiles = 0;
     for (int i = 0; i < nprob; ++i) {
         b.p[i] = probs[i];
         const GemmProblem& q = probs[i];   // fused QK norm + RoPE: whole heads per tile, 16-byte row stores
@@ -1605,11 +1614,14 @@ int launch_gemm256s(hipStream_t stream, const GemmProblem* probs, int nprob) {
             return 1;
         tiles[i] = wide ? ((q.M + 511) / 512) * ((q.N + 127) / 128) : ((q.M + 32 * ni - 1) / (32 * ni)) * ((q.N + TN - 1) / TN);
     }
-    if (nprob == 1) b.p[1] = probs[0];
-    b.tile_start1 = tiles[0];
+    for (int i = nprob; i < GEMM_MAX_PROBS; ++i) b.p[i] = probs[0];
+    for (int i = 0; i < GEMM_MAX_PROBS; ++i) {
+        b.tile_start[i] = total_tiles;
+        total_tiles += tiles[i];
+    }
     b.flags = 1;   // 16-byte bf16 / SwiGLU epilogue stores
     b.trace = nullptr;
-    const dim3 grid(tiles[0] + tiles[1]), block(256);
+    const dim3 grid(total_tiles), block(256);
     static const char* trace_env = F2_DEV_ENV("FLUX2MI_GEMM_TRACE");
     static int seen = 0;
     const size_t tn = (size_t)grid.x * 32;   // 8 words per wave

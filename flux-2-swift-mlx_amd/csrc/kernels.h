@@ -102,10 +102,13 @@ struct GemmProblem {
     // tensor for its statistics.  nullptr = off.
     float* gn_part;
 };
+// Problems of one launch: callers batch at most two (the text / image halves of a double block); the launcher's own split-K form
+// (gemm.hip) expands them into up to GEMM_MAX_PROBS K ranges, each a problem of its own.
+constexpr int GEMM_MAX_PROBS = 8;
 struct GemmBatch {
-    GemmProblem p[2];
+    GemmProblem p[GEMM_MAX_PROBS];
     int nprob;
-    int tile_start1;
+    int tile_start[GEMM_MAX_PROBS];   // first workgroup of problem i (tile_start[0] = 0)
     int flags;    // gemm256: bit 0 = 16-byte bf16 epilogue stores
     unsigned long long* trace;   // gemm256: per-wave time stamps (dev tool), nullptr normally
     int splits;   // 128x128 kernel: K ranges per tile (1 = whole K in one workgroup)
