@@ -222,7 +222,10 @@ def lib() -> C.CDLL:
             f"(`python -c 'import __graft_entry__ as g; g.build()'` or `make -C {_HERE}/csrc`). "
             "There is no CPU fallback.")
     handle = C.CDLL(LIB_PATH)
+    older_build = "FLUX2MI_LIB" in os.environ   # tools/ab_libs.sh: an earlier round's library for a same-box A/B may lack this round's entry points
     for name, (res, args) in PROTOTYPES.items():
+        if older_build and not hasattr(handle, name):
+            continue
         fn = getattr(handle, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
