@@ -295,6 +295,8 @@ int launch_nchw_f32_to_nhwc_bf16(hipStream_t stream, const float* in, uint16_t* 
 int launch_nchw_f32_to_nhwc_bf16_padded(hipStream_t stream, const float* in, uint16_t* out, int C, int C_pad, int H, int W);
 // NHWC bf16 [P, C] channels [c0, c0+n) -> f32 [n, P] (NCHW)
 int launch_nhwc_bf16_to_nchw_f32(hipStream_t stream, const uint16_t* in, float* out, int C, int c0, int n, int64_t P);
+// OHWI [cout_pad][3][3][cin] -> [cout_pad][3][seg] (a kernel row's 3 * cin values, zero-padded to seg % 64 == 0): vae.cpp, convolutions with cin % 64 != 0
+int launch_conv_w_taprow(hipStream_t stream, const uint16_t* w, int cout_pad, int cin, int seg, uint16_t* out);
 int launch_softmax_rows(hipStream_t stream, const float* in, uint16_t* out, int rows, int cols);
 // vae_attention.hip — the VAE mid block's single-head attention as ONE streaming kernel (no P x P scores in HBM); head dim 512 / 384.
 // O [P, C] bf16 = softmax(Q K^T * scale) V + vbias; Q, K [P, C] bf16 row-major, V^T [C][ldv] bf16 with ldv >= ceil32(P), ldv % 8 == 0 and

@@ -20,6 +20,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include <memory>
 #include "common.h"
 #include "kernels.h"
 
@@ -38,7 +39,7 @@ struct Param {
     int i_pad = 0;         // conv: input channels padded to this count (conv_in of the encoder)
 };
 
-struct ConvW { int w = -1, b = -1, cin = 0, cout = 0, ks = 0; };
+struct ConvW { int w = -1, b = -1, cin = 0, cout = 0, ks = 0; int seg_w = -1, seg = 0; };   // seg_w: index into flux2mi_vae::taprow_w (cin % 64 != 0)
 struct GNW { int g = -1, b = -1, c = 0; };
 struct LinW { int w = -1, b = -1; };
 struct ResnetW { GNW n1, n2; ConvW c1, c2, sc; bool has_sc = false; };
@@ -60,6 +61,9 @@ struct flux2mi_vae {
     ResnetW up[4][3];
     ConvW upsample[3];
     DevBuf up_phase[3];                 // the upsample convolutions as four 2x2 convolutions (launch_upsample_phase_weights), built by finalize
+    // 3x3 convolutions whose channel count is not a multiple of 64 (the small decoder's 96): weights re-laid out per kernel ROW (3 * cin values
+    // + zeros to a whole number of K-tiles) so that they run on the GEMM kernel too (conv_gemm); built by finalize, one per such convolution
+    std::vector<std::unique_ptr<DevBuf>> taprow_w;
     int bn_mean = -1, bn_var = -1;
     // encoder side
     ConvW e_conv_in, e_conv_out, e_quant, e_down[3];
@@ -241,6 +245,7 @@ extern "C" int flux2mi_vae_destroy(flux2mi_vae* v) {
                       &v->av, &v->avt, &v->scores, &v->probs, &v->gn_partial, &v->gn_ab, &v->zin, &v->img_in, &v->gn_chan};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : v->up_phase) b.release();
+    for (auto& b : v->taprow_w) b->release();
     delete v;
     return FLUX2MI_OK;
 }
@@ -306,6 +311,33 @@ extern "C" int flux2mi_vae_finalize(flux2mi_vae* v) {
         F2_TRY(v->up_phase[i].reserve((size_t)16 * cout_pad * c.cin * 2));
         F2_LAUNCH(launch_upsample_phase_weights(v->ctx->stream, reinterpret_cast<const uint16_t*>(v->params[c.w].ptr), cout_pad, c.cin,
                                                 v->up_phase[i].as<uint16_t>()), "upsample_phase_weights");
+    }
+    // the decoder's 3x3 convolutions with cin % 64 != 0 (small decoder, 96 channels): tap-row weights for the GEMM kernel
+    {
+        static const bool on = [] {
+            const char* e = F2_DEV_ENV("FLUX2MI_VAE_TAPROW");
+            return e ? atoi(e) != 0 : true;
+        }();
+        v->taprow_w.clear();
+        auto prep = [&](ConvW& c) -> int {
+            c.seg_w = -1;
+            if (!on || c.w < 0 || c.ks != 3 || c.cin % 64 == 0 || c.cin % 32 != 0 || c.cin < 64 || v->params[c.w].i_pad) return FLUX2MI_OK;
+            const int cout_pad = pad32(c.cout);
+            c.seg = ((3 * c.cin + 63) / 64) * 64;
+            auto buf = std::make_unique<DevBuf>();
+            buf->keep = true;
+            F2_TRY(buf->reserve((size_t)cout_pad * 3 * c.seg * 2));
+            F2_LAUNCH(launch_conv_w_taprow(v->ctx->stream, reinterpret_cast<const uint16_t*>(v->params[c.w].ptr), cout_pad, c.cin, c.seg,
+                                           buf->as<uint16_t>()), "conv_w_taprow");
+            c.seg_w = (int)v->taprow_w.size();
+            v->taprow_w.push_back(std::move(buf));
+            return FLUX2MI_OK;
+        };
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 3; ++j) {
+                F2_TRY(prep(v->up[i][j].c1));
+                F2_TRY(prep(v->up[i][j].c2));
+            }
     }
     F2_CHECK_HIP(hipStreamSynchronize(v->ctx->stream));
     v->finalized = true;
@@ -393,7 +425,7 @@ struct Dec {
         // the kernel's per-lane source offsets are 32-bit: the zero-haloed operand must stay under 4 GB (2048^2 x 256 channels does; larger
         // images take the gather kernels)
         const bool off_ok = (unsigned long long)(H + 2) * (unsigned long long)(Wd + 2) * (unsigned long long)c.cin * 2ull < (1ull << 32);
-        return on && c.ks == 3 && c.cin % 64 == 0 && c.cout % 4 == 0 && n_ok && off_ok && H >= 8 && Wd >= 8 && (long)H * Wd >= 4096;
+        return on && c.ks == 3 && (c.cin % 64 == 0 || c.seg_w >= 0) && c.cout % 4 == 0 && n_ok && off_ok && H >= 8 && Wd >= 8 && (long)H * Wd >= 4096;
     }
     // GroupNorm(+SiLU) of plain x -> zero-haloed y
     int gn_padded(const GNW& g, const uint16_t* x, uint16_t* y, int H, int Wd, int silu) {
@@ -416,6 +448,14 @@ struct Dec {
         p.M = H * wp - 2; p.N = c.cout; p.K = 9 * c.cin; p.epi = EPI_CONV; p.alpha = 1.0f;
         p.vec = F(c.b); p.resid = resid; p.ldr = c.cout;
         p.conv_seg = 3 * (c.cin / 64); p.conv_row_jump = (long long)(wp - 3) * c.cin * 2;
+        if (c.cin % 64 != 0) {
+            // cin % 64 != 0 (96): the K segment is a kernel ROW — its 3 * cin values are contiguous in the zero-haloed image — padded to whole
+            // K-tiles; the pad columns of the weights are zero, the image bytes under them are the next pixel's first channels (finite), and
+            // behind the image's last pixel 128 zero bytes (the buffer has the room: it is sized for the widest level)
+            p.W = v->taprow_w[c.seg_w]->as<uint16_t>(); p.ldw = 3 * c.seg; p.K = 3 * c.seg;
+            p.conv_seg = c.seg / 64; p.conv_row_jump = ((long long)wp * c.cin - c.seg) * 2;
+            F2_CHECK_HIP(hipMemsetAsync(const_cast<uint16_t*>(xp) + (size_t)(H + 2) * wp * c.cin, 0, 128, st));
+        }
         p.conv_wp = wp; p.conv_w = Wd; p.conv_out_padded = y_padded ? 1 : 0;
         int srows = 0;
         if (!y_padded) {   // a plain output feeds a GroupNorm next: its statistics come out of this launch's epilogue
@@ -592,7 +632,7 @@ extern "C" int flux2mi_vae_decode(flux2mi_vae* v, const float* z, int h, int w, 
         }
         if (padded > max_elems) max_elems = padded;
     }
-    for (int i = 0; i < 4; ++i) F2_TRY(v->act[i].reserve(max_elems * 2));
+    for (int i = 0; i < 4; ++i) F2_TRY(v->act[i].reserve(max_elems * 2 + 256));   // + the zeroed pad behind a tap-row operand (conv_gemm)
     F2_TRY(v->zin.reserve((size_t)h * w * 32 * 2));
     Dec d{v, v->ctx->stream};
     uint16_t* A = v->act[0].as<uint16_t>();
@@ -674,7 +714,7 @@ extern "C" int flux2mi_vae_encode(flux2mi_vae* v, const float* image, int H, int
         const size_t ch = (size_t)c.channels[i];
         if (hw * ch > max_elems) max_elems = hw * ch;
     }
-    for (int i = 0; i < 4; ++i) F2_TRY(v->act[i].reserve(max_elems * 2));
+    for (int i = 0; i < 4; ++i) F2_TRY(v->act[i].reserve(max_elems * 2 + 256));   // + the zeroed pad behind a tap-row operand (conv_gemm)
     F2_TRY(v->img_in.reserve((size_t)H * W * 32 * 2));
     Dec d{v, v->ctx->stream};
     uint16_t* A = v->act[0].as<uint16_t>();

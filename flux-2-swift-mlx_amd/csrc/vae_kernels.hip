@@ -756,12 +756,31 @@ __global__ __launch_bounds__(256) void upsample_phase_weights_kernel(const uint1
 
 }  // namespace
 
+// OHWI [cout_pad][3][3][cin] -> [cout_pad][3][seg]: the three taps of a kernel row (3 * cin values, contiguous in the zero-haloed NHWC
+// image too) followed by zeros up to seg = a whole number of 64-deep K-tiles.  The GEMM convolution (gemm256s, GemmProblem::conv_*) then
+// takes channel counts that are not a multiple of 64 (the small decoder's 96): a tap ROW is its K segment instead of a tap.
+__global__ void conv_w_taprow_kernel(const uint16_t* __restrict__ w, int cout_pad, int cin, int seg, uint16_t* __restrict__ out) {
+    const long total = (long)cout_pad * 3 * seg;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % seg);
+        const long row = i / seg;                       // o * 3 + ky
+        out[i] = k < 3 * cin ? w[row * 3 * cin + k] : (uint16_t)0;
+    }
+}
+
 #define VK_DONE() return hipGetLastError() == hipSuccess ? 0 : 2
 
 int launch_upsample_phase_weights(hipStream_t stream, const uint16_t* w, int cout_pad, int cin, uint16_t* w_phase) {
     if (!w || !w_phase || cout_pad <= 0 || cin <= 0) return 1;
     const long total = (long)16 * cout_pad * cin;
     hipLaunchKernelGGL(upsample_phase_weights_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, stream, w, cout_pad, cin, w_phase);
+    VK_DONE();
+}
+
+int launch_conv_w_taprow(hipStream_t stream, const uint16_t* w, int cout_pad, int cin, int seg, uint16_t* out) {
+    if (!w || !out || cout_pad <= 0 || cin <= 0 || seg < 3 * cin || (seg & 63)) return 1;
+    const long total = (long)cout_pad * 3 * seg;
+    hipLaunchKernelGGL(conv_w_taprow_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, stream, w, cout_pad, cin, seg, out);
     VK_DONE();
 }
 
