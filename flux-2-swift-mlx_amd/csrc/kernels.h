@@ -299,7 +299,8 @@ int launch_nhwc_bf16_to_nchw_f32(hipStream_t stream, const uint16_t* in, float* 
 int launch_conv_w_taprow(hipStream_t stream, const uint16_t* w, int cout_pad, int cin, int seg, uint16_t* out);
 int launch_softmax_rows(hipStream_t stream, const float* in, uint16_t* out, int rows, int cols);
 // vae_attention.hip — the VAE mid block's single-head attention as ONE streaming kernel (no P x P scores in HBM); head dim 512 / 384.
-// O [P, C] bf16 = softmax(Q K^T * scale) V + vbias; Q, K [P, C] bf16 row-major, V^T [C][ldv] bf16 with ldv >= ceil32(P), ldv % 8 == 0 and
+// O [P, C] bf16 = softmax(Q K^T * scale) V + vbias; Q [P, C], K [ceil32(P), C] bf16 row-major (K's rows behind P: readable, any values),
+// V^T [C][ldv] bf16 with ldv >= ceil32(P), ldv % 8 == 0 and
 // FINITE values in the columns P .. ceil32(P) - 1; vbias f32 [C] or NULL.  0 ok / 1 unsupported / 2 launch error.
 bool vae_attention_supported(int C);
 int launch_vae_attention(hipStream_t stream, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, int ldv, const float* vbias,

@@ -586,7 +586,7 @@ struct Dec {
     int attention_streaming(const AttnW& w, uint16_t* A, uint16_t* B, int P, int C) {
         const size_t pc = (size_t)P * C * 2;
         const int ldv = (P + 31) & ~31;
-        F2_TRY(v->aq.reserve(pc)); F2_TRY(v->ak.reserve(pc)); F2_TRY(v->av.reserve(pc)); F2_TRY(v->avt.reserve((size_t)C * ldv * 2));
+        F2_TRY(v->aq.reserve(pc)); F2_TRY(v->ak.reserve((size_t)ldv * C * 2)); F2_TRY(v->av.reserve(pc)); F2_TRY(v->avt.reserve((size_t)C * ldv * 2));   // K: ceil32(P) readable rows
         F2_TRY(gn(w.gn, A, B, P, 0));
         F2_TRY(lin(w.q, B, v->aq.as<uint16_t>(), P, C, nullptr));
         F2_TRY(lin(w.k, B, v->ak.as<uint16_t>(), P, C, nullptr));
@@ -766,8 +766,17 @@ extern "C" int flux2mi_op_vae_attention(flux2mi_ctx* ctx, const void* q, const v
         F2_CHECK_HIP(hipMemcpy2DAsync(vt, (size_t)ldv * 2, tmp.ptr, (size_t)P * 2, (size_t)P * 2, C, hipMemcpyDeviceToDevice, ctx->stream));
         F2_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // tmp is released on return
     }
+    // the kernel reads ceil32(P) key rows (the pad rows' scores are masked): a caller's [P, C] buffer ends at row P
+    DevBuf kpad;
+    const uint16_t* kk = reinterpret_cast<const uint16_t*>(k);
+    if (ldv != P) {
+        F2_TRY(kpad.reserve((size_t)ldv * C * 2));
+        F2_CHECK_HIP(hipMemcpyAsync(kpad.ptr, k, (size_t)P * C * 2, hipMemcpyDeviceToDevice, ctx->stream));
+        kk = kpad.as<uint16_t>();
+    }
+    struct SyncAtExit { hipStream_t s; bool on; ~SyncAtExit() { if (on) (void)hipStreamSynchronize(s); } } sync_at_exit{ctx->stream, ldv != P};   // kpad is released on return
     prof_before(ctx, PROF_VAE_ATTN);
-    const int r = launch_vae_attention(ctx->stream, reinterpret_cast<const uint16_t*>(q), reinterpret_cast<const uint16_t*>(k), vt, ldv, nullptr,
+    const int r = launch_vae_attention(ctx->stream, reinterpret_cast<const uint16_t*>(q), kk, vt, ldv, nullptr,
                                        reinterpret_cast<uint16_t*>(out), P, C, 1.0f / sqrtf((float)C));
     prof_after(ctx, PROF_VAE_ATTN, 4.0 * (double)P * (double)P * C);
     F2_LAUNCH(r, "op_vae_attention");

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64 * VA_NW, 1) void vae_attention_kernel(const uint
     constexpr int NKB = KS / 4;                   // fragment batches of Q K^T: 4 k-steps x 2 key blocks = 8 reads each
     constexpr int NVB = CB / 8;                   // fragment batches of P V: 8 column blocks each
     static_assert(HD % 128 == 0 && CB % VA_NW == 0 && VA_BN % VA_NW == 0 && CB % 8 == 0, "tile shape");
-    __shared__ __attribute__((aligned(1024))) uint8_t smem[2 * STG];
+    __shared__ __attribute__((aligned(1024))) uint8_t smem[2 * STG];   // K slots 0, 1 (2 x KT), then V^T slots 0, 1 (2 x VT)
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -104,34 +104,19 @@ __global__ __launch_bounds__(64 * VA_NW, 1) void vae_attention_kernel(const uint
     for (int j = 0; j < CPW; ++j) vo_v[j] = ((uint32_t)(16 * j + r) * (uint32_t)ldv + 8u * (uint32_t)g) * 2u;
     const uint8_t* k_src = reinterpret_cast<const uint8_t*>(K) + (size_t)(wid * KPW) * (HD * 2);               // + tile * 32 rows
     const uint8_t* v_src = reinterpret_cast<const uint8_t*>(Vt) + (size_t)(16 * wid * CPW) * (size_t)ldv * 2;   // + tile * 64 bytes
-    const uint32_t m0_k = lds_base + (uint32_t)(wid * KPW) * KROW, m0_v = lds_base + KT + (uint32_t)(wid * CPW) * 1024u;
+    const uint32_t m0_k = lds_base + (uint32_t)(wid * KPW) * KROW, m0_v = lds_base + 2 * KT + (uint32_t)(wid * CPW) * 1024u;
 #define VA_DMA(vo_, sb_, m0_, off_) \
     asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo_), "s"(sb_), "s"(m0_), "i"(off_) : "memory", "scc")
-    // every tile but the last: whole rows exist
-    auto issue = [&](int tile, int st) VA_INLINE {
+    // K has ceil32(P) readable rows (launch_vae_attention's contract): every tile's rows exist.  K slots [0, 2 KT), V^T slots behind them.
+    auto issue_k = [&](int tile, int slot) VA_INLINE {
         const uint8_t* ks_ = k_src + (size_t)tile * (VA_BN * HD * 2);
-        const uint8_t* vs_ = v_src + (size_t)tile * (VA_BN * 2);
-        const uint32_t mk = m0_k + (uint32_t)st * STG, mv = m0_v + (uint32_t)st * STG;
+        const uint32_t mk = m0_k + (uint32_t)slot * KT;
         va_for([&](auto jc) VA_INLINE { constexpr int j = decltype(jc)::value; (void)vo_k; (void)ks_; (void)mk; VA_DMA(vo_k[j], ks_, mk, j * KROW); }, std::make_integer_sequence<int, KPW>{});
-        va_for([&](auto jc) VA_INLINE { constexpr int j = decltype(jc)::value; (void)vo_v; (void)vs_; (void)mv; VA_DMA(vo_v[j], vs_, mv, j * 1024); }, std::make_integer_sequence<int, CPW>{});
     };
-    // the last tile: rows behind the last key re-read row P - 1 (finite scores, masked below); V^T columns exist up to ldv (finite)
-    auto issue_last = [&](int tile, int st) VA_INLINE {
+    auto issue_v = [&](int tile, int slot) VA_INLINE {
         const uint8_t* vs_ = v_src + (size_t)tile * (VA_BN * 2);
-        const uint32_t mk = m0_k + (uint32_t)st * STG, mv = m0_v + (uint32_t)st * STG;
-        va_for([&](auto jc) VA_INLINE {
-            constexpr int j = decltype(jc)::value;
-            (void)vo_k; (void)mk;
-            const int row = min(tile * VA_BN + wid * KPW + j, P - 1);
-            const uint8_t* ks_ = reinterpret_cast<const uint8_t*>(K) + (size_t)row * (HD * 2);
-            const uint32_t vo = vo_k[j] - (uint32_t)j * (HD * 2);
-            VA_DMA(vo, ks_, mk, j * KROW);
-        }, std::make_integer_sequence<int, KPW>{});
+        const uint32_t mv = m0_v + (uint32_t)slot * VT;
         va_for([&](auto jc) VA_INLINE { constexpr int j = decltype(jc)::value; (void)vo_v; (void)vs_; (void)mv; VA_DMA(vo_v[j], vs_, mv, j * 1024); }, std::make_integer_sequence<int, CPW>{});
-    };
-    auto issue_any = [&](int tile, int st) VA_INLINE {
-        if (tile == nt - 1) issue_last(tile, st);
-        else issue(tile, st);
     };
 
     // ---- fragment addresses.  K: A row r of key block kb is key 8 (r >> 2) + 4 kb + (r & 3); chunk (4 ks + g) ^ r
@@ -139,7 +124,7 @@ __global__ __launch_bounds__(64 * VA_NW, 1) void vae_attention_kernel(const uint
     uint32_t k_x[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) k_x[j] = k_row + ((((uint32_t)(4 * j + g)) ^ (uint32_t)r) << 4);
-    const uint32_t v_x = KT + (uint32_t)lane * 16u;
+    const uint32_t v_x = (uint32_t)lane * 16u;
 
     bf16x8 ones;
 #pragma unroll
@@ -159,16 +144,17 @@ __global__ __launch_bounds__(64 * VA_NW, 1) void vae_attention_kernel(const uint
         for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const bf16x8*>(sp + v_x + (8 * b + i) * 1024);
     };
     // S^T = K Q^T of the tile staged at `sp`; leaves the first V^T batch requested in fa when with_v
-    auto scores = [&](const uint8_t* sp, bool with_v) VA_INLINE {
+    auto scores = [&](const uint8_t* sp, auto&& after_first_reads) VA_INLINE {
         read_k(sp, 0, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        after_first_reads();          // the DMA requests of this hand-over go out under the latency of the first fragment reads
         va_for([&](auto bc_) VA_INLINE {
             constexpr int b = decltype(bc_)::value;
-            (void)fa; (void)fb; (void)qf; (void)s0; (void)s1; (void)sp; (void)with_v;
+            (void)fa; (void)fb; (void)qf; (void)s0; (void)s1; (void)sp;
             bf16x8 (&cur)[8] = (b & 1) ? fb : fa;
             bf16x8 (&nxt)[8] = (b & 1) ? fa : fb;
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (b + 1 < NKB) read_k(sp, b + 1, nxt);
-            else if (with_v) read_v(sp, 0, nxt);
             __builtin_amdgcn_sched_barrier(0);
             VA_FENCE8(cur);
 #pragma unroll
@@ -198,13 +184,19 @@ __global__ __launch_bounds__(64 * VA_NW, 1) void vae_attention_kernel(const uint
     };
 
     // ---- the offset: the query's maximum over the first key tile (scaled: log2 domain)
-    issue_any(0, 0);
+    issue_k(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    scores(smem, false);
+    scores(smem, [] {});
     if (nt == 1) mask_last();
     float m_off = query_max(max8()) * scale_log2e;
 
+    // ---- the tile loop.  K and V^T have their own two-slot rings and their own hand-over per tile, so that each operand is requested
+    // a tile and a half before its first read (the loop is bound by the latency of the LDS-DMA, not its rate: with one hand-over per tile —
+    // K and V^T requested together, one tile ahead — it ran 6-15 % slower when the requests were issued half a tile later):
+    //   top of tile t:  K(t) has landed everywhere, P V(t-1) is done everywhere  -> request V^T(t+1) into V slot (t+1)&1;  Q K^T(t)
+    //   mid of tile t:  V^T(t) has landed everywhere, Q K^T(t) is done everywhere -> request K(t+2) into K slot t&1;  softmax, P V(t)
+    // Requests in program order: K0 V0 K1 | V1 | K2 | V2 | ...: behind K(t) there are V(t) and K(t+1), behind V(t) there are K(t+1), V(t+1).
     f32x4 acc[CB];
     f32x4 lsum;                  // row sums on the matrix pipe: A = ones gives sum_k P^T[k][q] in every row (the sum of the bf16 numerators)
     for (int pass = 0; pass < 2; ++pass) {
@@ -212,17 +204,19 @@ __global__ __launch_bounds__(64 * VA_NW, 1) void vae_attention_kernel(const uint
         for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
         lsum = f32x4{0.f, 0.f, 0.f, 0.f};
         float mx = -3.0e38f;     // this lane's running maximum (raw scores)
-        __syncthreads();         // stage 0 is free (the sample above / the previous pass)
-        issue_any(0, 0);
+        __syncthreads();         // every slot is free (the sample above / the previous pass)
+        issue_k(0, 0);
+        issue_v(0, 0);
+        if (nt > 1) issue_k(1, 1);
         asm volatile("s_nop 7" ::: "memory");
         for (int t = 0; t < nt; ++t) {
-            const int st = t & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile t have landed
-            __syncthreads();                                      // everybody's have; everybody is done with tile t - 1 (the other stage)
-            if (t + 1 < nt - 1) issue(t + 1, st ^ 1);
-            else if (t + 1 == nt - 1) issue_last(t + 1, st ^ 1);
-            const uint8_t* sp = smem + st * STG;
-            scores(sp, true);                                     // first V^T batch now in flight in (NKB odd ? fa : fb)
+            const int sl = t & 1;
+            const bool more = t + 1 < nt;
+            // K(t): everything but the V^T(t) and K(t+1) requests behind it
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(KPW + CPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(CPW) : "memory");
+            __syncthreads();
+            scores(smem + sl * KT, [&]() VA_INLINE { if (more) issue_v(t + 1, sl ^ 1); });
             if (t == nt - 1) mask_last();
             mx = fmaxf(mx, max8());
             // numerators 2^(s c - m) as bf16: the B operand (k = 8 g + j) of O^T += V^T P^T
@@ -232,17 +226,24 @@ __global__ __launch_bounds__(64 * VA_NW, 1) void vae_attention_kernel(const uint
             const uint32_t p2 = pack_bf16x2(__builtin_amdgcn_exp2f(fmaf(s1[0], scale_log2e, nm)), __builtin_amdgcn_exp2f(fmaf(s1[1], scale_log2e, nm)));
             const uint32_t p3 = pack_bf16x2(__builtin_amdgcn_exp2f(fmaf(s1[2], scale_log2e, nm)), __builtin_amdgcn_exp2f(fmaf(s1[3], scale_log2e, nm)));
             bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4{p0, p1, p2, p3});
+            // V^T(t): everything but the K(t+1) and V^T(t+1) requests behind it (the last tile: nothing is behind it)
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(KPW + CPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const uint8_t* spv = smem + 2 * KT + sl * VT;
+            read_v(spv, 0, fa);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < nt) issue_k(t + 2, sl);
             // the packs (VALU) feed MFMAs that hipcc does not recognise as such: an MFMA issued right behind v_cvt_pk_bf16_f32 read the
             // OLD register contents (measured: row sums of garbage, run to run different) — wait states here, and the row-sum MFMA last
             asm volatile("s_nop 7" : "+v"(pf));
             va_for([&](auto bc_) VA_INLINE {
                 constexpr int b = decltype(bc_)::value;
-                (void)fa; (void)fb; (void)acc; (void)pf; (void)sp;
-                constexpr bool cur_is_fb = ((NKB + b) & 1) != 0;      // the batch `scores` left in flight continues the fa / fb alternation
-                bf16x8 (&cur)[8] = cur_is_fb ? fb : fa;
-                bf16x8 (&nxt)[8] = cur_is_fb ? fa : fb;
+                (void)fa; (void)fb; (void)acc; (void)pf; (void)spv;
+                bf16x8 (&cur)[8] = (b & 1) ? fb : fa;
+                bf16x8 (&nxt)[8] = (b & 1) ? fa : fb;
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (b + 1 < NVB) read_v(sp, b + 1, nxt);
+                if constexpr (b + 1 < NVB) read_v(spv, b + 1, nxt);
                 __builtin_amdgcn_sched_barrier(0);
                 VA_FENCE8(cur);
 #pragma unroll
@@ -277,7 +278,8 @@ __global__ __launch_bounds__(64 * VA_NW, 1) void vae_attention_kernel(const uint
 // true when launch_vae_attention takes head dim C
 bool vae_attention_supported(int C) { return C == 512 || C == 384; }
 
-// O [P, C] bf16 = softmax(Q K^T * scale) V + vbias, with Q, K [P, C] bf16 row-major and V^T [C][ldv] bf16 (ldv >= ceil32(P), the
+// O [P, C] bf16 = softmax(Q K^T * scale) V + vbias, with Q [P, C], K [ceil32(P), C] bf16 row-major (the rows behind P: readable, any values —
+// their scores are masked) and V^T [C][ldv] bf16 (ldv >= ceil32(P), the
 // columns P .. ceil32(P) - 1 finite — zero; ldv % 8 == 0).  vbias f32 [C] or NULL.  Returns 0 ok / 1 unsupported / 2 launch error.
 int launch_vae_attention(hipStream_t stream, const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, int ldv, const float* vbias,
                          uint16_t* O, int P, int C, float scale) {
