@@ -8,8 +8,9 @@
 //   * workgroup = 4 waves x 16 queries; a wave keeps its 16 queries' Q as MFMA B fragments (HD/32 x 4 VGPRs) and O^T for them as
 //     HD/16 accumulator quads (HD 512: 128 registers) — head dim 512 leaves no room for more than 16 queries per wave;
 //   * keys in tiles of 32: K [32 keys][HD] and V^T [HD][32 keys] of a tile are staged ONCE per workgroup into LDS by LDS-DMA
-//     (global_load_lds_dwordx4, 1 KB per wave instruction, no VGPR round trip), two stages, one barrier per tile: the DMA of tile t + 1
-//     runs under the MFMAs of tile t;
+//     (global_load_lds_dwordx4, 1 KB per wave instruction, no VGPR round trip).  K and V^T have their own two-slot rings and their own
+//     hand-over (barrier) per tile, so that each operand is requested a tile and a half before its first read: the loop is bound by
+//     the latency of the DMA, not by any rate (profiles/NOTEBOOK.md, round 6);
 //   * both products swapped so that a probability never leaves its lane: S^T = K Q^T (v_mfma_f32_16x16x32_bf16, A = K fragment from
 //     LDS, B = Q), lane (g, q) of the result holds keys of query q only; the A rows of key block kb are ASSIGNED keys
 //     8 (row >> 2) + 4 kb + (row & 3), so the lane's 4 + 4 results are keys 8g .. 8g + 7 in order — exactly the B fragment (k = 8g + j)
@@ -24,8 +25,10 @@
 //     with the exact maxima as offsets — exact for any scores, paid only by inputs that need it.  Row sums are the sums of the
 //     bf16-ROUNDED numerators, i.e. of what P V multiplies;
 //   * the value bias is added at the end (softmax rows sum to 1): V^T comes from a role-swapped GEMM without a bias epilogue.
-// MFMA work 4 P^2 HD; per tile and workgroup 64 KB of L2 -> LDS and 256 KB of LDS reads per 1024 MFMA cycles per wave: the kernel is
-// bound by those two streams, not the matrix pipe.
+// MFMA work 4 P^2 HD.  Per tile and wave: 65 MFMAs (1040 cycles), 64 ds_read_b128 (all four waves read the whole K and V^T tile: 256 KB
+// per tile and CU = 1024 cycles of the LDS), 64 KB of L2 -> LDS delivery, ~290 instructions of a wave that is alone on its SIMD: four
+// limits of the same size, each reached at about a third — the phases of a tile run one after the other in ONE wave per SIMD (364
+// registers: no second wave).  Measured 0.27-0.31 of the 2.5 PF peak.
 #include "dev.h"
 #include "kernels.h"
 #include <utility>
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(64 * VA_NW, 1) void vae_attention_kernel(const uint
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(src + 32 * ks);
     }
 
-    // ---- DMA of one key tile into a stage: wave w brings key rows KPW w .. and V^T blocks CPW w ..; three instructions per piece
+    // ---- DMA of a tile's K / V^T into a ring slot: wave w brings key rows KPW w .. and V^T blocks CPW w ..; three instructions per piece
     // (M0 <- LDS destination, the hazard nop, the DMA): per-lane offsets fixed, one scalar base per operand and tile.
     // K row k of the tile: LDS chunk `lane` <- global chunk lane ^ swz(k); HD 384: lanes 48..63 fill the unused quarter with a valid chunk
     uint32_t vo_k[KPW], vo_v[CPW];
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(64 * VA_NW, 1) void vae_attention_kernel(const uint
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const bf16x8*>(sp + v_x + (8 * b + i) * 1024);
     };
-    // S^T = K Q^T of the tile staged at `sp`; leaves the first V^T batch requested in fa when with_v
+    // S^T = K Q^T of the K tile staged at `sp`
     auto scores = [&](const uint8_t* sp, auto&& after_first_reads) VA_INLINE {
         read_k(sp, 0, fa);
         __builtin_amdgcn_sched_barrier(0);
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(64 * VA_NW, 1) void vae_attention_kernel(const uint
             }
         }, std::make_integer_sequence<int, NKB>{});
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 15" ::: "memory");      // the last two MFMAs' results are in s0 / s1
+        asm volatile("s_nop 15" : "+v"(s0), "+v"(s1));   // the last two MFMAs' results are in s0 / s1 (the operands tie every reader behind the wait states)
     };
     auto max8 = [&]() VA_INLINE -> float {
         return fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
