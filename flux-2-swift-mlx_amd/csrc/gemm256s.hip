@@ -589,10 +589,17 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                 // transposed one — and everything behind it (bias, residual, GroupNorm sums, rounding, stores) happens where lane
                 // l owns 8 consecutive columns (l & 7) of rows (l >> 3) and (l >> 3) + 8: a store instruction is 8 whole 128-byte runs.
                 const int tr = lane >> 3, tc = lane & 7;
-                float* const tile = reinterpret_cast<float*>(smem + 36864 + wid * 8704);            // 2 x [16][68] f32, behind the sums' 33 KB
-                constexpr int TP = 68;                                                              // pitch in floats (272 B)
-                float* const wr = tile + frow * TP + fq * 4;                                        // + jj * 16: block jj of the half
-                const float* const rd = tile + tr * TP + tc * 8;                                    // + t * 8 * TP: rows tr, tr + 8
+                float* const tile = reinterpret_cast<float*>(smem + 36864 + wid * 8704);            // 2 x [16][64] f32, behind the sums' 33 KB
+                // 16-byte chunk c of row r lives at chunk c ^ (r & 7) of a 256-byte row: conflict-free for BOTH access patterns (the padded
+                // pitch of 68 floats left the transposed reads 2-way on a third of their lane groups: SQ_LDS_BANK_CONFLICT 8 % of the
+                // 512 x 128 tile's LDS cycles, profiles/r05_m_vae_pmc_sq.txt).  The XOR only moves a lane's chunks among fixed slots: two
+                // base addresses per side (even / odd block of the write, first / second chunk of the read) and immediate offsets as before.
+                constexpr int TP = 64;                                                              // pitch in floats (256 B)
+                const int wsw = frow & 7, rsw = tr & 7;
+                float* const wr0 = tile + frow * TP + (((wsw >> 2) << 2) | (fq ^ (wsw & 3))) * 4;          // blocks jj = 0, 2: + jj * 16
+                float* const wr1 = tile + frow * TP + ((((wsw >> 2) ^ 1) << 2) | (fq ^ (wsw & 3))) * 4;    // blocks jj = 1, 3: + (jj - 1) * 16
+                const float* const rd0 = tile + tr * TP + ((2 * tc) ^ rsw) * 4;                     // + t * 8 * TP: rows tr, tr + 8 (same r & 7)
+                const float* const rd1 = tile + tr * TP + ((2 * tc + 1) ^ rsw) * 4;
                 // the lane's 2 NI rows (tr + 8 n of the wave's rows): pixel arithmetic once, incrementally (steps of 8 rows: one division)
                 uint32_t offC[2 * NI], offR[2 * NI];
                 uint32_t ibits = 0u, sbits = 0u;     // bit n = row n is an interior pixel / is stored
@@ -702,12 +709,14 @@ __global__ __launch_bounds__(256, 1) void gemm256s_kernel(GemmBatch batch) {
                     // block i is worked on
                     auto tile_w = [&](int i) GS_INLINE {
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4*>(wr + (i & 1) * (16 * TP) + jj * 16) = acc[i][4 * h + jj];
+                        for (int jj = 0; jj < 4; ++jj)
+                            *reinterpret_cast<f32x4*>(((jj & 1) ? wr1 : wr0) + (i & 1) * (16 * TP) + (jj & 2) * 16) = acc[i][4 * h + jj];
                     };
                     auto tile_r = [&](int i, f32x4 (&v)[4]) GS_INLINE {
-                        const float* r0 = rd + (i & 1) * (16 * TP);
-                        v[0] = *reinterpret_cast<const f32x4*>(r0); v[1] = *reinterpret_cast<const f32x4*>(r0 + 4);
-                        v[2] = *reinterpret_cast<const f32x4*>(r0 + 8 * TP); v[3] = *reinterpret_cast<const f32x4*>(r0 + 8 * TP + 4);
+                        const float* r0 = rd0 + (i & 1) * (16 * TP);
+                        const float* r1 = rd1 + (i & 1) * (16 * TP);
+                        v[0] = *reinterpret_cast<const f32x4*>(r0); v[1] = *reinterpret_cast<const f32x4*>(r1);
+                        v[2] = *reinterpret_cast<const f32x4*>(r0 + 8 * TP); v[3] = *reinterpret_cast<const f32x4*>(r1 + 8 * TP);
                     };
                     f32x4 cur[4], nxt[4];
                     tile_w(0);
