@@ -810,19 +810,21 @@ int run_gemm(flux2mi_dit* m, const GemmProblem* p_in, int n, int extra_cls, cons
     // gemm_splitk_ws_bytes says 0 for everything else, the 1024^2 shapes of every model among them)
     GemmProblem pw[2];
     const GemmProblem* p = p_in;
-    if (n <= 2 && !p_in[0].fp8 && (p_in[0].epi == EPI_GATE_RESID || p_in[0].epi == EPI_F32) && !p_in[0].splitk_ws) {
+    if (n <= 2 && (p_in[0].epi == EPI_GATE_RESID || p_in[0].epi == EPI_F32) && !p_in[0].splitk_ws) {
         size_t need[2] = {0, 0}, tot = 0;
         for (int i = 0; i < n; ++i) {
-            need[i] = (gemm_splitk_ws_bytes(p_in[i].M, p_in[i].N, p_in[i].K) + 255) & ~(size_t)255;
+            need[i] = (gemm_splitk_ws_bytes(p_in[i].M, p_in[i].N, p_in[i].K, p_in[i].fp8 != 0) + 255) & ~(size_t)255;
             tot += need[i];
         }
-        if (tot && need[0] && (n == 1 || need[1])) {
+        if (tot) {
             F2_TRY(m->splitk_ws.reserve(tot));
             size_t off = 0;
             for (int i = 0; i < n; ++i) {
                 pw[i] = p_in[i];
-                pw[i].splitk_ws = reinterpret_cast<float*>(m->splitk_ws.as<uint8_t>() + off);
-                pw[i].splitk_ws_bytes = need[i];
+                if (need[i]) {
+                    pw[i].splitk_ws = reinterpret_cast<float*>(m->splitk_ws.as<uint8_t>() + off);
+                    pw[i].splitk_ws_bytes = need[i];
+                }
                 off += need[i];
             }
             p = pw;

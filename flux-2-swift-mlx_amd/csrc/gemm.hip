@@ -386,12 +386,15 @@ static int gemm256s_splitk_plan(const GemmProblem* probs, int nprob, bool need_w
     int nk_min = 1 << 30;
     for (int i = 0; i < nprob; ++i) {
         const GemmProblem& q = probs[i];
-        if (q.fp8 || q.M <= 0 || q.N <= 0 || q.K <= 0 || q.K % 64 != 0 || !splitk_epi_ok(q.epi) || q.qk_qw || q.qk8 || q.col_perm16) return 1;
+        const int kt = q.fp8 ? 128 : 64;
+        if (q.M <= 0 || q.N <= 0 || q.K <= 0 || q.K % kt != 0 || !splitk_epi_ok(q.epi) || q.qk_qw || q.qk8 || q.col_perm16 || q.c2_q8) return 1;
+        if ((q.fp8 != 0) != (probs[0].fp8 != 0)) return 1;
+        if (q.fp8 && (q.epi == EPI_BF16 || q.epi == EPI_BIAS_BF16 || (!q.a_scale && !q.a_bscale) || !q.w_scale)) return 1;   // e4m3: the x += gate y and f32 launches
         if ((q.N & 3) || (q.ldc & 3) || (reinterpret_cast<uintptr_t>(q.C) & 15) || (q.vec && (reinterpret_cast<uintptr_t>(q.vec) & 15)) ||
             (q.resid && ((q.ldr & 3) || (reinterpret_cast<uintptr_t>(q.resid) & 7))))
             return 1;
         tiles += (long)((q.M + 255) / 256) * ((q.N + 255) / 256);
-        nk_min = q.K / 64 < nk_min ? q.K / 64 : nk_min;
+        nk_min = q.K / kt < nk_min ? q.K / kt : nk_min;
     }
     if (tiles > 128 || nk_min < 16) return 1;
     int s = GEMM_MAX_PROBS / nprob;
@@ -406,16 +409,117 @@ static int gemm256s_splitk_plan(const GemmProblem* probs, int nprob, bool need_w
         }
     return s < 2 ? 1 : s;
 }
-size_t gemm_splitk_ws_bytes(int M, int N, int K) {
-    const int s = gemm_splitk_plan(M, N, K);
-    size_t need = s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+// Tail split (launch_gemm): a single x += gate y problem whose 256-row tiles overflow ONE round of the chip by a little (Klein-9B's N = 4096
+// launches at S 4608: 18 x 16 = 288 tiles) would run as 160-row tiles on two rounds (464 tiles; for e4m3 operands those are bound by the
+// L2 -> LDS stream at 0.70-0.76 of MFMA issue).  Instead: the first floor(256 / tiles_n) row tiles as one launch of exactly one round of
+// 256-row tiles (0.90 of MFMA issue), the remaining rows as a split-K launch (above).  Returns the rows of the first launch, 0 = no split.
+static int gemm_tail_split_rows(int M, int N, int K, bool fp8) {
+    static const bool on = [] {
+        const char* e = F2_DEV_ENV("FLUX2MI_GEMM_TAIL");
+        return e ? atoi(e) != 0 : true;
+    }();
+    // bf16 only: with e4m3 operands the K ranges' f32 planes and the extra launches eat what the taller tiles give (measured on Klein-9B,
+    // same box: bf16 57.46 -> 56.17 ms per step, e4m3 35.30 -> 35.40: profiles/r06_p_tail_split_ab_same_box.txt)
+    if (!on || fp8 || M <= 0 || N <= 0 || (N & 255) || K / 64 < 32) return 0;
+    const long tiles_n = N / 256, tiles = (long)((M + 255) / 256) * tiles_n;
+    if (tiles <= 256 || tiles > 256 + 48) return 0;
+    const long rows_a = (256 / tiles_n) * 256;
+    if (rows_a <= 0 || rows_a >= M) return 0;
+    if ((long)((M - rows_a + 255) / 256) * tiles_n > 48) return 0;
+    return (int)rows_a;
+}
+size_t gemm_splitk_ws_bytes(int M, int N, int K, bool fp8) {
+    size_t need = 0;
+    if (!fp8) {
+        const int s = gemm_splitk_plan(M, N, K);
+        need = s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+    }
     // the 256x256 kernel's split-K: what a single-problem launch of this shape would take (a two-problem launch takes at most as much per problem)
     GemmProblem q;
     memset((void*)&q, 0, sizeof q);
-    q.M = M; q.N = N; q.K = K; q.epi = EPI_F32; q.ldc = N;
+    q.M = M; q.N = N; q.K = K; q.epi = EPI_F32; q.ldc = N; q.fp8 = fp8 ? 1 : 0;
+    static const float one = 1.0f;
+    if (fp8) { q.a_scale = &one; q.w_scale = &one; }   // (presence only: the plan does not read them)
+    const int rows_a = gemm_tail_split_rows(M, N, K, fp8);
+    if (rows_a) q.M = M - rows_a;                       // the tail split's second launch is what splits K
     const int s2 = gemm256s_splitk_plan(&q, 1, false);
-    if (s2 > 1 && (size_t)s2 * M * N * sizeof(float) > need) need = (size_t)s2 * M * N * sizeof(float);
+    if (s2 > 1 && (size_t)s2 * q.M * N * sizeof(float) > need) need = (size_t)s2 * q.M * N * sizeof(float);
     return need;
+}
+
+int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob);
+// split-K and the tail split on the 256x256 kernel (comments at gemm256s_splitk_plan / gemm_tail_split_rows): -1 = neither applies
+static int launch_gemm_splitk_or_tail(hipStream_t stream, const GemmProblem* probs, int nprob) {
+    // ---- tail split: x += gate y launches that overflow one round of 256-row tiles by a little
+    bool all_gr = true;
+    for (int i = 0; i < nprob; ++i) all_gr = all_gr && probs[i].epi == EPI_GATE_RESID && !probs[i].qk_qw && (probs[i].N & 255) == 0;
+    if (all_gr && nprob == 2) {
+        // the text / image pair of a double block: when the larger problem is one round on its own, the two go out as two launches
+        // (the smaller one then splits K below)
+        const long t0 = (long)((probs[0].M + 255) / 256) * (probs[0].N / 256), t1 = (long)((probs[1].M + 255) / 256) * (probs[1].N / 256);
+        const int big = t0 >= t1 ? 0 : 1;
+        const long tb = big ? t1 : t0, tsm = big ? t0 : t1;
+        static const bool on = [] {
+            const char* e = F2_DEV_ENV("FLUX2MI_GEMM_TAIL");
+            return e ? atoi(e) != 0 : true;
+        }();
+        if (on && !probs[0].fp8 && !probs[1].fp8 && tb + tsm > 256 && tb <= 256 && tb >= 224 && tsm <= 48 && probs[big].K / 64 >= 32 && probs[1 - big].splitk_ws) {
+            const int r = launch_gemm(stream, &probs[big], 1);
+            return r ? r : launch_gemm(stream, &probs[1 - big], 1);
+        }
+    }
+    if (all_gr && nprob == 1 && probs[0].splitk_ws) {
+        const GemmProblem& q = probs[0];
+        const int rows_a = gemm_tail_split_rows(q.M, q.N, q.K, q.fp8 != 0);
+        if (rows_a) {
+            const size_t esz = q.fp8 ? 1 : 2;
+            GemmProblem a = q, rr = q;
+            a.M = rows_a; a.splitk_ws = nullptr; a.splitk_ws_bytes = 0;
+            rr.M = q.M - rows_a;
+            rr.A = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(q.A) + (size_t)rows_a * q.lda * esz);
+            rr.C = reinterpret_cast<float*>(q.C) + (size_t)rows_a * q.ldc;
+            if (q.a_scale) rr.a_scale = q.a_scale + rows_a;
+            if (q.a_bscale) rr.a_bscale = q.a_bscale + rows_a / 16;
+            const int r = launch_gemm(stream, &a, 1);
+            return r ? r : launch_gemm(stream, &rr, 1);
+        }
+    }
+    // ---- split-K: few tiles, long K
+    const int sk = gemm256s_splitk_plan(probs, nprob, true);
+    if (sk <= 1) return -1;
+    GemmProblem sub[GEMM_MAX_PROBS];
+    int ns = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const GemmProblem& q = probs[i];
+        const int kt = q.fp8 ? 128 : 64;
+        const size_t esz = q.fp8 ? 1 : 2;
+        const int nk = q.K / kt, chunk = (nk + sk - 1) / sk;
+        for (int j = 0; j < sk; ++j) {
+            const int k0 = j * chunk, k1 = (j + 1) * chunk < nk ? (j + 1) * chunk : nk;
+            GemmProblem& t = sub[ns++];
+            memset((void*)&t, 0, sizeof t);
+            t.A = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(q.A) + (size_t)k0 * kt * esz); t.lda = q.lda;
+            t.W = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(q.W) + (size_t)k0 * kt * esz); t.ldw = q.ldw;
+            t.C = q.splitk_ws + (size_t)j * q.M * q.N; t.ldc = q.N;
+            t.M = q.M; t.N = q.N; t.K = (k1 > k0 ? k1 - k0 : 0) * kt;
+            t.epi = EPI_F32; t.alpha = 1.0f;
+            // e4m3 operands: the partial accumulators leave with their scales applied (per row / per column factors, or the block scales
+            // inside the MFMA: one table row per K-tile) — the planes then add like the bf16 ones
+            t.fp8 = q.fp8; t.a_scale = q.a_scale; t.w_scale = q.w_scale;
+            t.a_bscale = q.a_bscale ? q.a_bscale + (size_t)k0 * q.a_bscale_ld : nullptr; t.a_bscale_ld = q.a_bscale_ld;
+        }
+    }
+    bool ok = gemm256s_eligible(sub, ns);
+    for (int i = 0; i < ns; ++i) ok = ok && sub[i].K > 0;
+    if (!ok) return -1;
+    const int r = launch_gemm256s(stream, sub, ns);
+    if (r != 0) return r;
+    for (int i = 0; i < nprob; ++i) {
+        const long total4 = (long)probs[i].M * (probs[i].N >> 2);
+        const unsigned blocks = (unsigned)((total4 + 255) / 256 > 4096 ? 4096 : (total4 + 255) / 256);
+        hipLaunchKernelGGL(gemm_splitk_reduce4_kernel, dim3(blocks), dim3(256), 0, stream, probs[i], sk);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
 int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
@@ -438,6 +542,10 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
                             (p.c2_q8_ld & 7) || (reinterpret_cast<uintptr_t>(p.c2_q8) & 7)))
                 return 1;
         }
+        {
+            const int r = launch_gemm_splitk_or_tail(stream, probs, nprob);
+            if (r >= 0) return r;
+        }
         // the one-wave-per-SIMD kernel (gemm256s.hip)
         return gemm256s_eligible(probs, nprob) ? launch_gemm256s(stream, probs, nprob) : 1;
     }
@@ -456,39 +564,9 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob) {
         }
         return hipGetLastError() == hipSuccess ? 0 : 2;
     }
-    // few tiles, long K: split-K on the 256x256 kernel (above)
     {
-        const int sk = gemm256s_splitk_plan(probs, nprob, true);
-        if (sk > 1) {
-            GemmProblem sub[GEMM_MAX_PROBS];
-            int ns = 0;
-            for (int i = 0; i < nprob; ++i) {
-                const GemmProblem& q = probs[i];
-                const int nk = q.K / 64, chunk = (nk + sk - 1) / sk;
-                for (int j = 0; j < sk; ++j) {
-                    const int k0 = j * chunk, k1 = (j + 1) * chunk < nk ? (j + 1) * chunk : nk;
-                    GemmProblem& t = sub[ns++];
-                    memset((void*)&t, 0, sizeof t);
-                    t.A = q.A + (size_t)k0 * 64; t.lda = q.lda;
-                    t.W = q.W + (size_t)k0 * 64; t.ldw = q.ldw;
-                    t.C = q.splitk_ws + (size_t)j * q.M * q.N; t.ldc = q.N;
-                    t.M = q.M; t.N = q.N; t.K = (k1 > k0 ? k1 - k0 : 0) * 64;
-                    t.epi = EPI_F32; t.alpha = 1.0f;
-                }
-            }
-            bool ok = gemm256s_eligible(sub, ns);
-            for (int i = 0; i < ns; ++i) ok = ok && sub[i].K > 0;
-            if (ok) {
-                const int r = launch_gemm256s(stream, sub, ns);
-                if (r != 0) return r;
-                for (int i = 0; i < nprob; ++i) {
-                    const long total4 = (long)probs[i].M * (probs[i].N >> 2);
-                    const unsigned blocks = (unsigned)((total4 + 255) / 256 > 4096 ? 4096 : (total4 + 255) / 256);
-                    hipLaunchKernelGGL(gemm_splitk_reduce4_kernel, dim3(blocks), dim3(256), 0, stream, probs[i], sk);
-                }
-                return hipGetLastError() == hipSuccess ? 0 : 2;
-            }
-        }
+        const int r = launch_gemm_splitk_or_tail(stream, probs, nprob);
+        if (r >= 0) return r;
     }
     // large problems -> 256x256 LDS-DMA kernel (gemm256s.hip); FLUX2MI_GEMM=128|256 forces a kernel
     {

@@ -117,7 +117,7 @@ int launch_gemm(hipStream_t stream, const GemmProblem* probs, int nprob);
 // GEMM rows per tile launch_gemm will use for these EPI_CONV problems: GemmProblem::gn_part has ceil(M / rows) rows per problem
 int gemm256s_conv_tile_rows(const GemmProblem* probs, int nprob);
 // Workspace launch_gemm wants in GemmProblem::splitk_ws to split the K dimension of a bf16 [M,K] x [N,K]^T product (0 = it would not split)
-size_t gemm_splitk_ws_bytes(int M, int N, int K);
+size_t gemm_splitk_ws_bytes(int M, int N, int K, bool fp8 = false);
 
 // ---------------------------------------------------------------- attention (attention.hip)
 // Joint (text+image) non-causal attention, head_dim 128, bf16 in/out, f32 softmax.
