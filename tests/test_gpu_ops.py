@@ -266,6 +266,8 @@ def test_gemm_race_screen(ctx):
     (4608, 4096, 4096),    # Klein-9B width (tile height 160)
     (100, 512, 256),       # every tile partial in M: the transposed-domain epilogue's predicated form only
     (4645, 3072, 3072),    # whole tiles (residual requested a batch ahead) and a last row of tiles with 37 rows
+    (4608, 4096, 4096),    # Klein-9B's N = d launches: 288 tiles of 256 rows = the tail split (one round of 256 tiles + a K split of the last 512 rows)
+    (768, 3072, 12288),    # linear2 at 256^2: 36 tiles, split-K into 7 ranges on the 256 x 256 kernel
 ])
 def test_gemm_gate_resid_exact(ctx, M, N, K):
     """x += gate * (A W^T) on integer-valued data (every partial sum exact in f32): bit-exact against
